@@ -1,0 +1,9 @@
+"""alchemy_amd -- MI355X (gfx950) ciphertext-arithmetic backend for ALCHEMY's PT2CT-lowered evaluator.
+
+The product is the C-ABI shared library ``alchemy_amd/lib/libalchemy_hip.so`` (sources in
+``alchemy_amd/csrc``, interface in ``include/alchemy_hip.h``).  This package is the thin ctypes binding
+used by the tests and bench.py plus the host-side mirror of the SymmSHE operations ALCHEMY's evaluator
+calls (``alchemy_amd.symmshe``).  There is no CPU fallback: importing works anywhere, but every compute
+call raises unless the HIP library is built and a gfx950 device is present.
+"""
+from .capi import AlchemyError, Buf, Hint, Ring, lib_path, load_library  # noqa: F401

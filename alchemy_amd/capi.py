@@ -1,0 +1,292 @@
+"""ctypes binding of include/alchemy_hip.h.  One Python method per C entry point; numpy int64 arrays of
+shape (count, n, L) stand for host buffers in Lol's tuple-interleaved layout."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+ALCH_OK = 0
+ALCH_E_INVALID, ALCH_E_NOT_PRIME, ALCH_E_NO_CRT, ALCH_E_UNSUPPORTED = -1, -2, -3, -4
+ALCH_E_NO_DEVICE, ALCH_E_HIP, ALCH_E_NOMEM = -5, -6, -7
+ALCH_POW_IN, ALCH_POW_OUT = 1, 2
+ALCH_GAD_TRIV, ALCH_GAD_BASE2 = 0, 1
+
+# every symbol include/alchemy_hip.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "alch_last_error", "alch_version", "alch_ring_create", "alch_ring_destroy", "alch_host_root", "alch_ring_n",
+    "alch_ring_set_stream", "alch_sync", "alch_timer_start", "alch_timer_stop", "alch_crt", "alch_crtinv",
+    "alch_mul", "alch_add", "alch_sub", "alch_scale", "alch_mulg_pow", "alch_mulg_dec", "alch_mulg_crt",
+    "alch_divg_pow", "alch_divg_dec", "alch_divg_crt", "alch_decompose_triv", "alch_buf_alloc", "alch_buf_free",
+    "alch_buf_elems", "alch_buf_upload", "alch_buf_download", "alch_buf_fill_uniform", "alch_buf_crt",
+    "alch_buf_crtinv", "alch_buf_mul", "alch_buf_add", "alch_buf_checksum", "alch_hint_load", "alch_hint_from_buf",
+    "alch_hint_free", "alch_ct_mul_relin", "alch_buf_rescale_drop0",
+]
+
+
+class AlchemyError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"alchemy_hip error {code}: {msg}")
+        self.code = code
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "lib", "libalchemy_hip.so")
+
+
+_lib = None
+
+
+def load_library():
+    """Load the HIP library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise AlchemyError(ALCH_E_NO_DEVICE, f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)")
+    l = C.CDLL(path)
+    P64, PU64, VP = C.POINTER(C.c_int64), C.POINTER(C.c_uint64), C.c_void_p
+    l.alch_last_error.restype = C.c_char_p
+    l.alch_version.restype = C.c_uint32
+    sig = {
+        "alch_ring_create": [C.c_uint32, C.c_int, PU64, C.POINTER(VP)],
+        "alch_ring_destroy": [VP],
+        "alch_host_root": [C.c_uint32, C.c_uint64, PU64, PU64],
+        "alch_ring_n": [VP, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "alch_ring_set_stream": [VP, VP],
+        "alch_sync": [VP],
+        "alch_timer_start": [VP],
+        "alch_timer_stop": [VP, C.POINTER(C.c_float)],
+        "alch_crt": [VP, P64], "alch_crtinv": [VP, P64],
+        "alch_mul": [VP, P64, P64], "alch_add": [VP, P64, P64], "alch_sub": [VP, P64, P64],
+        "alch_scale": [VP, P64, PU64],
+        "alch_mulg_pow": [VP, P64], "alch_mulg_dec": [VP, P64], "alch_mulg_crt": [VP, P64],
+        "alch_divg_pow": [VP, P64], "alch_divg_dec": [VP, P64], "alch_divg_crt": [VP, P64],
+        "alch_decompose_triv": [VP, P64, P64],
+        "alch_buf_alloc": [VP, C.c_size_t, C.POINTER(VP)],
+        "alch_buf_free": [VP],
+        "alch_buf_elems": [VP, C.POINTER(C.c_size_t)],
+        "alch_buf_upload": [VP, C.c_size_t, C.c_size_t, P64],
+        "alch_buf_download": [VP, C.c_size_t, C.c_size_t, P64],
+        "alch_buf_fill_uniform": [VP, C.c_uint64],
+        "alch_buf_crt": [VP, C.c_size_t, C.c_size_t],
+        "alch_buf_crtinv": [VP, C.c_size_t, C.c_size_t],
+        "alch_buf_mul": [VP, VP, VP, C.c_size_t],
+        "alch_buf_add": [VP, VP, VP, C.c_size_t],
+        "alch_buf_checksum": [VP, C.c_size_t, C.c_size_t, PU64],
+        "alch_hint_load": [VP, C.c_int, P64, C.POINTER(VP)],
+        "alch_hint_from_buf": [VP, C.c_int, VP, C.POINTER(VP)],
+        "alch_hint_free": [VP],
+        "alch_ct_mul_relin": [VP, VP, VP, VP, VP, C.c_size_t, PU64, C.c_uint],
+        "alch_buf_rescale_drop0": [VP, VP, C.c_size_t],
+    }
+    for name, args in sig.items():
+        fn = getattr(l, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    _lib = l
+    return l
+
+
+def _check(rc: int):
+    if rc < 0:
+        raise AlchemyError(rc, load_library().alch_last_error().decode())
+    return rc
+
+
+def _p64(a: np.ndarray):
+    assert a.dtype == np.int64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def _pu64(vals):
+    arr = (C.c_uint64 * len(vals))(*[int(v) for v in vals])
+    return arr
+
+
+def host_root(m: int, q: int):
+    """(psi, generator) of the root rule; host-only, needs no GPU."""
+    psi, g = C.c_uint64(), C.c_uint64()
+    _check(load_library().alch_host_root(m, q, C.byref(psi), C.byref(g)))
+    return int(psi.value), int(g.value)
+
+
+class Ring:
+    """alch_ring: one (cyclotomic index, RNS modulus list) context, i.e. one `Cyc t m' zq` type."""
+
+    def __init__(self, m: int, qs):
+        self._l = load_library()
+        self.m, self.n, self.qs, self.L = int(m), int(m) // 2, [int(q) for q in qs], len(qs)
+        h = C.c_void_p()
+        _check(self._l.alch_ring_create(self.m, self.L, _pu64(self.qs), C.byref(h)))
+        self._h = h
+        w = C.c_int()
+        _check(self._l.alch_ring_n(self._h, None, None, C.byref(w)))
+        self.word_bytes = int(w.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.alch_ring_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- stream / timing
+    def set_stream(self, hip_stream: int):
+        _check(self._l.alch_ring_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def sync(self):
+        _check(self._l.alch_sync(self._h))
+
+    def timer_start(self):
+        _check(self._l.alch_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        _check(self._l.alch_timer_stop(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    # --- Tensor methods on host buffers (shape (n, L) int64, returns a new array)
+    def _host1(self, fn, a):
+        out = np.ascontiguousarray(a, dtype=np.int64).copy()
+        assert out.shape == (self.n, self.L), out.shape
+        _check(fn(self._h, _p64(out)))
+        return out
+
+    def _host2(self, fn, a, b):
+        out = np.ascontiguousarray(a, dtype=np.int64).copy()
+        bb = np.ascontiguousarray(b, dtype=np.int64)
+        assert out.shape == bb.shape == (self.n, self.L)
+        _check(fn(self._h, _p64(out), _p64(bb)))
+        return out
+
+    def crt(self, a): return self._host1(self._l.alch_crt, a)
+    def crtinv(self, a): return self._host1(self._l.alch_crtinv, a)
+    def mul(self, a, b): return self._host2(self._l.alch_mul, a, b)
+    def add(self, a, b): return self._host2(self._l.alch_add, a, b)
+    def sub(self, a, b): return self._host2(self._l.alch_sub, a, b)
+    def mulg_pow(self, a): return self._host1(self._l.alch_mulg_pow, a)
+    def mulg_dec(self, a): return self._host1(self._l.alch_mulg_dec, a)
+    def mulg_crt(self, a): return self._host1(self._l.alch_mulg_crt, a)
+    def divg_pow(self, a): return self._host1(self._l.alch_divg_pow, a)
+    def divg_dec(self, a): return self._host1(self._l.alch_divg_dec, a)
+    def divg_crt(self, a): return self._host1(self._l.alch_divg_crt, a)
+
+    def scale(self, a, s):
+        out = np.ascontiguousarray(a, dtype=np.int64).copy()
+        _check(self._l.alch_scale(self._h, _p64(out), _pu64(s)))
+        return out
+
+    def decompose_triv(self, c_pow):
+        c = np.ascontiguousarray(c_pow, dtype=np.int64)
+        out = np.zeros((self.L, self.n, self.L), dtype=np.int64)
+        _check(self._l.alch_decompose_triv(self._h, _p64(c), _p64(out)))
+        return [out[i] for i in range(self.L)]
+
+    # --- device-resident
+    def alloc(self, n_elems: int) -> "Buf":
+        return Buf(self, n_elems)
+
+    def upload(self, host) -> "Buf":
+        host = np.ascontiguousarray(host, dtype=np.int64)
+        assert host.ndim == 3 and host.shape[1:] == (self.n, self.L)
+        b = Buf(self, host.shape[0])
+        b.upload(host)
+        return b
+
+    def hint_load(self, host_crt, gadget: int = ALCH_GAD_TRIV) -> "Hint":
+        host = np.ascontiguousarray(host_crt, dtype=np.int64)
+        assert host.shape == (2 * self.L, self.n, self.L)
+        h = C.c_void_p()
+        _check(self._l.alch_hint_load(self._h, gadget, _p64(host), C.byref(h)))
+        return Hint(self, h)
+
+    def hint_from_buf(self, buf: "Buf", gadget: int = ALCH_GAD_TRIV) -> "Hint":
+        h = C.c_void_p()
+        _check(self._l.alch_hint_from_buf(self._h, gadget, buf._h, C.byref(h)))
+        return Hint(self, h)
+
+    def ct_mul_relin(self, hint: "Hint", a: "Buf", b: "Buf", out: "Buf", batch: int, s_pre=None, flags: int = 0):
+        sp = _pu64(s_pre) if s_pre is not None else None
+        _check(self._l.alch_ct_mul_relin(self._h, hint._h, a._h, b._h, out._h, batch, sp, flags))
+
+
+class Buf:
+    """alch_buf: device-resident array of ring elements (limb-major, 32- or 64-bit words)."""
+
+    def __init__(self, ring: Ring, n_elems: int):
+        self.ring, self.n_elems = ring, int(n_elems)
+        h = C.c_void_p()
+        _check(ring._l.alch_buf_alloc(ring._h, self.n_elems, C.byref(h)))
+        self._h = h
+
+    def free(self):
+        if getattr(self, "_h", None):
+            self.ring._l.alch_buf_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def upload(self, host, first: int = 0):
+        host = np.ascontiguousarray(host, dtype=np.int64)
+        _check(self.ring._l.alch_buf_upload(self._h, first, host.shape[0], _p64(host)))
+
+    def download(self, first: int = 0, count: int | None = None):
+        count = self.n_elems - first if count is None else count
+        out = np.zeros((count, self.ring.n, self.ring.L), dtype=np.int64)
+        _check(self.ring._l.alch_buf_download(self._h, first, count, _p64(out)))
+        return out
+
+    def fill_uniform(self, seed: int):
+        _check(self.ring._l.alch_buf_fill_uniform(self._h, C.c_uint64(seed)))
+
+    def crt(self, first: int = 0, count: int | None = None):
+        _check(self.ring._l.alch_buf_crt(self._h, first, self.n_elems - first if count is None else count))
+
+    def crtinv(self, first: int = 0, count: int | None = None):
+        _check(self.ring._l.alch_buf_crtinv(self._h, first, self.n_elems - first if count is None else count))
+
+    def mul(self, a: "Buf", b: "Buf", count: int):
+        _check(self.ring._l.alch_buf_mul(self._h, a._h, b._h, count))
+
+    def add(self, a: "Buf", b: "Buf", count: int):
+        _check(self.ring._l.alch_buf_add(self._h, a._h, b._h, count))
+
+    def checksum(self, first: int = 0, count: int | None = None) -> int:
+        s = C.c_uint64()
+        _check(self.ring._l.alch_buf_checksum(self._h, first, self.n_elems - first if count is None else count, C.byref(s)))
+        return int(s.value)
+
+    def rescale_drop0_into(self, dst: "Buf", count: int):
+        _check(self.ring._l.alch_buf_rescale_drop0(self._h, dst._h, count))
+
+
+class Hint:
+    """alch_hint: device-resident KSQuadCircHint (Montgomery form)."""
+
+    def __init__(self, ring: Ring, handle):
+        self.ring, self._h = ring, handle
+
+    def free(self):
+        if getattr(self, "_h", None):
+            self.ring._l.alch_hint_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

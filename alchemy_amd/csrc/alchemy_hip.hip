@@ -1,0 +1,786 @@
+// C ABI of the MI355X ciphertext-arithmetic backend (see include/alchemy_hip.h) and the element-wise
+// kernels around the LDS-resident transforms of kernels_ntt.hpp.
+//
+// No CPU fallback lives here: every compute entry point needs a gfx950 device and reports
+// ALCH_E_NO_DEVICE / ALCH_E_HIP otherwise.  Nothing in this library includes or links oracle/.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/alchemy_hip.h"
+#include "kernels_ntt.hpp"
+#include "ring_host.hpp"
+
+using namespace alch;
+
+// ------------------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------------------
+struct alch_ring {
+    u32 m = 0, n = 0;
+    int logn = 0, L = 0, word = 0;            // word = 4 or 8 bytes per residue on the device
+    u64 q[MAXL] = {0};
+    bool balanced = false;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void* tables = nullptr;                    // all twiddle tables, one allocation
+    DevRing<u32> d32;
+    DevRing<u64> d64;
+    void* ws_digits = nullptr;                 // digit scratch [chunk][L][n] signed words
+    size_t ws_digits_bytes = 0;
+    void* ws_in = nullptr;                     // crt scratch for ALCH_POW_IN (2 * 2*batch elements)
+    size_t ws_in_bytes = 0;
+    void* ws_host = nullptr;                   // staging for the host-buffer Tensor methods
+    size_t ws_host_bytes = 0;
+    u64* ws_sum = nullptr;                     // checksum accumulator
+    size_t chunk = 256;                        // ciphertexts per (tensor_intt, ks_accum) launch pair
+};
+
+struct alch_buf {
+    alch_ring* ring;
+    size_t n_elems;
+    void* dptr;
+};
+
+struct alch_hint {
+    alch_ring* ring;
+    int gadget;
+    int digits;
+    void* dptr;                                // [digit][2][L][n] words, Montgomery form
+};
+
+// ------------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            return fail(ALCH_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+    } while (0)
+
+extern "C" const char* alch_last_error(void) { return g_err.c_str(); }
+extern "C" uint32_t alch_version(void) { return (1u << 16) | 0u; }
+
+// ------------------------------------------------------------------------------------------------------
+// element-wise kernels (HBM-bound; 16 B per lane, grid-stride, ~2048 workgroups)
+// ------------------------------------------------------------------------------------------------------
+__host__ __device__ static inline u64 splitmix64(u64 x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+template <typename W>
+__global__ void k_fill_uniform(DevRing<W> R, W* data, size_t words, u64 seed) {
+    const size_t n = (size_t)1 << R.logn;
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < words; w += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)((w / n) % (size_t)R.L);
+        data[w] = (W)(splitmix64(seed + w) % (u64)R.mod[j].q);
+    }
+}
+
+// Lol's tuple-interleaved int64 (coefficient-major, limb-minor) <-> limb-major device words.
+template <typename W, bool TO_DEVICE>
+__global__ void k_transpose(DevRing<W> R, W* dev, int64_t* host, size_t elems) {
+    const size_t n = (size_t)1 << R.logn;
+    const size_t L = (size_t)R.L;
+    const size_t total = elems * L * n;
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < total; w += (size_t)gridDim.x * blockDim.x) {
+        const size_t k = w % n, j = (w / n) % L, e = w / (n * L);
+        const size_t h = (e * n + k) * L + j;
+        if (TO_DEVICE) dev[w] = (W)(u64)host[h];
+        else host[h] = (int64_t)(u64)dev[w];
+    }
+}
+
+enum PwOp { PW_MUL = 0, PW_ADD = 1, PW_SUB = 2 };
+
+template <typename W, int OP>
+__global__ void k_pointwise(DevRing<W> R, W* dst, const W* a, const W* b, size_t words) {
+    const size_t n = (size_t)1 << R.logn;
+    typedef typename Vec4<W>::type V;
+    constexpr int VL = Vec4<W>::LANES;
+    const size_t nv = words / VL;
+    for (size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x; v < nv; v += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(((v * VL) / n) % (size_t)R.L);
+        const ModP<W> m = R.mod[j];
+        V x = reinterpret_cast<const V*>(a)[v], y = reinterpret_cast<const V*>(b)[v], z;
+#pragma unroll
+        for (int e = 0; e < VL; ++e) {
+            if (OP == PW_MUL) z[e] = mont_mul(mont_mul(x[e], m.r2, m), y[e], m);
+            else if (OP == PW_ADD) z[e] = add_mod(x[e], y[e], m.q);
+            else z[e] = sub_mod(x[e], y[e], m.q);
+        }
+        reinterpret_cast<V*>(dst)[v] = z;
+    }
+}
+
+// dst = src * s_j (mod q_j); sm[j] = s_j in Montgomery form.  TO_MONT callers pass sm = R^2 mod q.
+template <typename W>
+__global__ void k_scale(DevRing<W> R, W* dst, const W* src, size_t words, Scal<W> sm) {
+    const size_t n = (size_t)1 << R.logn;
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < words; w += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)((w / n) % (size_t)R.L);
+        dst[w] = mont_mul(src[w], sm.v[j], R.mod[j]);
+    }
+}
+
+// TrivGad decompose + reduce on one Pow-basis element: digits[i] (limb-major element i) limb j =
+// centred(c limb i) mod q_j.
+template <typename W>
+__global__ void k_decompose_triv(DevRing<W> R, const W* c, W* digits) {
+    typedef typename Signed<W>::type SW;
+    const size_t n = (size_t)1 << R.logn;
+    const size_t L = (size_t)R.L;
+    const size_t total = L * L * n;
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < total; w += (size_t)gridDim.x * blockDim.x) {
+        const size_t k = w % n, j = (w / n) % L, i = w / (n * L);
+        const W qi = R.mod[i].q, qj = R.mod[j].q;
+        const W v = c[i * n + k];
+        const SW z = v > ((qi - 1) >> 1) ? (SW)v - (SW)qi : (SW)v;
+        SW r = z % (SW)qj;
+        if (r < 0) r += (SW)qj;
+        digits[w] = (W)r;
+    }
+}
+
+// Rescale (a,b) -> b: dst limb j-1 = q_0^-1 (src_j - reduce(lift src_0)).  q0inv_m[j] = q_0^-1 mod q_j (Montgomery).
+template <typename W>
+__global__ void k_rescale_drop0(DevRing<W> R, const W* src, W* dst, size_t elems, Scal<W> q0inv_m) {
+    typedef typename Signed<W>::type SW;
+    const size_t n = (size_t)1 << R.logn;
+    const size_t L = (size_t)R.L;
+    const size_t total = elems * (L - 1) * n;
+    const W q0 = R.mod[0].q;
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < total; w += (size_t)gridDim.x * blockDim.x) {
+        const size_t k = w % n, jm = (w / n) % (L - 1), e = w / (n * (L - 1));
+        const size_t j = jm + 1;
+        const ModP<W> m = R.mod[j];
+        const W x0 = src[(e * L) * n + k];
+        const SW z = x0 > ((q0 - 1) >> 1) ? (SW)x0 - (SW)q0 : (SW)x0;
+        SW zr = z % (SW)m.q;
+        if (zr < 0) zr += (SW)m.q;
+        const W d = sub_mod(src[(e * L + j) * n + k], (W)zr, m.q);
+        dst[w] = mont_mul(d, q0inv_m.v[j], m);
+    }
+}
+
+template <typename W>
+__global__ void k_checksum(const W* data, size_t words, u64* sum) {
+    u64 acc = 0;
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < words; w += (size_t)gridDim.x * blockDim.x)
+        acc += splitmix64((u64)w ^ ((u64)data[w] << 20));
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)sum, (unsigned long long)acc);
+}
+
+static inline unsigned ew_grid(size_t items) {
+    size_t g = (items + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// ring construction
+// ------------------------------------------------------------------------------------------------------
+template <typename W>
+static int build_dev_ring(alch_ring* r, DevRing<W>& d) {
+    const size_t n = r->n;
+    const int L = r->L;
+    std::vector<W> all(2 * (size_t)L * n);
+    HIP_TRY(hipMalloc(&r->tables, all.size() * sizeof(W)));
+    memset(&d, 0, sizeof d);
+    d.L = L;
+    d.logn = r->logn;
+    u64 maxhalf = 0;
+    for (int j = 0; j < L; ++j) maxhalf = std::max(maxhalf, (r->q[j] - 1) / 2);
+    for (int j = 0; j < L; ++j) {
+        const u64 q = r->q[j];
+        d.mod[j] = make_modp<W>(q);
+        const u64 psi = h_root(q, r->m);
+        std::vector<W> f, inv;
+        h_build_twiddles<W>(q, psi, r->logn, f, inv);
+        memcpy(&all[(size_t)(2 * j) * n], f.data(), n * sizeof(W));
+        memcpy(&all[(size_t)(2 * j + 1) * n], inv.data(), n * sizeof(W));
+        d.twf[j] = reinterpret_cast<W*>(r->tables) + (size_t)(2 * j) * n;
+        d.twi[j] = reinterpret_cast<W*>(r->tables) + (size_t)(2 * j + 1) * n;
+        const u64 ninv = h_powmod(n % q, q - 2, q);
+        const u64 r1 = d.mod[j].r1;
+        d.ninv_m[j] = (W)h_mulmod(ninv, r1, q);
+        // inv[1] is tw^-1[1] * R; times n^-1 stays in Montgomery form
+        d.w1ninv_m[j] = (W)h_mulmod((u64)inv[1], ninv, q);
+        d.dig_off[j] = (W)(((maxhalf + q - 1) / q) * q);
+    }
+    HIP_TRY(hipMemcpy(r->tables, all.data(), all.size() * sizeof(W), hipMemcpyHostToDevice));
+    return ALCH_OK;
+}
+
+static int validate_ring_args(uint32_t m, int L, const uint64_t* q, int* logn_out, int* word_out) {
+    if (!q || L < 1 || L > MAXL) return fail(ALCH_E_INVALID, "alch_ring_create: need 1 <= L <= 8 moduli");
+    if (m < 32 || (m & (m - 1))) return fail(ALCH_E_UNSUPPORTED, "cyclotomic index must be a power of two >= 32");
+    int logn = 0;
+    while ((1u << logn) < m / 2) ++logn;
+    bool all32 = true;
+    for (int j = 0; j < L; ++j) {
+        if (q[j] >= (1ull << 62)) return fail(ALCH_E_UNSUPPORTED, "modulus must be below 2^62");
+        if (q[j] >= (1ull << 31)) all32 = false;
+        if (q[j] < 3 || !h_is_prime(q[j])) return fail(ALCH_E_NOT_PRIME, "modulus " + std::to_string(q[j]) + " is not prime");
+        if ((q[j] - 1) % m) return fail(ALCH_E_NO_CRT, "modulus " + std::to_string(q[j]) + " is not 1 mod m: no CRT basis (Lol: crtFuncs = Nothing)");
+        for (int i = 0; i < j; ++i)
+            if (q[i] == q[j]) return fail(ALCH_E_INVALID, "RNS moduli must be distinct");
+    }
+    const int word = all32 ? 4 : 8;
+    const int maxlog = all32 ? 15 : 14;
+    if (logn > maxlog) return fail(ALCH_E_UNSUPPORTED, "ring dimension exceeds one LDS-resident transform (n <= 2^15 for 32-bit, 2^14 for 64-bit residues)");
+    *logn_out = logn;
+    *word_out = word;
+    return ALCH_OK;
+}
+
+extern "C" int alch_host_root(uint32_t m, uint64_t q, uint64_t* psi, uint64_t* generator) {
+    if (m < 2 || (m & (m - 1)) || q < 3 || !h_is_prime(q)) return fail(ALCH_E_INVALID, "alch_host_root: bad (m, q)");
+    if ((q - 1) % m) return fail(ALCH_E_NO_CRT, "q is not 1 mod m");
+    if (generator) *generator = h_smallest_generator(q);
+    if (psi) *psi = h_root(q, m);
+    return ALCH_OK;
+}
+
+extern "C" int alch_ring_create(uint32_t m, int L, const uint64_t* q, alch_ring** out) {
+    if (!out) return fail(ALCH_E_INVALID, "alch_ring_create: null out");
+    *out = nullptr;
+    int logn = 0, word = 0;
+    int rc = validate_ring_args(m, L, q, &logn, &word);
+    if (rc != ALCH_OK) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(ALCH_E_NO_DEVICE, "no HIP device: this backend has no CPU fallback");
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+        return fail(ALCH_E_NO_DEVICE, "cannot query HIP device");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(ALCH_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+
+    alch_ring* r = new alch_ring();
+    r->m = m;
+    r->n = m / 2;
+    r->logn = logn;
+    r->L = L;
+    r->word = word;
+    for (int j = 0; j < L; ++j) r->q[j] = q[j];
+    u64 qmin = ~0ull, qmax = 0;
+    for (int j = 0; j < L; ++j) { qmin = std::min(qmin, q[j]); qmax = std::max(qmax, q[j]); }
+    r->balanced = (qmax - 1) / 2 < qmin;
+    if (const char* c = getenv("ALCH_CHUNK")) {
+        long v = atol(c);
+        if (v >= 8) r->chunk = (size_t)v;
+    }
+    hipError_t e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete r; return fail(ALCH_E_HIP, "hipStreamCreate failed"); }
+    r->own_stream = true;
+    if (hipEventCreate(&r->ev0) != hipSuccess || hipEventCreate(&r->ev1) != hipSuccess) { delete r; return fail(ALCH_E_HIP, "hipEventCreate failed"); }
+    if (hipMalloc((void**)&r->ws_sum, sizeof(u64)) != hipSuccess) { delete r; return fail(ALCH_E_NOMEM, "hipMalloc failed"); }
+    rc = (word == 4) ? build_dev_ring<u32>(r, r->d32) : build_dev_ring<u64>(r, r->d64);
+    if (rc != ALCH_OK) { alch_ring_destroy(r); return rc; }
+    *out = r;
+    return ALCH_OK;
+}
+
+extern "C" int alch_ring_destroy(alch_ring* r) {
+    if (!r) return ALCH_OK;
+    if (r->stream) (void)hipStreamSynchronize(r->stream);
+    if (r->tables) (void)hipFree(r->tables);
+    if (r->ws_digits) (void)hipFree(r->ws_digits);
+    if (r->ws_in) (void)hipFree(r->ws_in);
+    if (r->ws_host) (void)hipFree(r->ws_host);
+    if (r->ws_sum) (void)hipFree(r->ws_sum);
+    if (r->ev0) (void)hipEventDestroy(r->ev0);
+    if (r->ev1) (void)hipEventDestroy(r->ev1);
+    if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
+    return ALCH_OK;
+}
+
+extern "C" int alch_ring_n(const alch_ring* r, uint32_t* n, int* L, int* word_bytes) {
+    if (!r) return fail(ALCH_E_INVALID, "null ring");
+    if (n) *n = r->n;
+    if (L) *L = r->L;
+    if (word_bytes) *word_bytes = r->word;
+    return ALCH_OK;
+}
+
+extern "C" int alch_ring_set_stream(alch_ring* r, void* s) {
+    if (!r) return fail(ALCH_E_INVALID, "null ring");
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
+    r->stream = (hipStream_t)s;
+    r->own_stream = false;
+    return ALCH_OK;
+}
+
+extern "C" int alch_sync(alch_ring* r) {
+    if (!r) return fail(ALCH_E_INVALID, "null ring");
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return ALCH_OK;
+}
+
+extern "C" int alch_timer_start(alch_ring* r) {
+    if (!r) return fail(ALCH_E_INVALID, "null ring");
+    HIP_TRY(hipEventRecord(r->ev0, r->stream));
+    return ALCH_OK;
+}
+
+extern "C" int alch_timer_stop(alch_ring* r, float* ms) {
+    if (!r || !ms) return fail(ALCH_E_INVALID, "null argument");
+    HIP_TRY(hipEventRecord(r->ev1, r->stream));
+    HIP_TRY(hipEventSynchronize(r->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, r->ev0, r->ev1));
+    return ALCH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------------
+static inline size_t elem_words(const alch_ring* r) { return (size_t)r->L * r->n; }
+static inline size_t elem_bytes(const alch_ring* r) { return elem_words(r) * (size_t)r->word; }
+
+static int ensure_ws(void** p, size_t* have, size_t need) {
+    if (*have >= need) return ALCH_OK;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *have = 0; }
+    if (hipMalloc(p, need) != hipSuccess) return fail(ALCH_E_NOMEM, "hipMalloc(" + std::to_string(need) + ") failed");
+    *have = need;
+    return ALCH_OK;
+}
+
+template <typename W> static const DevRing<W>& dev_ring(const alch_ring* r);
+template <> const DevRing<u32>& dev_ring<u32>(const alch_ring* r) { return r->d32; }
+template <> const DevRing<u64>& dev_ring<u64>(const alch_ring* r) { return r->d64; }
+
+static hipError_t dispatch(int logn, const NttCall<u32>& c) {
+    if (logn <= 9) return dispatch32_small(logn, c);
+    if (logn <= 13) return dispatch32_mid(logn, c);
+    if (logn == 14) return dispatch32_14(logn, c);
+    return dispatch32_15(logn, c);
+}
+static hipError_t dispatch(int logn, const NttCall<u64>& c) {
+    if (logn <= 11) return dispatch64_small(logn, c);
+    return dispatch64_big(logn, c);
+}
+
+template <typename W>
+static int do_crt(alch_ring* r, void* data, size_t first_elem, size_t count, bool inverse) {
+    if (count == 0) return ALCH_OK;
+    NttCall<W> c{};
+    c.op = inverse ? OP_CRTINV : OP_CRT;
+    c.ring = &dev_ring<W>(r);
+    c.stream = r->stream;
+    c.data = reinterpret_cast<W*>(data);
+    const size_t polys = count * (size_t)r->L;
+    // grids are 32-bit: split very large batches
+    size_t done = 0;
+    while (done < polys) {
+        size_t now = std::min<size_t>(polys - done, (size_t)1 << 30);
+        c.first_poly = first_elem * (size_t)r->L + done;
+        c.npoly = now;
+        hipError_t e = dispatch(r->logn, c);
+        if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("crt launch: ") + hipGetErrorString(e));
+        done += now;
+    }
+    return ALCH_OK;
+}
+
+static int buf_crt(alch_buf* b, size_t first, size_t count, bool inverse) {
+    if (!b) return fail(ALCH_E_INVALID, "null buffer");
+    if (first + count > b->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
+    alch_ring* r = b->ring;
+    return r->word == 4 ? do_crt<u32>(r, b->dptr, first, count, inverse) : do_crt<u64>(r, b->dptr, first, count, inverse);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// device buffers
+// ------------------------------------------------------------------------------------------------------
+extern "C" int alch_buf_alloc(alch_ring* r, size_t n_elems, alch_buf** out) {
+    if (!r || !out || n_elems == 0) return fail(ALCH_E_INVALID, "alch_buf_alloc: bad argument");
+    void* p = nullptr;
+    if (hipMalloc(&p, n_elems * elem_bytes(r)) != hipSuccess)
+        return fail(ALCH_E_NOMEM, "hipMalloc of " + std::to_string(n_elems * elem_bytes(r)) + " bytes failed");
+    *out = new alch_buf{r, n_elems, p};
+    return ALCH_OK;
+}
+
+extern "C" int alch_buf_free(alch_buf* b) {
+    if (!b) return ALCH_OK;
+    (void)hipStreamSynchronize(b->ring->stream);
+    (void)hipFree(b->dptr);
+    delete b;
+    return ALCH_OK;
+}
+
+extern "C" int alch_buf_elems(const alch_buf* b, size_t* n) {
+    if (!b || !n) return fail(ALCH_E_INVALID, "null argument");
+    *n = b->n_elems;
+    return ALCH_OK;
+}
+
+template <typename W>
+static int do_transfer(alch_ring* r, void* dev, size_t count, int64_t* host, bool to_device) {
+    const size_t bytes = count * elem_words(r) * sizeof(int64_t);
+    int rc = ensure_ws(&r->ws_host, &r->ws_host_bytes, bytes);
+    if (rc != ALCH_OK) return rc;
+    int64_t* stage = reinterpret_cast<int64_t*>(r->ws_host);
+    const size_t total = count * elem_words(r);
+    if (to_device) {
+        HIP_TRY(hipMemcpyAsync(stage, host, bytes, hipMemcpyHostToDevice, r->stream));
+        hipLaunchKernelGGL((k_transpose<W, true>), dim3(ew_grid(total)), dim3(256), 0, r->stream, dev_ring<W>(r),
+                           reinterpret_cast<W*>(dev), stage, count);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(r->stream));      // host buffer is caller-owned: do not retain it
+    } else {
+        hipLaunchKernelGGL((k_transpose<W, false>), dim3(ew_grid(total)), dim3(256), 0, r->stream, dev_ring<W>(r),
+                           reinterpret_cast<W*>(dev), stage, count);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(host, stage, bytes, hipMemcpyDeviceToHost, r->stream));
+        HIP_TRY(hipStreamSynchronize(r->stream));
+    }
+    return ALCH_OK;
+}
+
+static int transfer(alch_ring* r, void* dev_base, size_t first, size_t count, int64_t* host, bool to_device) {
+    // bounded staging: move at most 64 MiB of int64 at a time
+    const size_t per = std::max<size_t>(1, ((size_t)64 << 20) / (elem_words(r) * sizeof(int64_t)));
+    size_t done = 0;
+    while (done < count) {
+        const size_t now = std::min(per, count - done);
+        char* dev = reinterpret_cast<char*>(dev_base) + (first + done) * elem_bytes(r);
+        int64_t* h = host + done * elem_words(r);
+        int rc = r->word == 4 ? do_transfer<u32>(r, dev, now, h, to_device) : do_transfer<u64>(r, dev, now, h, to_device);
+        if (rc != ALCH_OK) return rc;
+        done += now;
+    }
+    return ALCH_OK;
+}
+
+extern "C" int alch_buf_upload(alch_buf* b, size_t first, size_t count, const int64_t* host) {
+    if (!b || !host) return fail(ALCH_E_INVALID, "null argument");
+    if (first + count > b->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
+    return transfer(b->ring, b->dptr, first, count, const_cast<int64_t*>(host), true);
+}
+
+extern "C" int alch_buf_download(const alch_buf* b, size_t first, size_t count, int64_t* host) {
+    if (!b || !host) return fail(ALCH_E_INVALID, "null argument");
+    if (first + count > b->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
+    return transfer(b->ring, b->dptr, first, count, host, false);
+}
+
+extern "C" int alch_buf_fill_uniform(alch_buf* b, uint64_t seed) {
+    if (!b) return fail(ALCH_E_INVALID, "null buffer");
+    alch_ring* r = b->ring;
+    const size_t words = b->n_elems * elem_words(r);
+    if (r->word == 4)
+        hipLaunchKernelGGL((k_fill_uniform<u32>), dim3(ew_grid(words)), dim3(256), 0, r->stream, r->d32, (u32*)b->dptr, words, seed);
+    else
+        hipLaunchKernelGGL((k_fill_uniform<u64>), dim3(ew_grid(words)), dim3(256), 0, r->stream, r->d64, (u64*)b->dptr, words, seed);
+    HIP_TRY(hipGetLastError());
+    return ALCH_OK;
+}
+
+extern "C" int alch_buf_crt(alch_buf* b, size_t first, size_t count) { return buf_crt(b, first, count, false); }
+extern "C" int alch_buf_crtinv(alch_buf* b, size_t first, size_t count) { return buf_crt(b, first, count, true); }
+
+template <typename W, int OP>
+static int do_pointwise(alch_ring* r, void* dst, const void* a, const void* b, size_t count) {
+    const size_t words = count * elem_words(r);
+    hipLaunchKernelGGL((k_pointwise<W, OP>), dim3(ew_grid(words / Vec4<W>::LANES)), dim3(256), 0, r->stream, dev_ring<W>(r),
+                       (W*)dst, (const W*)a, (const W*)b, words);
+    HIP_TRY(hipGetLastError());
+    return ALCH_OK;
+}
+
+static int buf_pointwise(alch_buf* dst, const alch_buf* a, const alch_buf* b, size_t count, int op) {
+    if (!dst || !a || !b) return fail(ALCH_E_INVALID, "null buffer");
+    if (a->ring != dst->ring || b->ring != dst->ring) return fail(ALCH_E_INVALID, "buffers belong to different rings");
+    if (count > dst->n_elems || count > a->n_elems || count > b->n_elems) return fail(ALCH_E_INVALID, "count out of bounds");
+    alch_ring* r = dst->ring;
+    if (r->word == 4) {
+        if (op == PW_MUL) return do_pointwise<u32, PW_MUL>(r, dst->dptr, a->dptr, b->dptr, count);
+        if (op == PW_ADD) return do_pointwise<u32, PW_ADD>(r, dst->dptr, a->dptr, b->dptr, count);
+        return do_pointwise<u32, PW_SUB>(r, dst->dptr, a->dptr, b->dptr, count);
+    }
+    if (op == PW_MUL) return do_pointwise<u64, PW_MUL>(r, dst->dptr, a->dptr, b->dptr, count);
+    if (op == PW_ADD) return do_pointwise<u64, PW_ADD>(r, dst->dptr, a->dptr, b->dptr, count);
+    return do_pointwise<u64, PW_SUB>(r, dst->dptr, a->dptr, b->dptr, count);
+}
+
+extern "C" int alch_buf_mul(alch_buf* d, const alch_buf* a, const alch_buf* b, size_t count) { return buf_pointwise(d, a, b, count, PW_MUL); }
+extern "C" int alch_buf_add(alch_buf* d, const alch_buf* a, const alch_buf* b, size_t count) { return buf_pointwise(d, a, b, count, PW_ADD); }
+
+extern "C" int alch_buf_checksum(const alch_buf* b, size_t first, size_t count, uint64_t* sum) {
+    if (!b || !sum) return fail(ALCH_E_INVALID, "null argument");
+    if (first + count > b->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
+    alch_ring* r = b->ring;
+    const size_t words = count * elem_words(r);
+    const char* base = reinterpret_cast<const char*>(b->dptr) + first * elem_bytes(r);
+    HIP_TRY(hipMemsetAsync(r->ws_sum, 0, sizeof(u64), r->stream));
+    if (r->word == 4) hipLaunchKernelGGL((k_checksum<u32>), dim3(ew_grid(words)), dim3(256), 0, r->stream, (const u32*)base, words, r->ws_sum);
+    else hipLaunchKernelGGL((k_checksum<u64>), dim3(ew_grid(words)), dim3(256), 0, r->stream, (const u64*)base, words, r->ws_sum);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(sum, r->ws_sum, sizeof(u64), hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return ALCH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host-buffer Tensor methods: stage one element through a scratch device buffer
+// ------------------------------------------------------------------------------------------------------
+struct ScratchBuf {
+    alch_buf* b = nullptr;
+    ~ScratchBuf() { if (b) alch_buf_free(b); }
+};
+
+static int host_unary(alch_ring* r, int64_t* data, int which) {
+    if (!r || !data) return fail(ALCH_E_INVALID, "null argument");
+    ScratchBuf s;
+    int rc = alch_buf_alloc(r, 1, &s.b);
+    if (rc != ALCH_OK) return rc;
+    if ((rc = alch_buf_upload(s.b, 0, 1, data)) != ALCH_OK) return rc;
+    if ((rc = buf_crt(s.b, 0, 1, which == 1)) != ALCH_OK) return rc;
+    return alch_buf_download(s.b, 0, 1, data);
+}
+
+extern "C" int alch_crt(alch_ring* r, int64_t* data) { return host_unary(r, data, 0); }
+extern "C" int alch_crtinv(alch_ring* r, int64_t* data) { return host_unary(r, data, 1); }
+
+static int host_binary(alch_ring* r, int64_t* a, const int64_t* b, int op) {
+    if (!r || !a || !b) return fail(ALCH_E_INVALID, "null argument");
+    ScratchBuf s;
+    int rc = alch_buf_alloc(r, 2, &s.b);
+    if (rc != ALCH_OK) return rc;
+    if ((rc = alch_buf_upload(s.b, 0, 1, a)) != ALCH_OK) return rc;
+    if ((rc = alch_buf_upload(s.b, 1, 1, b)) != ALCH_OK) return rc;
+    alch_buf second{r, 1, reinterpret_cast<char*>(s.b->dptr) + elem_bytes(r)};
+    if ((rc = buf_pointwise(s.b, s.b, &second, 1, op)) != ALCH_OK) return rc;
+    return alch_buf_download(s.b, 0, 1, a);
+}
+
+extern "C" int alch_mul(alch_ring* r, int64_t* a, const int64_t* b) { return host_binary(r, a, b, PW_MUL); }
+extern "C" int alch_add(alch_ring* r, int64_t* a, const int64_t* b) { return host_binary(r, a, b, PW_ADD); }
+extern "C" int alch_sub(alch_ring* r, int64_t* a, const int64_t* b) { return host_binary(r, a, b, PW_SUB); }
+
+template <typename W>
+static int scal_to_mont(const alch_ring* r, const uint64_t* s, int power_of_R, Scal<W>& out) {
+    // out[j] = s[j] * R^power mod q_j  (s == NULL means 1)
+    const int bits = 8 * (int)sizeof(W);
+    for (int j = 0; j < MAXL; ++j) out.v[j] = 0;
+    for (int j = 0; j < r->L; ++j) {
+        const u64 q = r->q[j];
+        u64 v = s ? s[j] % q : 1;
+        const u64 r1 = h_powmod(2, (u64)bits, q);
+        for (int p = 0; p < power_of_R; ++p) v = h_mulmod(v, r1, q);
+        out.v[j] = (W)v;
+    }
+    return ALCH_OK;
+}
+
+template <typename W>
+static int do_scale(alch_ring* r, void* dst, const void* src, size_t count, const uint64_t* s) {
+    Scal<W> sm;
+    scal_to_mont<W>(r, s, 1, sm);
+    const size_t words = count * elem_words(r);
+    hipLaunchKernelGGL((k_scale<W>), dim3(ew_grid(words)), dim3(256), 0, r->stream, dev_ring<W>(r), (W*)dst, (const W*)src, words, sm);
+    HIP_TRY(hipGetLastError());
+    return ALCH_OK;
+}
+
+extern "C" int alch_scale(alch_ring* r, int64_t* a, const uint64_t* s) {
+    if (!r || !a || !s) return fail(ALCH_E_INVALID, "null argument");
+    ScratchBuf t;
+    int rc = alch_buf_alloc(r, 1, &t.b);
+    if (rc != ALCH_OK) return rc;
+    if ((rc = alch_buf_upload(t.b, 0, 1, a)) != ALCH_OK) return rc;
+    rc = r->word == 4 ? do_scale<u32>(r, t.b->dptr, t.b->dptr, 1, s) : do_scale<u64>(r, t.b->dptr, t.b->dptr, 1, s);
+    if (rc != ALCH_OK) return rc;
+    return alch_buf_download(t.b, 0, 1, a);
+}
+
+// g_m = 1 for a two-power index: mulG/divG are the identity in every basis.
+static int identity_op(alch_ring* r, int64_t* a) {
+    if (!r || !a) return fail(ALCH_E_INVALID, "null argument");
+    return ALCH_OK;
+}
+extern "C" int alch_mulg_pow(alch_ring* r, int64_t* a) { return identity_op(r, a); }
+extern "C" int alch_mulg_dec(alch_ring* r, int64_t* a) { return identity_op(r, a); }
+extern "C" int alch_mulg_crt(alch_ring* r, int64_t* a) { return identity_op(r, a); }
+extern "C" int alch_divg_pow(alch_ring* r, int64_t* a) { return identity_op(r, a); }
+extern "C" int alch_divg_dec(alch_ring* r, int64_t* a) { return identity_op(r, a); }
+extern "C" int alch_divg_crt(alch_ring* r, int64_t* a) { return identity_op(r, a); }
+
+extern "C" int alch_decompose_triv(alch_ring* r, const int64_t* c_pow, int64_t* digits) {
+    if (!r || !c_pow || !digits) return fail(ALCH_E_INVALID, "null argument");
+    ScratchBuf s;
+    int rc = alch_buf_alloc(r, 1 + (size_t)r->L, &s.b);
+    if (rc != ALCH_OK) return rc;
+    if ((rc = alch_buf_upload(s.b, 0, 1, c_pow)) != ALCH_OK) return rc;
+    char* dig = reinterpret_cast<char*>(s.b->dptr) + elem_bytes(r);
+    const size_t total = (size_t)r->L * elem_words(r);
+    if (r->word == 4) hipLaunchKernelGGL((k_decompose_triv<u32>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d32, (const u32*)s.b->dptr, (u32*)dig);
+    else hipLaunchKernelGGL((k_decompose_triv<u64>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d64, (const u64*)s.b->dptr, (u64*)dig);
+    HIP_TRY(hipGetLastError());
+    return alch_buf_download(s.b, 1, (size_t)r->L, digits);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// hint
+// ------------------------------------------------------------------------------------------------------
+static int hint_from_device(alch_ring* r, int gadget, const void* src_crt, alch_hint** out) {
+    if (gadget != ALCH_GAD_TRIV) return fail(ALCH_E_UNSUPPORTED, "device key switch supports TrivGad in this round");
+    const int digits = r->L;
+    const size_t elems = 2 * (size_t)digits;
+    void* p = nullptr;
+    if (hipMalloc(&p, elems * elem_bytes(r)) != hipSuccess) return fail(ALCH_E_NOMEM, "hipMalloc(hint) failed");
+    // Montgomery form: multiply by R^2 under mont_mul  -> x * R
+    int rc;
+    if (r->word == 4) {
+        Scal<u32> sm; scal_to_mont<u32>(r, nullptr, 2, sm);
+        const size_t words = elems * elem_words(r);
+        hipLaunchKernelGGL((k_scale<u32>), dim3(ew_grid(words)), dim3(256), 0, r->stream, r->d32, (u32*)p, (const u32*)src_crt, words, sm);
+    } else {
+        Scal<u64> sm; scal_to_mont<u64>(r, nullptr, 2, sm);
+        const size_t words = elems * elem_words(r);
+        hipLaunchKernelGGL((k_scale<u64>), dim3(ew_grid(words)), dim3(256), 0, r->stream, r->d64, (u64*)p, (const u64*)src_crt, words, sm);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { (void)hipFree(p); return fail(ALCH_E_HIP, std::string("hint conversion: ") + hipGetErrorString(e)); }
+    rc = ALCH_OK;
+    *out = new alch_hint{r, gadget, digits, p};
+    return rc;
+}
+
+extern "C" int alch_hint_load(alch_ring* r, int gadget, const int64_t* host_crt, alch_hint** out) {
+    if (!r || !host_crt || !out) return fail(ALCH_E_INVALID, "null argument");
+    ScratchBuf s;
+    int rc = alch_buf_alloc(r, 2 * (size_t)r->L, &s.b);
+    if (rc != ALCH_OK) return rc;
+    if ((rc = alch_buf_upload(s.b, 0, 2 * (size_t)r->L, host_crt)) != ALCH_OK) return rc;
+    rc = hint_from_device(r, gadget, s.b->dptr, out);
+    if (rc == ALCH_OK) HIP_TRY(hipStreamSynchronize(r->stream));
+    return rc;
+}
+
+extern "C" int alch_hint_from_buf(alch_ring* r, int gadget, const alch_buf* src, alch_hint** out) {
+    if (!r || !src || !out) return fail(ALCH_E_INVALID, "null argument");
+    if (src->ring != r || src->n_elems < 2 * (size_t)r->L) return fail(ALCH_E_INVALID, "hint source needs 2*L elements of this ring");
+    return hint_from_device(r, gadget, src->dptr, out);
+}
+
+extern "C" int alch_hint_free(alch_hint* h) {
+    if (!h) return ALCH_OK;
+    (void)hipStreamSynchronize(h->ring->stream);
+    (void)hipFree(h->dptr);
+    delete h;
+    return ALCH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// the hot path
+// ------------------------------------------------------------------------------------------------------
+template <typename W>
+static int do_mul_relin(alch_ring* r, const alch_hint* hint, const void* a, const void* b, void* out, size_t batch,
+                        const uint64_t* s_pre) {
+    typedef typename Signed<W>::type SW;
+    const size_t chunk = std::min(r->chunk, (batch + 7) / 8 * 8);
+    int rc = ensure_ws(&r->ws_digits, &r->ws_digits_bytes, chunk * elem_words(r) * sizeof(SW));
+    if (rc != ALCH_OK) return rc;
+    NttCall<W> c{};
+    c.ring = &dev_ring<W>(r);
+    c.stream = r->stream;
+    c.hint = reinterpret_cast<const W*>(hint->dptr);
+    c.digits = r->ws_digits;
+    c.balanced = r->balanced;
+    scal_to_mont<W>(r, s_pre, 2, c.spre_r2);
+    const size_t ct_words = 2 * elem_words(r);
+    for (size_t done = 0; done < batch; done += chunk) {
+        const size_t now = std::min(chunk, batch - done);
+        c.a = reinterpret_cast<const W*>(a) + done * ct_words;
+        c.b = reinterpret_cast<const W*>(b) + done * ct_words;
+        c.out = reinterpret_cast<W*>(out) + done * ct_words;
+        c.nct = now;
+        c.op = OP_TENSOR_INTT;
+        hipError_t e = dispatch(r->logn, c);
+        if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("tensor_intt launch: ") + hipGetErrorString(e));
+        c.op = OP_KS_ACCUM;
+        e = dispatch(r->logn, c);
+        if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("ks_accum launch: ") + hipGetErrorString(e));
+    }
+    return ALCH_OK;
+}
+
+extern "C" int alch_ct_mul_relin(alch_ring* r, const alch_hint* hint, const alch_buf* a, const alch_buf* b, alch_buf* out,
+                                 size_t batch, const uint64_t* s_pre, unsigned flags) {
+    if (!r || !hint || !a || !b || !out) return fail(ALCH_E_INVALID, "null argument");
+    if (hint->ring != r || a->ring != r || b->ring != r || out->ring != r) return fail(ALCH_E_INVALID, "handles belong to different rings");
+    if (batch == 0) return ALCH_OK;
+    if (a->n_elems < 2 * batch || b->n_elems < 2 * batch || out->n_elems < 2 * batch)
+        return fail(ALCH_E_INVALID, "buffers must hold 2*batch ring elements");
+    if (out == a || out == b) return fail(ALCH_E_INVALID, "out must not alias an input");
+    const void* pa = a->dptr;
+    const void* pb = b->dptr;
+    int rc;
+    if (flags & ALCH_POW_IN) {
+        const size_t bytes = 2 * batch * elem_bytes(r);
+        if ((rc = ensure_ws(&r->ws_in, &r->ws_in_bytes, 2 * bytes)) != ALCH_OK) return rc;
+        char* wa = reinterpret_cast<char*>(r->ws_in);
+        char* wb = wa + bytes;
+        HIP_TRY(hipMemcpyAsync(wa, a->dptr, bytes, hipMemcpyDeviceToDevice, r->stream));
+        HIP_TRY(hipMemcpyAsync(wb, b->dptr, bytes, hipMemcpyDeviceToDevice, r->stream));
+        rc = r->word == 4 ? do_crt<u32>(r, wa, 0, 4 * batch, false) : do_crt<u64>(r, wa, 0, 4 * batch, false);
+        if (rc != ALCH_OK) return rc;
+        pa = wa;
+        pb = wb;
+    }
+    rc = r->word == 4 ? do_mul_relin<u32>(r, hint, pa, pb, out->dptr, batch, s_pre)
+                      : do_mul_relin<u64>(r, hint, pa, pb, out->dptr, batch, s_pre);
+    if (rc != ALCH_OK) return rc;
+    if (flags & ALCH_POW_OUT) return buf_crt(out, 0, 2 * batch, true);
+    return ALCH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// modSwitch building block
+// ------------------------------------------------------------------------------------------------------
+extern "C" int alch_buf_rescale_drop0(const alch_buf* src, alch_buf* dst, size_t count) {
+    if (!src || !dst) return fail(ALCH_E_INVALID, "null buffer");
+    alch_ring* rs = src->ring;
+    alch_ring* rd = dst->ring;
+    if (rs->L < 2 || rd->L != rs->L - 1 || rd->n != rs->n || rd->word != rs->word)
+        return fail(ALCH_E_INVALID, "destination ring must be the source ring minus limb 0");
+    for (int j = 1; j < rs->L; ++j)
+        if (rs->q[j] != rd->q[j - 1]) return fail(ALCH_E_INVALID, "destination limbs must equal source limbs 1..L-1");
+    if (count > src->n_elems || count > dst->n_elems) return fail(ALCH_E_INVALID, "count out of bounds");
+    uint64_t inv[MAXL] = {0};
+    for (int j = 1; j < rs->L; ++j) inv[j] = h_powmod(rs->q[0] % rs->q[j], rs->q[j] - 2, rs->q[j]);
+    const size_t total = count * (size_t)rd->L * rd->n;
+    HIP_TRY(hipStreamSynchronize(rd->stream));
+    if (rs->word == 4) {
+        Scal<u32> sm; scal_to_mont<u32>(rs, inv, 1, sm);
+        hipLaunchKernelGGL((k_rescale_drop0<u32>), dim3(ew_grid(total)), dim3(256), 0, rs->stream, rs->d32, (const u32*)src->dptr, (u32*)dst->dptr, count, sm);
+    } else {
+        Scal<u64> sm; scal_to_mont<u64>(rs, inv, 1, sm);
+        hipLaunchKernelGGL((k_rescale_drop0<u64>), dim3(ew_grid(total)), dim3(256), 0, rs->stream, rs->d64, (const u64*)src->dptr, (u64*)dst->dptr, count, sm);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(rs->stream));
+    return ALCH_OK;
+}

@@ -1,0 +1,326 @@
+// LDS-resident NTT kernels: batched crt / crtInv and the two fused kernels of ct_mul_relin.
+//
+//   k_crt          Tensor crt / crtInv on a batch of limb-polynomials, in place.
+//   k_tensor_intt  per (ciphertext, limb i):  c2_i = a1_i * b1_i * s_i  (the quadratic coefficient of
+//                  SymmSHE's (*), Crypto/Alchemy/Interpreter/Eval.hs:65-67), crtInv in LDS, centred lift
+//                  -> TrivGad digit d_i (signed words, Pow basis).  First half of keySwitchQuadCirc
+//                  (Eval.hs:133): `decompose c2`.
+//   k_ks_accum     per (ciphertext, limb j):  out_{0,1} = c_{0,1} + sum_i crt_j(reduce d_i) * hint_i,{0,1}
+//                  with c0 = a0 b0 s, c1 = (a0 b1 + a1 b0) s; the i = j digit is c2_j itself (d_j = c2_j
+//                  mod q_j), so only L-1 transforms run per limb.  Accumulators stay in registers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "ntt_engine.hpp"
+
+namespace alch {
+
+constexpr int MAXL = 8;
+
+template <typename W>
+struct DevRing {
+    int L;
+    int logn;
+    ModP<W> mod[MAXL];
+    W ninv_m[MAXL];      // n^-1 in Montgomery form
+    W w1ninv_m[MAXL];    // tw_inv[1] * n^-1 in Montgomery form
+    W dig_off[MAXL];     // multiple of q_j >= max_i (q_i-1)/2: makes a signed digit non-negative
+    const W* twf[MAXL];  // forward twiddles (device, Montgomery form), n words
+    const W* twi[MAXL];  // inverse twiddles
+};
+
+template <typename W> struct Scal { W v[MAXL]; };   // per-limb scalars passed by value
+
+template <typename W> struct Signed;
+template <> struct Signed<u32> { typedef int32_t type; };
+template <> struct Signed<u64> { typedef int64_t type; };
+
+enum OpKind { OP_CRT = 0, OP_CRTINV = 1, OP_TENSOR_INTT = 2, OP_KS_ACCUM = 3 };
+
+template <typename W>
+struct NttCall {
+    OpKind op;
+    const DevRing<W>* ring;
+    hipStream_t stream;
+    // OP_CRT / OP_CRTINV
+    W* data;
+    size_t first_poly, npoly;
+    // fused kernels
+    const W* a;
+    const W* b;
+    void* digits;          // Signed<W>*, [ct][L][n]
+    const W* hint;         // [digit][2][L][n], Montgomery form
+    W* out;
+    size_t nct;            // ciphertexts in this launch (a, b, out, digits already offset to the first)
+    Scal<W> spre_r2;       // s_j * R^2 mod q_j
+    bool balanced;         // every |digit| < every q_j  ->  reduce is one add
+};
+
+// ---- staging helpers -------------------------------------------------------------------------------
+template <int LOGN, typename W, typename F>
+__device__ __forceinline__ void stage_in(W* lds, F&& load4) {
+    typedef Geo<LOGN> G;
+    typedef typename Vec4<W>::type V;
+    constexpr int VL = Vec4<W>::LANES;
+#pragma unroll
+    for (int r = 0; r < G::E / VL; ++r) {
+        const int idx = (threadIdx.x + G::T * r) * VL;
+        V v = load4(idx);
+        *reinterpret_cast<V*>(&lds[swz<LOGN>(idx)]) = v;
+    }
+}
+
+// ---- batched crt / crtInv --------------------------------------------------------------------------
+template <int LOGN, typename W, bool INVERSE>
+__global__ void __launch_bounds__(Geo<LOGN>::T) k_crt(DevRing<W> R, W* __restrict__ data, size_t first_poly) {
+    typedef Geo<LOGN> G;
+    typedef typename Vec4<W>::type V;
+    constexpr int VL = Vec4<W>::LANES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W* lds = reinterpret_cast<W*>(smem);
+    const size_t p = first_poly + blockIdx.x;
+    const int j = (int)(p % (size_t)R.L);
+    W* poly = data + p * (size_t)G::N;
+    const W q = R.mod[j].q, qni = R.mod[j].qni;
+
+    stage_in<LOGN, W>(lds, [&](int idx) { return *reinterpret_cast<const V*>(poly + idx); });
+    __syncthreads();
+    if constexpr (!INVERSE) ntt_forward<LOGN, W, false>(lds, R.twf[j], q, qni, (int)threadIdx.x, NoEpilogue());
+    else ntt_inverse<LOGN, W, false>(lds, R.twi[j], q, qni, R.ninv_m[j], R.w1ninv_m[j], (int)threadIdx.x, NoEpilogue());
+#pragma unroll
+    for (int r = 0; r < G::E / VL; ++r) {
+        const int idx = (threadIdx.x + G::T * r) * VL;
+        V v = *reinterpret_cast<const V*>(&lds[swz<LOGN>(idx)]);
+#pragma unroll
+        for (int e = 0; e < VL; ++e) v[e] = csub(v[e], q);
+        *reinterpret_cast<V*>(poly + idx) = v;
+    }
+}
+
+// ---- fused kernel A: tensor c2 + crtInv + centred lift ---------------------------------------------
+template <int LOGN, typename W>
+__global__ void __launch_bounds__(Geo<LOGN>::T)
+k_tensor_intt(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
+              typename Signed<W>::type* __restrict__ digits, Scal<W> spre) {
+    typedef Geo<LOGN> G;
+    typedef typename Vec4<W>::type V;
+    typedef typename Signed<W>::type SW;
+    constexpr int VL = Vec4<W>::LANES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W* lds = reinterpret_cast<W*>(smem);
+    const int L = R.L;
+    const size_t ct = blockIdx.x / (unsigned)L;
+    const int i = (int)(blockIdx.x % (unsigned)L);
+    const ModP<W> m = R.mod[i];
+    const W q = m.q, qni = m.qni;
+    const W sr2 = spre.v[i];
+    const W* a1 = a + ((2 * ct + 1) * (size_t)L + i) * (size_t)G::N;
+    const W* b1 = b + ((2 * ct + 1) * (size_t)L + i) * (size_t)G::N;
+
+    stage_in<LOGN, W>(lds, [&](int idx) {
+        V x = *reinterpret_cast<const V*>(a1 + idx);
+        V y = *reinterpret_cast<const V*>(b1 + idx);
+        V v;
+#pragma unroll
+        for (int e = 0; e < VL; ++e) {
+            W xs = csub(mont_mul_lazy(x[e], sr2, q, qni), q);       // a1 * s * R
+            v[e] = mont_mul_lazy(y[e], xs, q, qni);                  // a1 * b1 * s   in [0,2q)
+        }
+        return v;
+    });
+    __syncthreads();
+    SW* d = digits + (ct * (size_t)L + i) * (size_t)G::N;
+    constexpr int RR = 1 << G::NS0;
+    constexpr int STRIDE = G::N / RR;
+    const W half = (q - 1) >> 1;
+    ntt_inverse<LOGN, W, true>(lds, R.twi[i], q, qni, R.ninv_m[i], R.w1ninv_m[i], (int)threadIdx.x, [&](int, int base, W* x) {
+#pragma unroll
+        for (int k = 0; k < RR; ++k) {
+            W v = csub(x[k], q);
+            SW z = v > half ? (SW)v - (SW)q : (SW)v;                 // centred lift (Lol `lift`)
+            d[base + k * STRIDE] = z;
+        }
+    });
+}
+
+// ---- fused kernel B: digit transforms + key-switch inner product ------------------------------------
+template <int LOGN, typename W, bool BALANCED>
+__global__ void __launch_bounds__(Geo<LOGN>::T)
+k_ks_accum(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
+           const typename Signed<W>::type* __restrict__ digits, const W* __restrict__ hint, W* __restrict__ out,
+           unsigned nct, Scal<W> spre) {
+    typedef Geo<LOGN> G;
+    typedef typename Vec4<W>::type V;
+    typedef typename Signed<W>::type SW;
+    typedef SW SV __attribute__((ext_vector_type(Vec4<W>::LANES)));
+    constexpr int VL = Vec4<W>::LANES;
+    constexpr int NG = G::E / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W* lds = reinterpret_cast<W*>(smem);
+    const int L = R.L;
+    // XCD-aware placement: workgroups b and b+8 share an XCD (round-robin dispatch), so the L limb
+    // workgroups of one ciphertext -- which all read the same digits d_i -- are given ids that agree
+    // mod 8 and hit the same L2.  Purely a speed choice; any placement is correct.
+    const unsigned grp = blockIdx.x / (8u * (unsigned)L);
+    const unsigned rem = blockIdx.x % (8u * (unsigned)L);
+    const int j = (int)(rem >> 3);
+    const size_t ct = (size_t)grp * 8u + (rem & 7u);
+    if (ct >= nct) return;
+
+    const ModP<W> m = R.mod[j];
+    const W q = m.q, qni = m.qni;
+    const W sr2 = spre.v[j];
+    const size_t n = (size_t)G::N;
+    const W* a0 = a + ((2 * ct) * (size_t)L + j) * n;
+    const W* a1 = a + ((2 * ct + 1) * (size_t)L + j) * n;
+    const W* b0 = b + ((2 * ct) * (size_t)L + j) * n;
+    const W* b1 = b + ((2 * ct + 1) * (size_t)L + j) * n;
+    const W* hj = hint + (size_t)j * n;                       // + ((i*2 + c)*L)*n
+    const size_t hstride = (size_t)L * n;
+
+    W acc0[G::E], acc1[G::E];
+    // c0, c1 and the diagonal digit (i == j): d_j = c2_j (mod q_j), no transform needed
+    {
+        const W* h0 = hj + (size_t)(2 * j) * hstride;
+        const W* h1 = hj + (size_t)(2 * j + 1) * hstride;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int k = 0; k < 16; k += VL) {
+                const int idx = (threadIdx.x + G::T * g) * 16 + k;
+                V va0 = *reinterpret_cast<const V*>(a0 + idx), va1 = *reinterpret_cast<const V*>(a1 + idx);
+                V vb0 = *reinterpret_cast<const V*>(b0 + idx), vb1 = *reinterpret_cast<const V*>(b1 + idx);
+                V vh0 = *reinterpret_cast<const V*>(h0 + idx), vh1 = *reinterpret_cast<const V*>(h1 + idx);
+#pragma unroll
+                for (int e = 0; e < VL; ++e) {
+                    W x0 = csub(mont_mul_lazy(va0[e], sr2, q, qni), q);       // a0 s R
+                    W x1 = csub(mont_mul_lazy(va1[e], sr2, q, qni), q);       // a1 s R
+                    W c0 = csub(mont_mul_lazy(vb0[e], x0, q, qni), q);        // a0 b0 s
+                    W c1 = csub(csub(mont_mul_lazy(vb1[e], x0, q, qni), q) +
+                                csub(mont_mul_lazy(vb0[e], x1, q, qni), q), q);   // (a0 b1 + a1 b0) s
+                    W c2 = mont_mul_lazy(vb1[e], x1, q, qni);                 // a1 b1 s, lazy
+                    acc0[g * 16 + k + e] = csub(c0 + csub(mont_mul_lazy(c2, vh0[e], q, qni), q), q);
+                    acc1[g * 16 + k + e] = csub(c1 + csub(mont_mul_lazy(c2, vh1[e], q, qni), q), q);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep one 4-coefficient slice of loads live at a time
+            }
+        }
+    }
+
+    for (int i = 0; i < L; ++i) {
+        if (i == j) continue;
+        const SW* d = digits + (ct * (size_t)L + i) * n;
+        __syncthreads();      // previous transform's last pass has finished reading LDS
+        stage_in<LOGN, W>(lds, [&](int idx) {
+            SV z = *reinterpret_cast<const SV*>(d + idx);
+            V v;
+#pragma unroll
+            for (int e = 0; e < VL; ++e) {
+                if constexpr (BALANCED) v[e] = (W)z[e] + q;                                   // (0, 2q)
+                else v[e] = mont_mul_lazy((W)((W)z[e] + R.dig_off[j]), m.r1, q, qni);        // [0, 2q)
+            }
+            return v;
+        });
+        __syncthreads();
+        const W* h0 = hj + (size_t)(2 * i) * hstride;
+        const W* h1 = hj + (size_t)(2 * i + 1) * hstride;
+        // Neither the twiddles nor the LDS addresses depend on i; unless both are made opaque here the
+        // compiler hoists every pass's address arithmetic and twiddle loads out of the digit loop and
+        // spills ~250 VGPRs per lane.
+        const W* twf = R.twf[j];
+        int tid = threadIdx.x;
+        asm volatile("" : "+s"(twf), "+v"(tid));
+        ntt_forward<LOGN, W, true, true>(lds, twf, q, qni, tid, [&](int g, int base, W* x) {
+#pragma unroll
+            for (int k = 0; k < 16; k += VL) {
+                V vh0 = *reinterpret_cast<const V*>(h0 + base + k), vh1 = *reinterpret_cast<const V*>(h1 + base + k);
+#pragma unroll
+                for (int e = 0; e < VL; ++e) {
+                    acc0[g * 16 + k + e] = csub(acc0[g * 16 + k + e] + csub(mont_mul_lazy(x[k + e], vh0[e], q, qni), q), q);
+                    acc1[g * 16 + k + e] = csub(acc1[g * 16 + k + e] + csub(mont_mul_lazy(x[k + e], vh1[e], q, qni), q), q);
+                }
+            }
+        });
+    }
+
+    W* o0 = out + ((2 * ct) * (size_t)L + j) * n;
+    W* o1 = out + ((2 * ct + 1) * (size_t)L + j) * n;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int k = 0; k < 16; k += VL) {
+            const int idx = (threadIdx.x + G::T * g) * 16 + k;
+            V v0, v1;
+#pragma unroll
+            for (int e = 0; e < VL; ++e) { v0[e] = acc0[g * 16 + k + e]; v1[e] = acc1[g * 16 + k + e]; }
+            *reinterpret_cast<V*>(o0 + idx) = v0;
+            *reinterpret_cast<V*>(o1 + idx) = v1;
+        }
+    }
+}
+
+// ---- launcher ----------------------------------------------------------------------------------------
+template <typename K>
+inline hipError_t set_lds(K kernel, size_t bytes) {
+    if (bytes <= 65536) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes);
+}
+
+template <typename W, int LOGN>
+inline hipError_t run_call(const NttCall<W>& c) {
+    typedef Geo<LOGN> G;
+    typedef typename Signed<W>::type SW;
+    const size_t lds_bytes = (size_t)G::N * sizeof(W);
+    const DevRing<W>& R = *c.ring;
+    hipError_t e;
+    switch (c.op) {
+    case OP_CRT: {
+        auto k = k_crt<LOGN, W, false>;
+        if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(G::T), lds_bytes, c.stream, R, c.data, c.first_poly);
+        break;
+    }
+    case OP_CRTINV: {
+        auto k = k_crt<LOGN, W, true>;
+        if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(G::T), lds_bytes, c.stream, R, c.data, c.first_poly);
+        break;
+    }
+    case OP_TENSOR_INTT: {
+        auto k = k_tensor_intt<LOGN, W>;
+        if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3((unsigned)(c.nct * (size_t)R.L)), dim3(G::T), lds_bytes, c.stream, R, c.a, c.b,
+                           (SW*)c.digits, c.spre_r2);
+        break;
+    }
+    case OP_KS_ACCUM: {
+        const size_t groups = (c.nct + 7) / 8;
+        const unsigned grid = (unsigned)(groups * 8 * (size_t)R.L);
+        if (c.balanced) {
+            auto k = k_ks_accum<LOGN, W, true>;
+            if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
+            hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), lds_bytes, c.stream, R, c.a, c.b, (const SW*)c.digits,
+                               c.hint, c.out, (unsigned)c.nct, c.spre_r2);
+        } else {
+            auto k = k_ks_accum<LOGN, W, false>;
+            if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
+            hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), lds_bytes, c.stream, R, c.a, c.b, (const SW*)c.digits,
+                               c.hint, c.out, (unsigned)c.nct, c.spre_r2);
+        }
+        break;
+    }
+    }
+    return hipGetLastError();
+}
+
+// One of these per translation unit (the unrolled radix-16 passes make each instantiation large, so
+// the LOGN range is split over several .hip files that build in parallel).
+hipError_t dispatch32_small(int logn, const NttCall<u32>& c);   // log n = 4..9
+hipError_t dispatch32_mid(int logn, const NttCall<u32>& c);     // 10..13
+hipError_t dispatch32_14(int logn, const NttCall<u32>& c);
+hipError_t dispatch32_15(int logn, const NttCall<u32>& c);
+hipError_t dispatch64_small(int logn, const NttCall<u64>& c);   // 4..11
+hipError_t dispatch64_big(int logn, const NttCall<u64>& c);     // 12..14
+
+}  // namespace alch

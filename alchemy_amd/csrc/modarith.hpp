@@ -1,0 +1,113 @@
+// Word-size modular arithmetic for gfx950 (and the host-side table builder).
+//
+// Montgomery multiplication with R = 2^32 (32-bit residues, q < 2^31) or R = 2^64 (q < 2^62).
+// Measured on MI355X (tools/ubench): v_mul_lo/v_mul_hi/v_mad_u64_u32 all issue at ~4.5 cycles per
+// wave64, v_add/v_sub at ~2.6, v_min_u32 at ~4.1.  The 32-bit Montgomery product below compiles to
+// exactly three multiplier instructions (v_mad_u64_u32, v_mul_lo_u32, v_mad_u64_u32) with no
+// separate add, one fewer instruction than Shoup's and with one-word twiddles.
+//
+// Ranges.  mont_mul_lazy(a, b): a any word, b < q  ->  a*b*R^-1 mod q in [0, 2q).
+// Ring data are kept "lazy" in [0, 2q) between butterfly stages (2q < 2^32 / 2^63); csub() brings
+// a [0,2q) value to [0,q).  4q does not fit a 32-bit word for ALCHEMY's 31-bit moduli
+// (examples/HomomRLWR.hs:37-43), so Harvey's [0,4q) butterflies are not used.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define ALCH_HD __host__ __device__ __forceinline__
+#else
+#define ALCH_HD inline
+#endif
+
+namespace alch {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+template <typename W>
+struct ModP {
+    W q;     // modulus
+    W qni;   // -q^-1 mod R
+    W r1;    // R mod q          (Montgomery form of 1)
+    W r2;    // R^2 mod q        (to_mont multiplier)
+};
+
+ALCH_HD u32 mont_mul_lazy(u32 a, u32 b, u32 q, u32 qni) {
+    u64 p = (u64)a * b;
+    u32 m = (u32)p * qni;
+    return (u32)((p + (u64)m * q) >> 32);
+}
+
+ALCH_HD u64 mul_hi64(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (u64)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+ALCH_HD u64 mont_mul_lazy(u64 a, u64 b, u64 q, u64 qni) {
+    u64 lo = a * b, hi = mul_hi64(a, b);
+    u64 m = lo * qni;
+    u64 hi2 = mul_hi64(m, q);
+    // lo + lo(m*q) == 0 mod 2^64; it carries exactly when lo != 0
+    return hi + hi2 + (lo != 0);
+}
+
+// [0,2q) -> [0,q).  x - q wraps to a huge value when x < q, so the unsigned min picks x.
+ALCH_HD u32 csub(u32 x, u32 q) { u32 y = x - q; return y < x ? y : x; }
+ALCH_HD u64 csub(u64 x, u64 q) { u64 y = x - q; return y < x ? y : x; }
+
+template <typename W>
+ALCH_HD W mont_mul(W a, W b, const ModP<W>& m) { return csub(mont_mul_lazy(a, b, m.q, m.qni), m.q); }
+template <typename W>
+ALCH_HD W add_mod(W a, W b, W q) { return csub((W)(a + b), q); }            // a,b in [0,q)
+template <typename W>
+ALCH_HD W sub_mod(W a, W b, W q) { W d = a - b; W e = d + q; return e < d ? e : d; }   // a,b in [0,q)
+
+// Forward (Cooley-Tukey) butterfly on lazy values: x,y in [0,2q), w = twiddle in Montgomery form.
+//   x' = x + w*y, y' = x - w*y   (mod q), outputs in [0,2q).  10 VALU instructions for W = u32.
+template <typename W>
+ALCH_HD void bfly_fwd(W& x, W& y, W w, W q, W qni) {
+    W xx = csub(x, q);
+    W t = csub(mont_mul_lazy(y, w, q, qni), q);
+    x = xx + t;
+    y = xx + (q - t);
+}
+
+// Inverse (Gentleman-Sande) butterfly: x' = x + y, y' = (x - y) * w.  in/out in [0,2q).
+template <typename W>
+ALCH_HD void bfly_inv(W& x, W& y, W w, W q, W qni) {
+    W a = csub(x, q), b = csub(y, q);
+    x = a + b;
+    y = mont_mul_lazy((W)(a - b + q), w, q, qni);
+}
+
+// ---- host-side helpers (table building) ------------------------------------------------------
+inline u64 h_mulmod(u64 a, u64 b, u64 q) { return (u64)(((unsigned __int128)a * b) % q); }
+inline u64 h_powmod(u64 b, u64 e, u64 q) {
+    u64 r = 1 % q;
+    b %= q;
+    while (e) {
+        if (e & 1) r = h_mulmod(r, b, q);
+        b = h_mulmod(b, b, q);
+        e >>= 1;
+    }
+    return r;
+}
+
+template <typename W>
+inline ModP<W> make_modp(u64 q) {
+    ModP<W> m;
+    m.q = (W)q;
+    W inv = 1;                                  // Newton: inv = q^-1 mod 2^bits
+    for (int i = 0; i < 7; ++i) inv *= (W)2 - (W)q * inv;
+    m.qni = (W)0 - inv;
+    const int bits = 8 * (int)sizeof(W);
+    u64 r1 = h_powmod(2, (u64)bits, q);
+    m.r1 = (W)r1;
+    m.r2 = (W)h_mulmod(r1, r1, q);
+    return m;
+}
+
+}  // namespace alch

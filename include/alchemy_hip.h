@@ -1,0 +1,160 @@
+/*
+ * alchemy_hip.h -- C ABI of the MI355X (gfx950) ciphertext-arithmetic backend for ALCHEMY's evaluator.
+ *
+ * This is the boundary a new Lol `Tensor` instance binds to.  The reference
+ * never names a backend: every ALCHEMY signature is polymorphic in the tensor type `t`
+ * (Crypto/Alchemy/Language/SHE.hs:21-45, Crypto/Alchemy/Interpreter/PT2CT.hs:78-96) and the backend is
+ * chosen only by the tensor type in an example's `PT` alias (examples/Arithmetic.hs:19,23).  The
+ * entry points below are what `instance Tensor GT` would `foreign import ccall`; each cites the
+ * reference call site (or the Lol Tensor method behind it) that it serves.  INTEGRATION.md shows
+ * the Haskell-side stub.
+ *
+ * Conventions
+ *   - plain C: no C++ types, no exceptions across the ABI.  Every function returns an int status
+ *     (ALCH_OK == 0, negative == error); alch_last_error() gives a thread-local message.
+ *   - ring R'_q = Z_q[X]/(X^n+1): cyclotomic index m = 2n a power of two, n >= 16; RNS limbs
+ *     q_0..q_{L-1}, limb 0 = outermost component of Lol's nested pair
+ *     (Crypto/Alchemy/Interpreter/PT2CT/Noise.hs:82-89,130).
+ *   - HOST buffers use Lol's layout: int64_t, tuple-interleaved ("AoS"): coefficient k of limb j of
+ *     one ring element at data[k*L + j], residues in [0, q_j)   (ZqBasic q Int64, examples/Common.hs:35).
+ *     Host buffers are caller-owned, modified in place, never retained.
+ *   - DEVICE buffers (alch_buf) are library-owned handles holding ring elements limb-major in HBM:
+ *     element e, limb j, coefficient k at word (e*L + j)*n + k; 32-bit words when every q_j < 2^31
+ *     (all of ALCHEMY's moduli, PT2CT.hs:137-139,283-285), 64-bit words otherwise (q < 2^62).
+ *   - Pow basis = coefficient vector; Dec basis == Pow basis for a two-power index; CRT basis slot k
+ *     holds a(psi^(2*brev(k)+1)), psi = g^((q-1)/m), g = smallest generator of Z_q^*.
+ *   - all work is queued on the ring's HIP stream; alch_sync() waits for it.  Entry points are
+ *     re-entrant across rings; one ring must not be driven from two threads at once.
+ *   - there is NO CPU fallback: without a gfx950 device every compute entry point fails with
+ *     ALCH_E_NO_DEVICE.
+ */
+#ifndef ALCHEMY_HIP_H
+#define ALCHEMY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALCH_OK 0
+#define ALCH_E_INVALID (-1)        /* bad argument (null, size, basis) */
+#define ALCH_E_NOT_PRIME (-2)      /* a modulus is not prime */
+#define ALCH_E_NO_CRT (-3)         /* q != 1 mod m: Lol's crtFuncs returns Nothing */
+#define ALCH_E_UNSUPPORTED (-4)    /* index not a power of two, n < 16, q too large */
+#define ALCH_E_NO_DEVICE (-5)      /* no gfx950 device / HIP runtime error at init */
+#define ALCH_E_HIP (-6)            /* HIP runtime error (message in alch_last_error) */
+#define ALCH_E_NOMEM (-7)
+#define ALCH_NOT_DIVISIBLE 1       /* divG family: Lol's Nothing (never happens for a two-power index) */
+
+typedef struct alch_ring alch_ring;
+typedef struct alch_buf alch_buf;
+typedef struct alch_hint alch_hint;
+
+/* flags of alch_ct_mul_relin */
+#define ALCH_POW_IN 1u             /* inputs are in the Pow basis (crt applied first)          */
+#define ALCH_POW_OUT 2u            /* outputs wanted in the Pow basis (crtInv applied last)     */
+
+/* gadgets (Crypto/Alchemy/Interpreter/PT2CT.hs:139-140) */
+#define ALCH_GAD_TRIV 0            /* TrivGad: one digit per limb, centred lift                 */
+#define ALCH_GAD_BASE2 1           /* BaseBGad 2 (host decompose only in this round)            */
+
+const char *alch_last_error(void);
+/* Library/ABI version: (major<<16)|minor. */
+uint32_t alch_version(void);
+
+/* ---- ring context ------------------------------------------------------------------------------
+ * Replaces the per-call twiddle/modulus arguments lol-cpp receives from Haskell; built once per
+ * (index, modulus-list) type, i.e. once per `Cyc t m' zq` instance (PT2CT.hs:251-254).
+ * m = cyclotomic index (2n).  Validates q prime and q == 1 mod m (else ALCH_E_NO_CRT, the CRTrans
+ * failure of Lol's crtFuncs), builds device-resident twiddle tables with the root rule above. */
+int alch_ring_create(uint32_t m, int L, const uint64_t *q, alch_ring **out);
+int alch_ring_destroy(alch_ring *ring);
+/* Host-only (no GPU needed): the root-rule constants of one modulus, for cross-checking against the
+ * oracle: psi (primitive m-th root), and the smallest generator. */
+int alch_host_root(uint32_t m, uint64_t q, uint64_t *psi, uint64_t *generator);
+int alch_ring_n(const alch_ring *ring, uint32_t *n, int *L, int *word_bytes);
+/* Use an externally created hipStream_t (e.g. torch's current stream) for all work of this ring. */
+int alch_ring_set_stream(alch_ring *ring, void *hip_stream);
+int alch_sync(alch_ring *ring);
+/* HIP-event timer on the ring's stream (what bench.py brackets the timed region with). */
+int alch_timer_start(alch_ring *ring);
+int alch_timer_stop(alch_ring *ring, float *elapsed_ms);
+
+/* ---- Tensor methods on host buffers (one ring element, Lol layout, in place) --------------------
+ * crt/crtInv: Tensor `crtFuncs` -> crt, crtInv; reached from every Cyc ring product under
+ * (*) on CT (Crypto/Alchemy/Interpreter/Eval.hs:65-67) and keySwitchQuadCirc (Eval.hs:133). */
+int alch_crt(alch_ring *ring, int64_t *data);
+int alch_crtinv(alch_ring *ring, int64_t *data);
+/* zipWithT (*), (+), (-) in one basis (CRT for mul): the pointwise half of a Cyc product. */
+int alch_mul(alch_ring *ring, int64_t *a, const int64_t *b);
+int alch_add(alch_ring *ring, int64_t *a, const int64_t *b);
+int alch_sub(alch_ring *ring, int64_t *a, const int64_t *b);
+/* Multiply limb j by scalar s[j] (scalarPow/scalarCRT product: toLSD/toMSD of SymmSHE). */
+int alch_scale(alch_ring *ring, int64_t *a, const uint64_t *s);
+/* mulG and divG families (Tensor mulGPow/mulGDec/mulGCRT, divGPow/divGDec/divGCRT; used by (*) on CT, which
+ * applies mulG to every product coefficient).  g_m = 1 for a two-power index: identity; divG returns
+ * ALCH_OK (Lol's Just) and never ALCH_NOT_DIVISIBLE. */
+int alch_mulg_pow(alch_ring *ring, int64_t *a);
+int alch_mulg_dec(alch_ring *ring, int64_t *a);
+int alch_mulg_crt(alch_ring *ring, int64_t *a);
+int alch_divg_pow(alch_ring *ring, int64_t *a);
+int alch_divg_dec(alch_ring *ring, int64_t *a);
+int alch_divg_crt(alch_ring *ring, int64_t *a);
+/* Lol `decompose` for TrivGad followed by `reduce` of every digit (the first half of `switch` in
+ * keySwitchQuadCirc, Eval.hs:133): c in the Pow basis; digits = L consecutive ring elements (each
+ * n*L int64, Pow basis), digit i = centred lift of limb i reduced into every limb. */
+int alch_decompose_triv(alch_ring *ring, const int64_t *c_pow, int64_t *digits);
+
+/* ---- device-resident ring-element arrays --------------------------------------------------------
+ * What a Haskell `ForeignPtr`-wrapped tensor would hold; upload/download do the AoS <-> limb-major
+ * transpose (and the 64 -> 32 bit narrowing when the ring uses 32-bit words). */
+int alch_buf_alloc(alch_ring *ring, size_t n_elems, alch_buf **out);
+int alch_buf_free(alch_buf *buf);
+int alch_buf_elems(const alch_buf *buf, size_t *n_elems);
+int alch_buf_upload(alch_buf *buf, size_t first, size_t count, const int64_t *host);
+int alch_buf_download(const alch_buf *buf, size_t first, size_t count, int64_t *host);
+/* Synthetic residues: word (e,j,k) = splitmix64(seed + ((e*L + j)*n + k)) mod q_j  (oracle:
+ * orc_fill_uniform uses the same rule). */
+int alch_buf_fill_uniform(alch_buf *buf, uint64_t seed);
+/* Batched Tensor crt / crtInv / pointwise ops on elements [first, first+count). */
+int alch_buf_crt(alch_buf *buf, size_t first, size_t count);
+int alch_buf_crtinv(alch_buf *buf, size_t first, size_t count);
+int alch_buf_mul(alch_buf *dst, const alch_buf *a, const alch_buf *b, size_t count);
+int alch_buf_add(alch_buf *dst, const alch_buf *a, const alch_buf *b, size_t count);
+/* 64-bit order-independent checksum of elements [first, first+count): sum over words of
+ * splitmix64(position ^ value<<20) -- used by the full-size parity tests. */
+int alch_buf_checksum(const alch_buf *buf, size_t first, size_t count, uint64_t *sum);
+
+/* ---- key-switch hint ----------------------------------------------------------------------------
+ * KSQuadCircHint gad (Cyc t m' zq) as produced by ksQuadCircHint
+ * (Crypto/Alchemy/Interpreter/KeysHints.hs:101-113): one degree-1 polynomial (h0_i, h1_i) per gadget
+ * digit.  host: 2*L consecutive ring elements in the CRT basis, order h0_0, h1_0, h0_1, h1_1, ... .
+ * Kept device-resident (Montgomery form) for every later call. */
+int alch_hint_load(alch_ring *ring, int gadget, const int64_t *host_crt, alch_hint **out);
+/* Same, taking 2*L CRT-basis elements already on the device (e.g. synthetic). */
+int alch_hint_from_buf(alch_ring *ring, int gadget, const alch_buf *src, alch_hint **out);
+int alch_hint_free(alch_hint *hint);
+
+/* ---- the hot path -------------------------------------------------------------------------------
+ * out[b] = keySwitchQuadCirc hint (a[b] * b[b])  for b < batch: SymmSHE (*) (Eval.hs:65-67) followed
+ * by keySwitchQuadCirc (Eval.hs:133) as PT2CT's mul_ sequences them (PT2CT.hs:172-177), on linear
+ * ciphertexts.  a, b, out hold 2*batch ring elements: ciphertext b = elements (2b, 2b+1) = (c0, c1).
+ * s_pre[j] = per-limb scalar folded into the tensor product: the product of both operands' toLSD
+ * scalars and of keySwitchQuadCirc's toMSD scalar (p^-1 mod q_j when both operands are LSD); NULL = 1.
+ * The (enc, k, l) metadata of SymmSHE's CT stays on the host (k1+k2+1, l1*l2 -- see
+ * alchemy_amd/host/symmshe.hpp).  flags: ALCH_POW_IN / ALCH_POW_OUT; default is CRT basis in and out,
+ * the representation Lol's Cyc keeps fresh ciphertexts and ring products in. */
+int alch_ct_mul_relin(alch_ring *ring, const alch_hint *hint, const alch_buf *a, const alch_buf *b,
+                      alch_buf *out, size_t batch, const uint64_t *s_pre, unsigned flags);
+
+/* ---- modSwitch building block (Eval.hs:130) ---------------------------------------
+ * Rescale (a,b) -> b on Pow-basis elements: src lives in ring_src (L limbs), dst in ring_dst whose
+ * limbs are ring_src's limbs 1..L-1:  dst_j = q_0^-1 * (src_j - reduce(lift src_0)). */
+int alch_buf_rescale_drop0(const alch_buf *src, alch_buf *dst, size_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALCHEMY_HIP_H */

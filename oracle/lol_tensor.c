@@ -1,0 +1,423 @@
+/*
+ * oracle/lol_tensor.c -- CPU restatement ("Lol-algorithm restatement", NOT Lol) of the tensor and
+ * SymmSHE arithmetic under ALCHEMY's ciphertext multiply + relinearize.
+ *
+ * TEST INFRASTRUCTURE ONLY: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * link or call this file, and only as the checker / the reported CPU baseline.  The product library
+ * (alchemy_amd/csrc) never includes, links or falls back to anything in oracle/.
+ *
+ * PARITY UNPINNED: the arithmetic of this path lives in the un-vendored third-party packages lol,
+ * lol-apps and lol-cpp (github.com/cpeikert/lol, branch alchemy-args-debruijn-monad,
+ * /root/reference/stack.yaml:54-60; cabal bounds lol >= 0.7, lol-apps >= 0.2, alchemy.cabal:51-52).
+ * Their sources are not in this pipeline, no Haskell toolchain exists, and the reference holds no
+ * tests, golden vectors or fixtures for the path.  This file restates the published
+ * algorithm (Crockett & Peikert, CCS'16; lol-cpp's scalar in-place C++ kernels over tuple-interleaved
+ * Int64 arrays) and is checked against oracle/model.py (exact definitions: direct-evaluation CRT,
+ * schoolbook products) -- not against Lol.
+ *
+ * What it follows, by reference call site:
+ *   crt / crtInv (Tensor methods behind every Cyc ring product)   examples/Arithmetic.hs:19,23
+ *   (*) on CT                                                    Crypto/Alchemy/Interpreter/Eval.hs:65-67
+ *   keySwitchQuadCirc                                            Eval.hs:133
+ *   modSwitch                                                    Eval.hs:130
+ *   op order of one mul_                                         Crypto/Alchemy/Interpreter/PT2CT.hs:172-177
+ *   storage type ZqBasic q Int64                                 examples/Common.hs:35
+ *
+ * Conventions (identical in oracle/model.py and include/alchemy_hip.h):
+ *   ring R'_q = Z_q[X]/(X^n+1), n a power of two (cyclotomic index m' = 2n)
+ *   layout: Lol's tuple-interleaved "AoS": coefficient i, limb j at data[i*L + j], int64, in [0,q_j)
+ *   root rule: g = smallest generator of Z_q^*, psi = g^((q-1)/(2n))
+ *   CRT slot k holds a(psi^(2*brev(k)+1))
+ *   algorithm: CRT_{2^e} = twist by psi^i, then an in-place radix-2 DFT of size n with omega = psi^2
+ *   (natural order in, bit-reversed order out); every modular product is a hardware `%`.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+typedef int64_t i64;
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+
+#define ORC_MAX_LIMBS 16
+
+typedef struct {
+    i64 n;               /* ring dimension */
+    int logn;
+    int L;               /* RNS limbs */
+    i64 q[ORC_MAX_LIMBS];
+    i64 psi[ORC_MAX_LIMBS];
+    i64 ninv[ORC_MAX_LIMBS];
+    i64 *twist[ORC_MAX_LIMBS];    /* psi^i, i < n */
+    i64 *itwist[ORC_MAX_LIMBS];   /* n^-1 * psi^-i */
+    i64 *omega[ORC_MAX_LIMBS];    /* omega^i, i < n/2 (omega = psi^2) */
+    i64 *iomega[ORC_MAX_LIMBS];   /* omega^-i */
+} orc_ring;
+
+/* ------------------------------------------------------------------ scalar arithmetic */
+
+static inline i64 mulmod(i64 a, i64 b, i64 q) {
+    if (q < ((i64)1 << 31)) return (a * b) % q;      /* Lol: Int64 products, q < 2^31.5 */
+    return (i64)(((u128)(u64)a * (u64)b) % (u64)q);  /* 60-bit q of BASELINE config 2 */
+}
+static inline i64 addmod(i64 a, i64 b, i64 q) { i64 s = a + b; return s >= q ? s - q : s; }
+static inline i64 submod(i64 a, i64 b, i64 q) { i64 s = a - b; return s < 0 ? s + q : s; }
+
+static i64 powmod(i64 b, u64 e, i64 q) {
+    i64 r = 1 % q;
+    b %= q;
+    while (e) {
+        if (e & 1) r = mulmod(r, b, q);
+        b = mulmod(b, b, q);
+        e >>= 1;
+    }
+    return r;
+}
+
+static int is_prime_u64(u64 n) {
+    static const u64 bases[] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+    if (n < 2) return 0;
+    for (int i = 0; i < 12; ++i) {
+        if (n % bases[i] == 0) return n == bases[i];
+    }
+    u64 d = n - 1;
+    int s = 0;
+    while ((d & 1) == 0) { d >>= 1; ++s; }
+    for (int i = 0; i < 12; ++i) {
+        i64 x = powmod((i64)bases[i], d, (i64)n);
+        if (x == 1 || (u64)x == n - 1) continue;
+        int comp = 1;
+        for (int r = 1; r < s; ++r) {
+            x = mulmod(x, x, (i64)n);
+            if ((u64)x == n - 1) { comp = 0; break; }
+        }
+        if (comp) return 0;
+    }
+    return 1;
+}
+
+/* smallest generator of Z_q^*: trial-division factorisation of q-1 (q-1 = 2^k * odd, odd < 2^46) */
+i64 orc_smallest_generator(i64 q) {
+    u64 fac[64];
+    int nf = 0;
+    u64 m = (u64)q - 1;
+    for (u64 p = 2; p * p <= m; p += (p == 2 ? 1 : 2)) {
+        if (m % p == 0) {
+            fac[nf++] = p;
+            while (m % p == 0) m /= p;
+        }
+    }
+    if (m > 1) fac[nf++] = m;
+    for (i64 g = 2;; ++g) {
+        int ok = 1;
+        for (int i = 0; i < nf && ok; ++i)
+            if (powmod(g, ((u64)q - 1) / fac[i], q) == 1) ok = 0;
+        if (ok) return g;
+    }
+}
+
+static inline i64 centred(i64 x, i64 q) { return (2 * x < q) ? x : x - q; }
+
+/* ------------------------------------------------------------------ ring context */
+
+void orc_ring_free(orc_ring *r) {
+    for (int j = 0; j < r->L; ++j) {
+        free(r->twist[j]); free(r->itwist[j]); free(r->omega[j]); free(r->iomega[j]);
+        r->twist[j] = r->itwist[j] = r->omega[j] = r->iomega[j] = NULL;
+    }
+}
+
+/* returns 0 on success, -1 bad argument, -2 q not prime, -3 q != 1 mod 2n (Lol: CRTrans = Nothing) */
+int orc_ring_init(orc_ring *r, i64 n, int L, const i64 *q) {
+    memset(r, 0, sizeof *r);
+    if (n < 2 || (n & (n - 1)) || L < 1 || L > ORC_MAX_LIMBS) return -1;
+    r->n = n;
+    r->L = L;
+    r->logn = 0;
+    while (((i64)1 << r->logn) < n) ++r->logn;
+    for (int j = 0; j < L; ++j) {
+        if (q[j] < 3 || !is_prime_u64((u64)q[j])) return -2;
+        if ((q[j] - 1) % (2 * n)) return -3;
+        r->q[j] = q[j];
+    }
+    for (int j = 0; j < L; ++j) {
+        i64 qj = q[j];
+        i64 g = orc_smallest_generator(qj);
+        i64 psi = powmod(g, (u64)(qj - 1) / (u64)(2 * n), qj);
+        i64 ipsi = powmod(psi, (u64)qj - 2, qj);
+        i64 om = mulmod(psi, psi, qj), iom = mulmod(ipsi, ipsi, qj);
+        r->psi[j] = psi;
+        r->ninv[j] = powmod(n % qj, (u64)qj - 2, qj);
+        r->twist[j] = malloc(sizeof(i64) * n);
+        r->itwist[j] = malloc(sizeof(i64) * n);
+        r->omega[j] = malloc(sizeof(i64) * (n / 2 ? n / 2 : 1));
+        r->iomega[j] = malloc(sizeof(i64) * (n / 2 ? n / 2 : 1));
+        i64 a = 1, b = r->ninv[j];
+        for (i64 i = 0; i < n; ++i) {
+            r->twist[j][i] = a;
+            r->itwist[j][i] = b;
+            a = mulmod(a, psi, qj);
+            b = mulmod(b, ipsi, qj);
+        }
+        a = 1; b = 1;
+        for (i64 i = 0; i < n / 2; ++i) {
+            r->omega[j][i] = a;
+            r->iomega[j][i] = b;
+            a = mulmod(a, om, qj);
+            b = mulmod(b, iom, qj);
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ Tensor methods (in place, AoS) */
+
+/* crt: Pow basis -> CRT basis.  One limb (stride L) at a time, like lol-cpp's per-tuple-component loop. */
+void orc_crt(const orc_ring *r, i64 *data) {
+    const i64 n = r->n;
+    const int L = r->L;
+    for (int j = 0; j < L; ++j) {
+        const i64 q = r->q[j];
+        i64 *x = data + j;
+        for (i64 i = 0; i < n; ++i) x[i * L] = mulmod(x[i * L], r->twist[j][i], q);
+        /* radix-2 decimation in frequency: natural in, bit-reversed out */
+        for (i64 half = n / 2, step = 1; half >= 1; half >>= 1, step <<= 1) {
+            for (i64 base = 0; base < n; base += 2 * half) {
+                for (i64 k = 0; k < half; ++k) {
+                    i64 *u = &x[(base + k) * L], *v = &x[(base + k + half) * L];
+                    i64 s = addmod(*u, *v, q);
+                    i64 d = submod(*u, *v, q);
+                    *u = s;
+                    *v = mulmod(d, r->omega[j][k * step], q);
+                }
+            }
+        }
+    }
+}
+
+/* crtInv: CRT basis -> Pow basis (includes the n^-1 scaling, Lol's mhat^-1). */
+void orc_crtinv(const orc_ring *r, i64 *data) {
+    const i64 n = r->n;
+    const int L = r->L;
+    for (int j = 0; j < L; ++j) {
+        const i64 q = r->q[j];
+        i64 *x = data + j;
+        /* radix-2 decimation in time: bit-reversed in, natural out */
+        for (i64 half = 1, step = n / 2; half < n; half <<= 1, step >>= 1) {
+            for (i64 base = 0; base < n; base += 2 * half) {
+                for (i64 k = 0; k < half; ++k) {
+                    i64 *u = &x[(base + k) * L], *v = &x[(base + k + half) * L];
+                    i64 t = mulmod(*v, r->iomega[j][k * step], q);
+                    i64 s = addmod(*u, t, q);
+                    i64 d = submod(*u, t, q);
+                    *u = s;
+                    *v = d;
+                }
+            }
+        }
+        for (i64 i = 0; i < n; ++i) x[i * L] = mulmod(x[i * L], r->itwist[j][i], q);
+    }
+}
+
+/* zipWithT (*) / (+) / (-) on two tensors of the same basis */
+void orc_mul(const orc_ring *r, i64 *a, const i64 *b) {
+    const i64 N = r->n * r->L;
+    for (i64 t = 0; t < N; ++t) a[t] = mulmod(a[t], b[t], r->q[t % r->L]);
+}
+void orc_add(const orc_ring *r, i64 *a, const i64 *b) {
+    const i64 N = r->n * r->L;
+    for (i64 t = 0; t < N; ++t) a[t] = addmod(a[t], b[t], r->q[t % r->L]);
+}
+void orc_sub(const orc_ring *r, i64 *a, const i64 *b) {
+    const i64 N = r->n * r->L;
+    for (i64 t = 0; t < N; ++t) a[t] = submod(a[t], b[t], r->q[t % r->L]);
+}
+/* scalarPow/scalarCRT-style multiply by a per-limb scalar */
+void orc_scale(const orc_ring *r, i64 *a, const i64 *s) {
+    const i64 N = r->n * r->L;
+    for (i64 t = 0; t < N; ++t) a[t] = mulmod(a[t], s[t % r->L], r->q[t % r->L]);
+}
+
+/* mulG / divG on any basis: g_m = 1 for a two-power index, so both are the identity and
+ * divG always succeeds (returns 1, Lol's `Just`). */
+int orc_mulg(const orc_ring *r, i64 *a) { (void)r; (void)a; return 1; }
+int orc_divg(const orc_ring *r, i64 *a) { (void)r; (void)a; return 1; }
+
+/* TrivGad decompose + reduce: c in the Pow basis; digits[i] (AoS, n*L) = reduce(centred lift of limb i)
+ * into every limb.  (Lol: decompose (a,b) = decompose a ++ decompose b, then `reduce <$>`.) */
+void orc_decompose_triv(const orc_ring *r, const i64 *c, i64 *const *digits) {
+    const i64 n = r->n;
+    const int L = r->L;
+    for (int i = 0; i < L; ++i) {
+        for (i64 k = 0; k < n; ++k) {
+            i64 z = centred(c[k * L + i], r->q[i]);
+            for (int j = 0; j < L; ++j) {
+                i64 v = z % r->q[j];
+                digits[i][k * L + j] = v < 0 ? v + r->q[j] : v;
+            }
+        }
+    }
+}
+
+/* number of BaseBGad-2 digits of modulus q: ceil(log2 q) */
+int orc_baseb_digits(i64 q) {
+    int k = 0;
+    u64 v = 1;
+    while (v < (u64)q) { v <<= 1; ++k; }
+    return k;
+}
+
+/* BaseBGad 2 decompose + reduce: balanced binary digits in {-1,0} ... of the centred lift, least
+ * significant first, the top digit absorbing the remainder; digits laid out limb after limb. */
+void orc_decompose_base2(const orc_ring *r, const i64 *c, i64 *const *digits) {
+    const i64 n = r->n;
+    const int L = r->L;
+    int off = 0;
+    for (int i = 0; i < L; ++i) {
+        int kd = orc_baseb_digits(r->q[i]);
+        for (i64 k = 0; k < n; ++k) {
+            i64 v = centred(c[k * L + i], r->q[i]);
+            for (int t = 0; t < kd; ++t) {
+                i64 d;
+                if (t < kd - 1) {
+                    d = ((v % 2) + 2) % 2;
+                    if (2 * d >= 2) d -= 2;
+                    v = (v - d) / 2;
+                } else {
+                    d = v;
+                }
+                for (int j = 0; j < L; ++j) {
+                    i64 w = d % r->q[j];
+                    digits[off + t][k * L + j] = w < 0 ? w + r->q[j] : w;
+                }
+            }
+        }
+        off += kd;
+    }
+}
+
+/* ------------------------------------------------------------------ SymmSHE hot path */
+
+/* keySwitchQuadCirc hint (a * b) on ciphertexts given in the CRT basis (the representation Lol's Cyc
+ * keeps fresh ciphertexts and ring products in), result in the CRT basis.
+ *   a0,a1,b0,b1 : linear ciphertext components (AoS, n*L)
+ *   hint        : 2*L arrays (AoS, CRT basis): hint[2*i] = h0_i, hint[2*i+1] = h1_i   (TrivGad)
+ *   s_pre       : per-limb scalar applied to the tensor product (product of the toLSD scalars of both
+ *                 operands and the toMSD scalar of the key switch; all 1 when nothing changes encoding)
+ *   out0,out1   : result components
+ * Work done, as Lol does it: 4 pointwise ring products + 1 add, crtInv of c2 (L transforms), decompose,
+ * crt of every reduced digit on every limb (L*L transforms), 2*L*L pointwise multiply-accumulates. */
+void orc_ct_mul_relin_crt(const orc_ring *r, const i64 *const *hint, const i64 *a0, const i64 *a1,
+                          const i64 *b0, const i64 *b1, const i64 *s_pre, i64 *out0, i64 *out1) {
+    const i64 N = r->n * r->L;
+    const int L = r->L;
+    i64 *c2 = malloc(sizeof(i64) * N), *tmp = malloc(sizeof(i64) * N);
+    i64 **dig = malloc(sizeof(i64 *) * L);
+    for (int i = 0; i < L; ++i) dig[i] = malloc(sizeof(i64) * N);
+
+    /* (*) : c0 = a0 b0, c1 = a0 b1 + a1 b0, c2 = a1 b1 ; mulG = id */
+    memcpy(out0, a0, sizeof(i64) * N); orc_mul(r, out0, b0);
+    memcpy(out1, a0, sizeof(i64) * N); orc_mul(r, out1, b1);
+    memcpy(tmp, a1, sizeof(i64) * N);  orc_mul(r, tmp, b0);
+    orc_add(r, out1, tmp);
+    memcpy(c2, a1, sizeof(i64) * N);   orc_mul(r, c2, b1);
+    /* toMSD (and the operands' toLSD) as one per-limb scalar */
+    orc_scale(r, out0, s_pre); orc_scale(r, out1, s_pre); orc_scale(r, c2, s_pre);
+
+    /* keySwitchQuadCirc: decompose needs the Pow basis */
+    orc_crtinv(r, c2);
+    orc_decompose_triv(r, c2, dig);
+    for (int i = 0; i < L; ++i) {
+        orc_crt(r, dig[i]);
+        memcpy(tmp, dig[i], sizeof(i64) * N); orc_mul(r, tmp, hint[2 * i]);     orc_add(r, out0, tmp);
+        memcpy(tmp, dig[i], sizeof(i64) * N); orc_mul(r, tmp, hint[2 * i + 1]); orc_add(r, out1, tmp);
+    }
+    for (int i = 0; i < L; ++i) free(dig[i]);
+    free(dig); free(tmp); free(c2);
+}
+
+/* Same with Pow-basis inputs and outputs (adds 4 crt on the way in and 2 crtInv on the way out). */
+void orc_ct_mul_relin_pow(const orc_ring *r, const i64 *const *hint, const i64 *a0, const i64 *a1,
+                          const i64 *b0, const i64 *b1, const i64 *s_pre, i64 *out0, i64 *out1) {
+    const i64 N = r->n * r->L;
+    i64 *buf = malloc(sizeof(i64) * N * 4);
+    const i64 *src[4] = {a0, a1, b0, b1};
+    for (int t = 0; t < 4; ++t) {
+        memcpy(buf + t * N, src[t], sizeof(i64) * N);
+        orc_crt(r, buf + t * N);
+    }
+    orc_ct_mul_relin_crt(r, hint, buf, buf + N, buf + 2 * N, buf + 3 * N, s_pre, out0, out1);
+    orc_crtinv(r, out0);
+    orc_crtinv(r, out1);
+    free(buf);
+}
+
+/* ------------------------------------------------------------------ RNS rescale (modSwitch), SURVEY 8(f) N1 */
+
+/* Rescale (a,b) -> b on a Pow-basis element: drops limb 0 (the outermost pair component).
+ * in: AoS n*L, out: AoS n*(L-1):  out_j = q_0^-1 * (x_j - reduce(lift x_0))  */
+void orc_rescale_drop0(const orc_ring *r, const i64 *in, i64 *out) {
+    const i64 n = r->n;
+    const int L = r->L;
+    i64 qinv[ORC_MAX_LIMBS];
+    for (int j = 1; j < L; ++j) qinv[j] = powmod(r->q[0] % r->q[j], (u64)r->q[j] - 2, r->q[j]);
+    for (i64 k = 0; k < n; ++k) {
+        i64 z = centred(in[k * L], r->q[0]);
+        for (int j = 1; j < L; ++j) {
+            i64 zr = z % r->q[j];
+            if (zr < 0) zr += r->q[j];
+            out[k * (L - 1) + (j - 1)] = mulmod(submod(in[k * L + j], zr, r->q[j]), qinv[j], r->q[j]);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ synthetic data + timing helpers */
+
+static inline u64 splitmix64(u64 x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+/* The synthetic-residue rule shared with the HIP library's alch_buf_fill_uniform:
+ * limb-major position (elem, limb j, coefficient k) of a buffer gets
+ *   splitmix64(seed + ((elem*L + j)*n + k)) mod q_j.   Written here into the AoS layout. */
+void orc_fill_uniform(const orc_ring *r, i64 *data, u64 seed, u64 elem) {
+    for (int j = 0; j < r->L; ++j)
+        for (i64 k = 0; k < r->n; ++k)
+            data[k * r->L + j] = (i64)(splitmix64(seed + ((elem * (u64)r->L + (u64)j) * (u64)r->n + (u64)k)) % (u64)r->q[j]);
+}
+
+/* Time `ops` keySwitchQuadCirc(a*b) on CRT-basis synthetic inputs, single thread; returns seconds. */
+double orc_bench_mul_relin(const orc_ring *r, int ops, u64 seed) {
+    const i64 N = r->n * r->L;
+    const int L = r->L;
+    i64 *buf = malloc(sizeof(i64) * N * 6);
+    i64 **hint = malloc(sizeof(i64 *) * 2 * L);
+    i64 ones[ORC_MAX_LIMBS];
+    for (int j = 0; j < L; ++j) ones[j] = 1;
+    for (int i = 0; i < 2 * L; ++i) {
+        hint[i] = malloc(sizeof(i64) * N);
+        orc_fill_uniform(r, hint[i], seed ^ 0xA1C4E5ull, (u64)i);
+    }
+    struct timespec t0, t1;
+    double total = 0.0;
+    for (int op = 0; op < ops; ++op) {
+        for (int t = 0; t < 4; ++t) orc_fill_uniform(r, buf + t * N, seed, (u64)(op * 4 + t));
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        orc_ct_mul_relin_crt(r, (const i64 *const *)hint, buf, buf + N, buf + 2 * N, buf + 3 * N, ones,
+                             buf + 4 * N, buf + 5 * N);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        total += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    }
+    for (int i = 0; i < 2 * L; ++i) free(hint[i]);
+    free(hint); free(buf);
+    return total;
+}
+
+orc_ring *orc_ring_new(void) { return calloc(1, sizeof(orc_ring)); }
+void orc_ring_delete(orc_ring *r) { if (r) { orc_ring_free(r); free(r); } }
+i64 orc_ring_psi(const orc_ring *r, int j) { return r->psi[j]; }

@@ -1,0 +1,105 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Bit-exact (integer arithmetic)."""
+import numpy as np
+import pytest
+
+from conftest import ARITH_QS, CFG2_Q60, CFG3_QS
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_elems(rng, count, n, qs):
+    return np.stack([np.stack([rng.integers(0, q, size=n, dtype=np.int64) for q in qs], axis=1) for _ in range(count)])
+
+
+def _ring_pair(oracle_lib, n, qs):
+    import alchemy_amd as A
+    return A.Ring(2 * n, qs), oracle_lib.Ring(n, qs)
+
+
+@pytest.mark.parametrize("logn", [4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
+def test_crt_crtinv_match_oracle(oracle_lib, logn):
+    n = 1 << logn
+    qs = CFG3_QS[:3] if logn > 8 else ARITH_QS
+    g, o = _ring_pair(oracle_lib, n, qs)
+    rng = np.random.default_rng(100 + logn)
+    x = _rand_elems(rng, 3, n, qs)
+    buf = g.upload(x)
+    buf.crt()
+    got = buf.download()
+    for e in range(3):
+        assert np.array_equal(got[e], o.crt(x[e])), f"crt mismatch elem {e}"
+    buf.crtinv()
+    assert np.array_equal(buf.download(), x), "crtInv . crt != id"
+    # crtInv on arbitrary CRT-basis input against the oracle
+    y = _rand_elems(rng, 2, n, qs)
+    b2 = g.upload(y)
+    b2.crtinv()
+    got = b2.download()
+    for e in range(2):
+        assert np.array_equal(got[e], o.crtinv(y[e]))
+
+
+@pytest.mark.parametrize("logn", [4, 8, 14])
+def test_crt_60bit(oracle_lib, logn):
+    n = 1 << logn
+    qs = [CFG2_Q60]
+    g, o = _ring_pair(oracle_lib, n, qs)
+    assert g.word_bytes == 8
+    rng = np.random.default_rng(7)
+    x = _rand_elems(rng, 2, n, qs)
+    buf = g.upload(x)
+    buf.crt()
+    got = buf.download()
+    for e in range(2):
+        assert np.array_equal(got[e], o.crt(x[e]))
+    buf.crtinv()
+    assert np.array_equal(buf.download(), x)
+    # pointwise product = negacyclic convolution (config 2: fwd NTT + pointwise mul + inverse NTT)
+    a, b = g.upload(x[:1]), g.upload(x[1:])
+    a.crt(); b.crt()
+    c = g.alloc(1)
+    c.mul(a, b, 1)
+    c.crtinv()
+    want = o.crtinv(o.mul(o.crt(x[0]), o.crt(x[1])))
+    assert np.array_equal(c.download()[0], want)
+
+
+def _mul_relin_case(oracle_lib, n, qs, batch, seed, s_pre=None, pow_basis=False):
+    import alchemy_amd as A
+    g, o = _ring_pair(oracle_lib, n, qs)
+    L = len(qs)
+    rng = np.random.default_rng(seed)
+    hint = _rand_elems(rng, 2 * L, n, qs)
+    a = _rand_elems(rng, 2 * batch, n, qs)
+    b = _rand_elems(rng, 2 * batch, n, qs)
+    gh = g.hint_load(hint)
+    ga, gb, gout = g.upload(a), g.upload(b), g.alloc(2 * batch)
+    flags = (A.capi.ALCH_POW_IN | A.capi.ALCH_POW_OUT) if pow_basis else 0
+    g.ct_mul_relin(gh, ga, gb, gout, batch, s_pre=s_pre, flags=flags)
+    got = gout.download()
+    for ct in range(batch):
+        w0, w1 = o.ct_mul_relin(list(hint), a[2 * ct], a[2 * ct + 1], b[2 * ct], b[2 * ct + 1], s_pre=s_pre,
+                                pow_basis=pow_basis)
+        assert np.array_equal(got[2 * ct], w0), f"c0 mismatch ct {ct}"
+        assert np.array_equal(got[2 * ct + 1], w1), f"c1 mismatch ct {ct}"
+
+
+@pytest.mark.parametrize("logn,qs,batch", [
+    (4, ARITH_QS, 3), (6, ARITH_QS[:2], 9), (8, ARITH_QS, 5), (8, ARITH_QS[:1], 2),
+    (10, CFG3_QS, 3), (12, CFG3_QS[:2], 2), (13, CFG3_QS, 2), (14, CFG3_QS, 1), (15, CFG3_QS, 2),
+])
+def test_ct_mul_relin_crt_basis(oracle_lib, logn, qs, batch):
+    _mul_relin_case(oracle_lib, 1 << logn, qs, batch, seed=1000 + logn)
+
+
+@pytest.mark.parametrize("logn,qs,batch", [(4, ARITH_QS, 2), (8, ARITH_QS, 3), (12, CFG3_QS, 1), (15, CFG3_QS, 1)])
+def test_ct_mul_relin_pow_basis(oracle_lib, logn, qs, batch):
+    _mul_relin_case(oracle_lib, 1 << logn, qs, batch, seed=2000 + logn, pow_basis=True)
+
+
+def test_ct_mul_relin_with_encoding_scalar(oracle_lib):
+    # toLSD/toMSD scalars folded into the tensor product: s = p^-1 mod q (p = 7, examples/Arithmetic.hs:23)
+    qs = ARITH_QS
+    s = [pow(7, -1, q) for q in qs]
+    _mul_relin_case(oracle_lib, 256, qs, 2, seed=77, s_pre=s)
