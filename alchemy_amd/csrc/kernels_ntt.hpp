@@ -35,6 +35,10 @@ template <typename W> struct Signed;
 template <> struct Signed<u32> { typedef int32_t type; };
 template <> struct Signed<u64> { typedef int64_t type; };
 
+}  // namespace alch
+#include "kernel_ks_half.hpp"
+namespace alch {
+
 enum OpKind { OP_CRT = 0, OP_CRTINV = 1, OP_TENSOR_INTT = 2, OP_KS_ACCUM = 3 };
 
 template <typename W>
@@ -230,7 +234,7 @@ k_ks_accum(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
         const W* twf = R.twf[j];
         int tid = threadIdx.x;
         asm volatile("" : "+s"(twf), "+v"(tid));
-        ntt_forward<LOGN, W, true, true>(lds, twf, q, qni, tid, [&](int g, int base, W* x) {
+        ntt_forward<LOGN, W, true, true>(lds, twf, q, qni, tid, [&acc0, &acc1, h0, h1, q, qni](int g, int base, W* x) {
 #pragma unroll
             for (int k = 0; k < 16; k += VL) {
                 V vh0 = *reinterpret_cast<const V*>(h0 + base + k), vh1 = *reinterpret_cast<const V*>(h1 + base + k);
@@ -295,6 +299,25 @@ inline hipError_t run_call(const NttCall<W>& c) {
         break;
     }
     case OP_KS_ACCUM: {
+        if constexpr (std::is_same<W, u32>::value && (LOGN == 15 || LOGN == 11)) {
+            // two workgroups per (ciphertext, limb): see kernel_ks_half.hpp
+            const size_t groups = (c.nct + 7) / 8;
+            const unsigned grid = (unsigned)(groups * 16 * (size_t)R.L);
+            const size_t half_lds = lds_bytes / 2;
+            constexpr int TH = 1 << (LOGN - 6);
+            if (c.balanced) {
+                auto k = k_ks_accum_half<LOGN, true>;
+                if ((e = set_lds(k, half_lds)) != hipSuccess) return e;
+                hipLaunchKernelGGL(k, dim3(grid), dim3(TH), half_lds, c.stream, R, c.a, c.b, (const int32_t*)c.digits,
+                                   c.hint, c.out, (unsigned)c.nct, c.spre_r2);
+            } else {
+                auto k = k_ks_accum_half<LOGN, false>;
+                if ((e = set_lds(k, half_lds)) != hipSuccess) return e;
+                hipLaunchKernelGGL(k, dim3(grid), dim3(TH), half_lds, c.stream, R, c.a, c.b, (const int32_t*)c.digits,
+                                   c.hint, c.out, (unsigned)c.nct, c.spre_r2);
+            }
+            break;
+        }
         const size_t groups = (c.nct + 7) / 8;
         const unsigned grid = (unsigned)(groups * 8 * (size_t)R.L);
         if (c.balanced) {

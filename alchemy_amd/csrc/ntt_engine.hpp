@@ -21,11 +21,11 @@
 
 namespace alch {
 
-template <int LOGN>
+template <int LOGN, int LOGT_ = -1>
 struct Geo {
     static_assert(LOGN >= 4 && LOGN <= 15, "ring dimension 16 .. 32768 per LDS-resident transform");
     static constexpr int N = 1 << LOGN;
-    static constexpr int LOGT = (LOGN - 4 > 10) ? 10 : (LOGN - 4);
+    static constexpr int LOGT = LOGT_ >= 0 ? LOGT_ : ((LOGN - 4 > 10) ? 10 : (LOGN - 4));
     static constexpr int T = 1 << LOGT;               // threads per workgroup
     static constexpr int E = N / T;                   // coefficients per thread per pass (16 or 32)
     static constexpr int NPASS = (LOGN + 3) / 4;
@@ -37,7 +37,7 @@ struct Geo {
 // stay contiguous (128-bit accesses remain legal).
 template <int LOGN>
 __device__ __forceinline__ int swz(int idx) {
-    if constexpr (Geo<LOGN>::SWZ) return idx ^ (((idx >> 6) & 3) << 2) ^ (((idx >> 8) & 3) << 4);
+    if constexpr (LOGN >= 10) return idx ^ (((idx >> 6) & 3) << 2) ^ (((idx >> 8) & 3) << 4);
     else return idx;
 }
 
@@ -45,26 +45,62 @@ template <typename W> struct Vec4;
 template <> struct Vec4<u32> { typedef u32 type __attribute__((ext_vector_type(4))); static constexpr int LANES = 4; };
 template <> struct Vec4<u64> { typedef u64 type __attribute__((ext_vector_type(2))); static constexpr int LANES = 2; };
 
+// ---- twiddles of one butterfly stage ---------------------------------------------------------------
+// Local stage r of a pass needs the CNT = 2^r consecutive table words tw[first .. first+CNT), first a
+// multiple of CNT: one vector load per four words instead of one dword load per butterfly.  When every
+// lane of the wave wants the same words (UNIFORM), the index is made wave-uniform so the loads become
+// scalar (s_load) and the twiddles live in SGPRs.
+template <typename W, int CNT, bool UNIFORM>
+__device__ __forceinline__ void load_tw(const W* __restrict__ tw, int first, W (&w)[CNT]) {
+    if constexpr (UNIFORM) {
+        const int f = __builtin_amdgcn_readfirstlane(first);
+#pragma unroll
+        for (int c = 0; c < CNT; ++c) w[c] = tw[f + c];
+    } else if constexpr (sizeof(W) == 4 && CNT >= 4) {
+        typedef u32 V __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int c = 0; c < CNT; c += 4) {
+            V v = *reinterpret_cast<const V*>(tw + first + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[c + e] = v[e];
+        }
+    } else if constexpr (CNT >= 2) {
+        typedef W V __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int c = 0; c < CNT; c += 2) {
+            V v = *reinterpret_cast<const V*>(tw + first + c);
+            w[c] = v[0];
+            w[c + 1] = v[1];
+        }
+    } else {
+        w[0] = tw[first];
+    }
+}
+
 // ---- one register-resident pass ------------------------------------------------------------------
-// Loads the thread's groups from LDS, runs NS stages, writes them back (unless KEEP, in which case the
-// results of the last pass stay in regs[][] for a fused epilogue and LDS is left stale).
 struct NoEpilogue {
     template <typename W> __device__ __forceinline__ void operator()(int, int, W*) const {}
 };
 
-// When KEEP, nothing is written back to LDS: epi(g, base, x) receives each finished group while its R
-// values x[0..R) are still in registers (x[k] = logical index base | k << LB, lazy in [0,2q)), so a fused
-// epilogue never needs more than one group live.
-template <int LOGN, typename W, int S0, int NS, bool INVERSE, bool KEEP, bool SERIAL, typename Epi>
+// Runs stages [S0, S0+NS) of a 2^LOGN-point transform on the thread's groups: loads them from LDS, NS
+// butterfly stages in registers, writes them back.  With KEEP nothing is written back: epi(g, base, x)
+// receives each finished group while its R values are still in registers (x[k] = logical index
+// base | k << LB, lazy in [0,2q)), so a fused epilogue never needs more than one group live.
+// `prefix`: the transform may be a sub-transform of a larger one whose leading stages ran elsewhere
+// (k_ks_accum_half: prefix = 2 + half); group h of stage s then uses twiddle (prefix << s) + h.  A whole
+// transform has prefix 1.
+template <int LOGN, int LOGT, typename W, int S0, int NS, bool INVERSE, bool KEEP, bool SERIAL, typename Epi>
 __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const W* __restrict__ tw, W q, W qni,
-                                         W ninv_m, W w1ninv_m, int t, Epi&& epi) {
-    typedef Geo<LOGN> G;
+                                         W ninv_m, W w1ninv_m, int t, int prefix, Epi&& epi) {
+    typedef Geo<LOGN, LOGT> G;
     constexpr int R = 1 << NS;
     constexpr int LB = LOGN - S0 - NS;
     constexpr int NG = G::E / R;                     // groups per thread
     static_assert(NG >= 1, "group larger than the per-thread coefficient budget");
     typedef typename Vec4<W>::type V;
     constexpr int VL = Vec4<W>::LANES;
+    // all 64 lanes of a wave share h when a run of equal h covers a whole wave
+    constexpr bool UNIFORM = (LB >= 6) && (G::T >= 64);
 
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -86,22 +122,39 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const W* __restric
             for (int k = 0; k < R; ++k) x[k] = lds[swz<LOGN>(base | (k << LB))];
         }
         // ---- butterflies
-        const int gm = (1 << S0) + h;
+        const int gm = (prefix << S0) + h;
         if constexpr (!INVERSE) {
 #pragma unroll
             for (int r = 0; r < NS; ++r) {
                 const int half = R >> (r + 1);
+                W w[1 << 3];
+                if (r == 0) { W t1[1]; load_tw<W, 1, UNIFORM>(tw, gm, t1); w[0] = t1[0]; }
+                else if (r == 1) { W t2[2]; load_tw<W, 2, UNIFORM>(tw, gm << 1, t2); w[0] = t2[0]; w[1] = t2[1]; }
+                else if (r == 2) { W t4[4]; load_tw<W, 4, UNIFORM>(tw, gm << 2, t4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) w[c] = t4[c]; }
+                else { W t8[8]; load_tw<W, 8, UNIFORM>(tw, gm << 3, t8);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) w[c] = t8[c]; }
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     if (k & half) continue;
-                    const W w = tw[(gm << r) + (k >> (NS - r))];
-                    bfly_fwd(x[k], x[k + half], w, q, qni);
+                    bfly_fwd(x[k], x[k + half], w[k >> (NS - r)], q, qni);
                 }
             }
         } else {
 #pragma unroll
             for (int r = NS - 1; r >= 0; --r) {
                 const int half = R >> (r + 1);
+                W w[1 << 3];
+                if (r == 0) { W t1[1]; load_tw<W, 1, UNIFORM>(tw, gm, t1); w[0] = t1[0]; }
+                else if (r == 1) { W t2[2]; load_tw<W, 2, UNIFORM>(tw, gm << 1, t2); w[0] = t2[0]; w[1] = t2[1]; }
+                else if (r == 2) { W t4[4]; load_tw<W, 4, UNIFORM>(tw, gm << 2, t4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) w[c] = t4[c]; }
+                else { W t8[8]; load_tw<W, 8, UNIFORM>(tw, gm << 3, t8);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) w[c] = t8[c]; }
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     if (k & half) continue;
@@ -111,8 +164,7 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const W* __restric
                         x[k] = mont_mul_lazy((W)(a + b), ninv_m, q, qni);
                         x[k + half] = mont_mul_lazy((W)(a - b + q), w1ninv_m, q, qni);
                     } else {
-                        const W w = tw[(gm << r) + (k >> (NS - r))];
-                        bfly_inv(x[k], x[k + half], w, q, qni);
+                        bfly_inv(x[k], x[k + half], w[k >> (NS - r)], q, qni);
                     }
                 }
             }
@@ -134,8 +186,8 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const W* __restric
 #pragma unroll
                 for (int k = 0; k < R; ++k) lds[swz<LOGN>(base | (k << LB))] = x[k];
             }
-            // One group at a time: callers (k_ks_accum) hold 2*E accumulators across the transform, and
-            // interleaving groups would push them over the 128-VGPR budget of a 1024-thread workgroup.
+            // One group at a time: callers (k_ks_accum*) hold 2*E accumulators across the transform, and
+            // interleaving groups would push them over the 128-VGPR budget.
             if constexpr (NG > 1 && SERIAL) __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -152,24 +204,24 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const W* __restric
 template <int LOGN, typename W, bool KEEP_LAST, bool SERIAL = false, typename Epi>
 __device__ __forceinline__ void ntt_forward(W* lds, const W* tw, W q, W qni, int tid, Epi&& epi) {
     typedef Geo<LOGN> G;
-    constexpr int P = G::NPASS, F = G::NS0;
+    constexpr int P = G::NPASS, F = G::NS0, LT = G::LOGT;
     NoEpilogue none;
     if constexpr (P == 1) {
-        ntt_pass<LOGN, W, 0, F, false, KEEP_LAST, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, epi);
+        ntt_pass<LOGN, LT, W, 0, F, false, KEEP_LAST, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, 1, epi);
     } else {
-        ntt_pass<LOGN, W, 0, F, false, false, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, none);
+        ntt_pass<LOGN, LT, W, 0, F, false, false, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, 1, none);
         __syncthreads();
         if constexpr (P == 2) {
-            ntt_pass<LOGN, W, F, 4, false, KEEP_LAST, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, epi);
+            ntt_pass<LOGN, LT, W, F, 4, false, KEEP_LAST, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, 1, epi);
         } else {
-            ntt_pass<LOGN, W, F, 4, false, false, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, none);
+            ntt_pass<LOGN, LT, W, F, 4, false, false, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, 1, none);
             __syncthreads();
             if constexpr (P == 3) {
-                ntt_pass<LOGN, W, F + 4, 4, false, KEEP_LAST, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, epi);
+                ntt_pass<LOGN, LT, W, F + 4, 4, false, KEEP_LAST, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, 1, epi);
             } else {
-                ntt_pass<LOGN, W, F + 4, 4, false, false, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, none);
+                ntt_pass<LOGN, LT, W, F + 4, 4, false, false, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, 1, none);
                 __syncthreads();
-                ntt_pass<LOGN, W, F + 8, 4, false, KEEP_LAST, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, epi);
+                ntt_pass<LOGN, LT, W, F + 8, 4, false, KEEP_LAST, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, 1, epi);
             }
         }
     }
@@ -183,12 +235,12 @@ template <int LOGN, typename W, bool KEEP_LAST, bool SERIAL = false, typename Ep
 __device__ __forceinline__ void ntt_inverse(W* lds, const W* twi, W q, W qni, W ninv_m, W w1ninv_m, int tid,
                                             Epi&& epi) {
     typedef Geo<LOGN> G;
-    constexpr int P = G::NPASS, F = G::NS0;
+    constexpr int P = G::NPASS, F = G::NS0, LT = G::LOGT;
     NoEpilogue none;
-    if constexpr (P >= 4) { ntt_pass<LOGN, W, F + 8, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, none); __syncthreads(); }
-    if constexpr (P >= 3) { ntt_pass<LOGN, W, F + 4, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, none); __syncthreads(); }
-    if constexpr (P >= 2) { ntt_pass<LOGN, W, F, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, none); __syncthreads(); }
-    ntt_pass<LOGN, W, 0, F, true, KEEP_LAST, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, epi);
+    if constexpr (P >= 4) { ntt_pass<LOGN, LT, W, F + 8, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, none); __syncthreads(); }
+    if constexpr (P >= 3) { ntt_pass<LOGN, LT, W, F + 4, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, none); __syncthreads(); }
+    if constexpr (P >= 2) { ntt_pass<LOGN, LT, W, F, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, none); __syncthreads(); }
+    ntt_pass<LOGN, LT, W, 0, F, true, KEEP_LAST, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, epi);
     if constexpr (!KEEP_LAST) __syncthreads();
 }
 

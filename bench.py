@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""bench.py -- ctxt-mul + relinearize throughput on MI355X (BASELINE.json's metric).
+
+One step = one pass of the hot path (alch_ct_mul_relin: SymmSHE (*) + keySwitchQuadCirc, CRT basis in and
+out) over one batch of synthetic ciphertext pairs that is already resident in HBM.
+Workload: n = 2^15, 4 RNS limbs (the four largest primes < 2^31 that are
+1 mod 2^16), TrivGad hint at the same modulus, B ciphertext pairs per GPU per step.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` = ciphertext pairs all ranks processed / max-over-ranks wall time.
+roofline.achieved = value/n_gpus x 6,291,456 algorithmic bytes per op (read two linear ciphertexts,
+write one, at the reference's 8-byte word) measured with HIP events on the library's stream.
+cpu_baseline = the C restatement of Lol's algorithm (oracle/, kind "port"), one thread, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG3_QS = [2147352577, 2146959361, 2146041857, 2145976321]
+LOGN = 15
+ALGO_BYTES_PER_OP = 6 * 4 * (1 << LOGN) * 8          # 6,291,456 B  
+HINT_BYTES = 2 * 4 * 4 * (1 << LOGN) * 8              # 8 MiB, counted once per batch
+HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(sample_ops: int):
+    from oracle import cref
+    ring = cref.Ring(1 << LOGN, CFG3_QS)
+    secs = ring.bench_mul_relin(sample_ops, 2026)
+    return {"value": sample_ops / secs, "unit": "ctxt-mul+relin/s", "cores": 1, "kind": "port",
+            "sample": f"{sample_ops} ops of keySwitchQuadCirc(a*b), n=2^15, L=4, CRT basis in/out, "
+                      f"single thread C restatement of Lol's CT algorithm ({secs:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8192, help="ciphertext pairs per GPU per step (weak scaling)")
+    ap.add_argument("--cpu-ops", type=int, default=384, help="ops in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--pow", action="store_true", help="also time the Pow-basis in/out variant (extra field)")
+    args = ap.parse_args()
+
+    import torch
+    from alchemy_amd import Ring, shard
+
+    rank, local_rank, world, dist = shard.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    ring = Ring(2 << LOGN, CFG3_QS)
+    B = args.batch
+    a, b, out = ring.alloc(2 * B), ring.alloc(2 * B), ring.alloc(2 * B)
+    hint_src = ring.alloc(2 * ring.L)
+    # seeds: 2026 + global ciphertext offset of this rank, hint 0xA1C4E5 (identical on every rank)
+    sh = shard.partition(B * world, world, rank)
+    a.fill_uniform(2026 + 2 * sh.first * 7919)
+    b.fill_uniform(900_000_007 + 2 * sh.first * 7919)
+    hint_src.fill_uniform(0xA1C4E5)
+    hint = ring.hint_from_buf(hint_src)
+    ring.sync()
+
+    def step():
+        ring.ct_mul_relin(hint, a, b, out, B)
+
+    for _ in range(args.warmup):
+        step()
+    ring.sync()
+    torch.cuda.synchronize()
+    shard.barrier(dist)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ring.timer_start()
+    for _ in range(args.steps):
+        step()
+    ev_ms = ring.timer_stop()
+    torch.cuda.synchronize()
+    shard.barrier(dist)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    wall_max = shard.max_over_ranks(wall, dist, dev)
+    ev_ms_max = shard.max_over_ranks(ev_ms, dist, dev)
+    checksum = out.checksum(0, 2)
+
+    pow_ops = None
+    if args.pow:
+        from alchemy_amd.capi import ALCH_POW_IN, ALCH_POW_OUT
+        Bp = min(B, 2048)
+        ring.ct_mul_relin(hint, a, b, out, Bp, flags=ALCH_POW_IN | ALCH_POW_OUT)
+        ring.sync()
+        ring.timer_start()
+        for _ in range(3):
+            ring.ct_mul_relin(hint, a, b, out, Bp, flags=ALCH_POW_IN | ALCH_POW_OUT)
+        pow_ops = 3 * Bp / (ring.timer_stop() * 1e-3)
+
+    if rank == 0:
+        total_ops = B * world * args.steps
+        value = total_ops / wall_max
+        # per-GPU achieved algorithmic bandwidth from the HIP-event time of the K launches on the stream
+        per_gpu_ops_s = B * args.steps / (ev_ms_max * 1e-3)
+        achieved = per_gpu_ops_s * (ALGO_BYTES_PER_OP + HINT_BYTES / B) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_op")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "ctxt-mul+relinearize/sec at n=2^15, 4 RNS limbs",
+            "value": value, "unit": "ctxt-mul+relin/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: keySwitchQuadCirc(hint, a*b) on linear ciphertexts, "
+                                   "n=2^15 (m'=2^16), L=4 primes<2^31, TrivGad hint at the same modulus, "
+                                   "CRT-basis in/out, inputs resident in HBM",
+                       "batch_per_gpu": B, "global_batch": B * world, "sharding": f"dp{world} by ciphertext, no collective",
+                       "moduli": CFG3_QS, "device_word_bytes": ring.word_bytes},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "note": "achieved = ops/s per GPU (HIP events over the timed launches) x 6,291,456 B "
+                                 "algorithmic bytes per op at the reference's 8-byte word (SURVEY 8d); "
+                                 "traffic = PMC HBM bytes per op (profiles/), device words are 4 bytes"},
+            "hip_event_ms_per_step": ev_ms_max / args.steps,
+            "out_checksum": f"{checksum:016x}",
+        }
+        if pow_ops is not None:
+            line["pow_basis_in_out_ops_per_s"] = pow_ops
+        if world == 1 and args.cpu_ops > 0:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_ops)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -7,6 +7,9 @@ from conftest import ARITH_QS, CFG2_Q60, CFG3_QS
 
 pytestmark = pytest.mark.gpu
 
+# all = 1 mod 2^16, wildly different sizes
+UNBAL_QS = [2147352577, 65537, 786433]
+
 
 def _rand_elems(rng, count, n, qs):
     return np.stack([np.stack([rng.integers(0, q, size=n, dtype=np.int64) for q in qs], axis=1) for _ in range(count)])
@@ -87,7 +90,10 @@ def _mul_relin_case(oracle_lib, n, qs, batch, seed, s_pre=None, pow_basis=False)
 
 @pytest.mark.parametrize("logn,qs,batch", [
     (4, ARITH_QS, 3), (6, ARITH_QS[:2], 9), (8, ARITH_QS, 5), (8, ARITH_QS[:1], 2),
-    (10, CFG3_QS, 3), (12, CFG3_QS[:2], 2), (13, CFG3_QS, 2), (14, CFG3_QS, 1), (15, CFG3_QS, 2),
+    (10, CFG3_QS, 3), (11, CFG3_QS, 9), (12, CFG3_QS[:2], 2), (13, CFG3_QS, 2), (14, CFG3_QS, 1), (15, CFG3_QS, 2),
+    (15, CFG3_QS, 11),
+    # unbalanced moduli (a digit of one limb exceeds another limb's modulus): general reduce path
+    (11, UNBAL_QS, 3), (15, UNBAL_QS, 2), (8, [1073750017, 8392193], 2),
 ])
 def test_ct_mul_relin_crt_basis(oracle_lib, logn, qs, batch):
     _mul_relin_case(oracle_lib, 1 << logn, qs, batch, seed=1000 + logn)
