@@ -37,7 +37,7 @@ struct alch_ring {
     void* ws_host = nullptr;                   // staging for the host-buffer Tensor methods
     size_t ws_host_bytes = 0;
     u64* ws_sum = nullptr;                     // checksum accumulator
-    size_t chunk = 256;                        // ciphertexts per (tensor_intt, ks_accum) launch pair
+    size_t chunk = 2048;                       // ciphertexts per (tensor_intt, ks_accum) launch pair
 };
 
 struct alch_buf {

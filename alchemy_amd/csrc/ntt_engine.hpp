@@ -35,10 +35,11 @@ struct Geo {
 
 // Logical coefficient index -> LDS word index.  Only bits >= 2 move, so aligned groups of four words
 // stay contiguous (128-bit accesses remain legal).
+// swz is linear over XOR: swz(a ^ b) = swz(a) ^ swz(b).  A pass therefore swizzles its group base once
+// and reaches element k with one XOR against the compile-time constant swz(k << LB).
 template <int LOGN>
-__device__ __forceinline__ int swz(int idx) {
-    if constexpr (LOGN >= 10) return idx ^ (((idx >> 6) & 3) << 2) ^ (((idx >> 8) & 3) << 4);
-    else return idx;
+__host__ __device__ constexpr int swz(int idx) {
+    return (LOGN >= 10) ? (idx ^ (((idx >> 6) & 3) << 2) ^ (((idx >> 8) & 3) << 4)) : idx;
 }
 
 template <typename W> struct Vec4;
@@ -108,18 +109,19 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const W* __restric
         const int lo = gamma & ((1 << LB) - 1);
         const int h = gamma >> LB;
         const int base = (h << (NS + LB)) | lo;
+        const int sb = swz<LOGN>(base);
         W x[R];
         // ---- load
         if constexpr (LB == 0 && R >= VL) {
 #pragma unroll
             for (int k = 0; k < R; k += VL) {
-                V v = *reinterpret_cast<const V*>(&lds[swz<LOGN>(base + k)]);
+                V v = *reinterpret_cast<const V*>(&lds[sb ^ swz<LOGN>(k)]);
 #pragma unroll
                 for (int e = 0; e < VL; ++e) x[k + e] = v[e];
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < R; ++k) x[k] = lds[swz<LOGN>(base | (k << LB))];
+            for (int k = 0; k < R; ++k) x[k] = lds[sb ^ swz<LOGN>(k << LB)];
         }
         // ---- butterflies
         const int gm = (prefix << S0) + h;
@@ -180,11 +182,11 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const W* __restric
                     V v;
 #pragma unroll
                     for (int e = 0; e < VL; ++e) v[e] = x[k + e];
-                    *reinterpret_cast<V*>(&lds[swz<LOGN>(base + k)]) = v;
+                    *reinterpret_cast<V*>(&lds[sb ^ swz<LOGN>(k)]) = v;
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < R; ++k) lds[swz<LOGN>(base | (k << LB))] = x[k];
+                for (int k = 0; k < R; ++k) lds[sb ^ swz<LOGN>(k << LB)] = x[k];
             }
             // One group at a time: callers (k_ks_accum*) hold 2*E accumulators across the transform, and
             // interleaving groups would push them over the 128-VGPR budget.

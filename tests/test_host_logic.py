@@ -1,0 +1,113 @@
+"""CPU: host-side logic of the product -- the C-ABI library loads and exports every symbol the header
+declares, validates its arguments, applies the documented root rule, and fails loudly without a GPU."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ARITH_QS, CFG2_Q60, CFG3_QS, ROOT
+
+import alchemy_amd as A
+from alchemy_amd import capi, shard
+from oracle import model as M
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "alchemy_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(alch_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = A.load_library()
+    declared = _header_functions()
+    assert len(declared) >= 35
+    missing = [f for f in declared if not hasattr(lib, f)]
+    assert not missing, missing
+    assert sorted(capi.SYMBOLS) == declared          # the binding covers the whole header
+    assert lib.alch_version() >> 16 == 1
+
+
+def test_library_links_no_oracle_code():
+    """The product must not route through the oracle: no orc_* symbol, no liblol_oracle dependency."""
+    out = subprocess.run(["nm", "-D", A.lib_path()], capture_output=True, text=True, check=True).stdout
+    assert "orc_" not in out
+    ldd = subprocess.run(["ldd", A.lib_path()], capture_output=True, text=True).stdout
+    assert "oracle" not in ldd
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "alchemy_amd")):
+        for f in files:
+            if not f.endswith((".py", ".hpp", ".hip", ".h", ".cpp")):
+                continue
+            for line in open(os.path.join(dirpath, f)):
+                st = line.strip()
+                if st.startswith(("import ", "from ")):
+                    assert "oracle" not in st, (f, st)
+                if st.startswith("#include"):
+                    assert "oracle" not in st and "lol_tensor" not in st, (f, st)
+
+
+@pytest.mark.parametrize("m,q", [(32, ARITH_QS[0]), (512, ARITH_QS[1]), (512, ARITH_QS[2]), (1 << 16, CFG3_QS[0]),
+                                 (1 << 16, CFG3_QS[3]), (1 << 15, CFG2_Q60), (4096, 12289), (1 << 16, 65537)])
+def test_root_rule_matches_oracle(oracle_lib, m, q):
+    psi, g = capi.host_root(m, q)
+    assert g == M.smallest_generator(q) == oracle_lib.smallest_generator(q)
+    assert psi == M.root_2n(q, m // 2)
+    assert pow(psi, m // 2, q) == q - 1               # primitive m-th root
+
+
+def test_host_root_rejects_bad_arguments():
+    with pytest.raises(A.AlchemyError) as e:
+        capi.host_root(1 << 16, ARITH_QS[1])          # 8392193 is not 1 mod 2^16
+    assert e.value.code == capi.ALCH_E_NO_CRT
+    with pytest.raises(A.AlchemyError) as e:
+        capi.host_root(512, 268440579)                # not prime
+    assert e.value.code == capi.ALCH_E_INVALID
+
+
+def _no_gpu():
+    import torch
+    return not torch.cuda.is_available()
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="checks the no-device error path")
+def test_ring_create_fails_loudly_without_gpu():
+    with pytest.raises(A.AlchemyError) as e:
+        A.Ring(512, ARITH_QS)
+    assert e.value.code == capi.ALCH_E_NO_DEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_ring_argument_validation_precedes_device_probe():
+    for args, code in [((512, [268440579]), capi.ALCH_E_NOT_PRIME),          # composite
+                       ((1 << 16, [ARITH_QS[1]]), capi.ALCH_E_NO_CRT),        # q != 1 mod m
+                       ((48, [ARITH_QS[0]]), capi.ALCH_E_UNSUPPORTED),        # index not a power of two
+                       ((16, [ARITH_QS[0]]), capi.ALCH_E_UNSUPPORTED),        # n < 16
+                       ((1 << 17, [CFG3_QS[3]]), capi.ALCH_E_NO_CRT),         # 2145976321 is 1 mod 2^16 only
+                       ((1 << 17, [CFG3_QS[0]]), capi.ALCH_E_UNSUPPORTED),    # n = 2^16 exceeds one LDS-resident transform
+                       ((512, [ARITH_QS[0], ARITH_QS[0]]), capi.ALCH_E_INVALID),
+                       ((512, []), capi.ALCH_E_INVALID)]:
+        with pytest.raises(A.AlchemyError) as e:
+            A.Ring(*args)
+        assert e.value.code == code, (args, str(e.value))
+
+
+def test_partition_covers_batch_exactly():
+    for total, world in [(8192, 1), (8192, 8), (10, 4), (3, 8), (0, 2), (65536, 3)]:
+        shards = [shard.partition(total, world, r) for r in range(world)]
+        assert sum(s.count for s in shards) == total
+        pos = 0
+        for s in shards:
+            assert s.first == pos
+            pos += s.count
+        assert max(s.count for s in shards) - min(s.count for s in shards) <= 1
+    with pytest.raises(ValueError):
+        shard.partition(4, 2, 2)
+
+
+def test_graft_entry_build_is_idempotent():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.build()
+    assert os.path.exists(A.lib_path())
