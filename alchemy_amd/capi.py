@@ -34,7 +34,8 @@ class AlchemyError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "lib", "libalchemy_hip.so")
+    # ALCH_LIB_PATH selects an experimental build of the same library (tools/build_variants.sh)
+    return os.environ.get("ALCH_LIB_PATH") or os.path.join(_HERE, "lib", "libalchemy_hip.so")
 
 
 _lib = None

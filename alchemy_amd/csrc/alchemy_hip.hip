@@ -28,16 +28,19 @@ struct alch_ring {
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void* tables = nullptr;                    // all twiddle tables, one allocation
+    void* tables_p = nullptr;                  // Plantard forward constants (32-bit rings)
     DevRing<u32> d32;
     DevRing<u64> d64;
-    void* ws_digits = nullptr;                 // digit scratch [chunk][L][n] signed words
+    void* ws_digits = nullptr;                 // digit scratch, two halves of [chunk][L][n] signed words
     size_t ws_digits_bytes = 0;
+    hipStream_t aux = nullptr;                 // second pipeline of ct_mul_relin (odd chunks)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void* ws_in = nullptr;                     // crt scratch for ALCH_POW_IN (2 * 2*batch elements)
     size_t ws_in_bytes = 0;
     void* ws_host = nullptr;                   // staging for the host-buffer Tensor methods
     size_t ws_host_bytes = 0;
     u64* ws_sum = nullptr;                     // checksum accumulator
-    size_t chunk = 2048;                       // ciphertexts per (tensor_intt, ks_accum) launch pair
+    size_t chunk = 1024;                       // ciphertexts per (tensor_intt, ks_accum) launch pair
 };
 
 struct alch_buf {
@@ -225,6 +228,21 @@ static int build_dev_ring(alch_ring* r, DevRing<W>& d) {
         d.dig_off[j] = (W)(((maxhalf + q - 1) / q) * q);
     }
     HIP_TRY(hipMemcpy(r->tables, all.data(), all.size() * sizeof(W), hipMemcpyHostToDevice));
+    if (sizeof(W) == 4) {
+        // forward twiddles once more as Plantard constants: tw[k] = psi^brev(k)
+        std::vector<u64> pl((size_t)L * n);
+        for (int j = 0; j < L; ++j) {
+            const u64 q = r->q[j];
+            const u64 psi = h_root(q, r->m);
+            std::vector<u64> pw(n);
+            u64 acc = 1;
+            for (size_t i = 0; i < n; ++i) { pw[i] = acc; acc = h_mulmod(acc, psi, q); }
+            for (size_t k = 0; k < n; ++k) pl[(size_t)j * n + k] = h_plant_const(pw[h_brev((u32)k, r->logn)], q);
+        }
+        HIP_TRY(hipMalloc(&r->tables_p, pl.size() * sizeof(u64)));
+        HIP_TRY(hipMemcpy(r->tables_p, pl.data(), pl.size() * sizeof(u64), hipMemcpyHostToDevice));
+        for (int j = 0; j < L; ++j) d.twp[j] = reinterpret_cast<const u64*>(r->tables_p) + (size_t)j * n;
+    }
     return ALCH_OK;
 }
 
@@ -292,6 +310,9 @@ extern "C" int alch_ring_create(uint32_t m, int L, const uint64_t* q, alch_ring*
     if (e != hipSuccess) { delete r; return fail(ALCH_E_HIP, "hipStreamCreate failed"); }
     r->own_stream = true;
     if (hipEventCreate(&r->ev0) != hipSuccess || hipEventCreate(&r->ev1) != hipSuccess) { delete r; return fail(ALCH_E_HIP, "hipEventCreate failed"); }
+    if (hipStreamCreateWithFlags(&r->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming) != hipSuccess) { delete r; return fail(ALCH_E_HIP, "aux stream/event creation failed"); }
     if (hipMalloc((void**)&r->ws_sum, sizeof(u64)) != hipSuccess) { delete r; return fail(ALCH_E_NOMEM, "hipMalloc failed"); }
     rc = (word == 4) ? build_dev_ring<u32>(r, r->d32) : build_dev_ring<u64>(r, r->d64);
     if (rc != ALCH_OK) { alch_ring_destroy(r); return rc; }
@@ -303,12 +324,16 @@ extern "C" int alch_ring_destroy(alch_ring* r) {
     if (!r) return ALCH_OK;
     if (r->stream) (void)hipStreamSynchronize(r->stream);
     if (r->tables) (void)hipFree(r->tables);
+    if (r->tables_p) (void)hipFree(r->tables_p);
     if (r->ws_digits) (void)hipFree(r->ws_digits);
     if (r->ws_in) (void)hipFree(r->ws_in);
     if (r->ws_host) (void)hipFree(r->ws_host);
     if (r->ws_sum) (void)hipFree(r->ws_sum);
     if (r->ev0) (void)hipEventDestroy(r->ev0);
     if (r->ev1) (void)hipEventDestroy(r->ev1);
+    if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
+    if (r->ev_join) (void)hipEventDestroy(r->ev_join);
+    if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamDestroy(r->aux); }
     if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
     return ALCH_OK;
@@ -700,19 +725,32 @@ template <typename W>
 static int do_mul_relin(alch_ring* r, const alch_hint* hint, const void* a, const void* b, void* out, size_t batch,
                         const uint64_t* s_pre) {
     typedef typename Signed<W>::type SW;
+    // The batch runs as chunks of (tensor_intt, ks_accum) launch pairs.  A chunk's digits (chunk * L * n
+    // signed words) are written by the first kernel and read 2(L-1) times by the second, so the chunk is kept
+    // small enough for them to stay in the 256 MiB Infinity Cache; to keep the GPU full across the kernel
+    // boundaries of such small launches, even and odd chunks run as two independent pipelines on two streams
+    // (each with its own digit scratch), so one pipeline's tail overlaps the other's head.
     const size_t chunk = std::min(r->chunk, (batch + 7) / 8 * 8);
-    int rc = ensure_ws(&r->ws_digits, &r->ws_digits_bytes, chunk * elem_words(r) * sizeof(SW));
+    const size_t dig_bytes = chunk * elem_words(r) * sizeof(SW);
+    int rc = ensure_ws(&r->ws_digits, &r->ws_digits_bytes, 2 * dig_bytes);
     if (rc != ALCH_OK) return rc;
     NttCall<W> c{};
     c.ring = &dev_ring<W>(r);
-    c.stream = r->stream;
     c.hint = reinterpret_cast<const W*>(hint->dptr);
-    c.digits = r->ws_digits;
     c.balanced = r->balanced;
     scal_to_mont<W>(r, s_pre, 2, c.spre_r2);
     const size_t ct_words = 2 * elem_words(r);
-    for (size_t done = 0; done < batch; done += chunk) {
+    const bool two = batch > chunk;
+    if (two) {
+        HIP_TRY(hipEventRecord(r->ev_fork, r->stream));
+        HIP_TRY(hipStreamWaitEvent(r->aux, r->ev_fork, 0));
+    }
+    size_t idx = 0;
+    for (size_t done = 0; done < batch; done += chunk, ++idx) {
         const size_t now = std::min(chunk, batch - done);
+        const bool odd = two && (idx & 1);
+        c.stream = odd ? r->aux : r->stream;
+        c.digits = reinterpret_cast<char*>(r->ws_digits) + (odd ? dig_bytes : 0);
         c.a = reinterpret_cast<const W*>(a) + done * ct_words;
         c.b = reinterpret_cast<const W*>(b) + done * ct_words;
         c.out = reinterpret_cast<W*>(out) + done * ct_words;
@@ -723,6 +761,10 @@ static int do_mul_relin(alch_ring* r, const alch_hint* hint, const void* a, cons
         c.op = OP_KS_ACCUM;
         e = dispatch(r->logn, c);
         if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("ks_accum launch: ") + hipGetErrorString(e));
+    }
+    if (two) {
+        HIP_TRY(hipEventRecord(r->ev_join, r->aux));
+        HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_join, 0));
     }
     return ALCH_OK;
 }

@@ -11,9 +11,72 @@
 // (tensor inputs, digits, hint, result stores) and barrier stalls hide under each other's butterflies;
 // the one-workgroup-per-CU form (k_ks_accum) idles the VALU during those phases.
 #pragma once
+#include <hip/hip_runtime.h>
 #include "ntt_engine.hpp"
 
+// experiment switches (tools/build_variants.sh)
+#ifndef ALCH_KS_SERIAL
+#define ALCH_KS_SERIAL true
+#endif
+#ifndef ALCH_KS_GBARRIER
+#define ALCH_KS_GBARRIER 1
+#endif
+
 namespace alch {
+
+// Diagnostic build only (-DALCH_STAMPS): wave 0 of every workgroup adds the shader-clock time it spent in
+// each phase to g_ks_stamps[phase]; read back by tools/stamp_report.py.  No stamp executes in the product.
+#ifdef ALCH_STAMPS
+__device__ unsigned long long g_ks_stamps[1024 * 16];
+#define KS_STAMP(ph)                                                                              \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long _t;                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        _t_acc[ph] += _t - _t_prev;                                                               \
+        _t_prev = _t;                                                                             \
+    } while (0)
+#define KS_STAMP_FLUSH()                                                                          \
+    do {                                                                                          \
+        if (threadIdx.x == KS_STAMP_LANE)                                                         \
+            for (int _p = 0; _p < 11; ++_p) atomicAdd(&g_ks_stamps[(blockIdx.x & 1023) * 16 + _p], _t_acc[_p]); \
+        unsigned long long _rt_last;                                                              \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_rt_last)::"memory");       \
+        if (threadIdx.x == KS_STAMP_LANE) {                                                       \
+            atomicAdd(&g_ks_stamps[(blockIdx.x & 1023) * 16 + 11], _t_prev - _t_first);           \
+            atomicAdd(&g_ks_stamps[(blockIdx.x & 1023) * 16 + 12], _rt_last - _rt_first);         \
+        }                                                                                         \
+    } while (0)
+}  // namespace alch
+extern "C" __attribute__((visibility("default"), used)) int alch_debug_stamps(unsigned long long* out16) {
+    static unsigned long long host[1024 * 16];
+    if (hipDeviceSynchronize() != hipSuccess) return -6;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(alch::g_ks_stamps), sizeof host) != hipSuccess) return -6;
+    for (int p = 0; p < 16; ++p) { out16[p] = 0; for (int w = 0; w < 1024; ++w) out16[p] += host[w * 16 + p]; }
+    for (auto& v : host) v = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(alch::g_ks_stamps), host, sizeof host) != hipSuccess) return -6;
+    return 0;
+}
+namespace alch {
+#ifndef KS_STAMP_LANE
+#define KS_STAMP_LANE 0
+#endif
+#define KS_STAMP_INIT()                                                                           \
+    unsigned long long _t_acc[11] = {0};                                                          \
+    unsigned long long _t_prev, _t_first, _rt_first;                                              \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_rt_first)::"memory");        \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t_prev)::"memory");              \
+    _t_first = _t_prev
+#else
+#define KS_STAMP(ph) do {} while (0)
+#define KS_STAMP_INIT() do {} while (0)
+#define KS_STAMP_FLUSH() do {} while (0)
+#endif
+
+// y * twiddle, fully reduced, for either twiddle representation
+__device__ __forceinline__ u32 tw_mul(u32 y, u64 br, u32 q, u32) { return plant_mul(y, br, q); }
+__device__ __forceinline__ u32 tw_mul(u32 y, u32 w, u32 q, u32 qni) { return csub(mont_mul_lazy(y, w, q, qni), q); }
 
 __device__ __forceinline__ u32 mont_red_lazy(u64 p, u32 q, u32 qni) {       // p < 2^32 * q  ->  [0, 2q)
     u32 m = (u32)p * qni;
@@ -24,7 +87,7 @@ template <int LOGN, bool BALANCED>
 __global__ void __launch_bounds__(1 << (LOGN - 6), 4)
 k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict__ b,
                 const int32_t* __restrict__ digits, const u32* __restrict__ hint, u32* __restrict__ out,
-                unsigned nct, Scal<u32> spre) {
+                unsigned nct, unsigned nitems, Scal<u32> spre, unsigned dbg_mask) {
     typedef u32 W;
     constexpr int LOGM = LOGN - 1, M = 1 << LOGM, N = 1 << LOGN, LT = LOGN - 6, T = 1 << LT;
     typedef Geo<LOGM, LT> G;
@@ -36,69 +99,110 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W* lds = reinterpret_cast<W*>(smem);
     const int L = R.L;
-    // XCD-aware placement (speed only): the 2L workgroups of one ciphertext get ids that agree mod 8, so
-    // they share an XCD and its L2 serves the digits they all read.
+    W* sink = lds + M;                                     // 4*T words: landing zone of the input prefetch
+    // Persistent workgroups: the grid is two workgroups per CU and each loops over work items
+    // (ciphertext, limb j, half), so there is no partial last wave of workgroups and a workgroup knows its next
+    // item early enough to prefetch that item's tensor inputs towards the caches.
+    // Item numbering is XCD-aware (speed only): the 2L items of one ciphertext agree mod 8, and gridDim is a
+    // multiple of 8, so they run on one XCD and its L2 serves the digits they all read.
     const unsigned per = 16u * (unsigned)L;
-    const unsigned grp = blockIdx.x / per, rem = blockIdx.x % per;
-    const unsigned which = rem >> 3;
-    const int j = (int)(which >> 1);
-    const int hf = (int)(which & 1u);
-    const size_t ct = (size_t)grp * 8u + (rem & 7u);
-    if (ct >= nct) return;
+    auto decode = [&](unsigned item, int& j_, int& hf_, size_t& ct_) {
+        const unsigned grp = item / per, rem = item % per;
+        const unsigned which = rem >> 3;
+        j_ = (int)(which >> 1);
+        hf_ = (int)(which & 1u);
+        ct_ = (size_t)grp * 8u + (rem & 7u);
+    };
+    for (unsigned item = blockIdx.x; item < nitems; item += gridDim.x) {
+    int j, hf;
+    size_t ct;
+    decode(item, j, hf, ct);
+    if (ct >= nct) continue;
 
     const ModP<W> m = R.mod[j];
     const W q = m.q, qni = m.qni;
     const W sr2 = spre.v[j];
     const size_t n = (size_t)N;
     const size_t slot0 = (size_t)hf * M;
-    const W* a0 = a + ((2 * ct) * (size_t)L + j) * n + slot0;
-    const W* a1 = a + ((2 * ct + 1) * (size_t)L + j) * n + slot0;
-    const W* b0 = b + ((2 * ct) * (size_t)L + j) * n + slot0;
-    const W* b1 = b + ((2 * ct + 1) * (size_t)L + j) * n + slot0;
+    const size_t cti = (dbg_mask == 0xFFFFFFF7u) ? (ct & 7) : ct;      // traffic experiment: alias the inputs
+    const W* a0 = a + ((2 * cti) * (size_t)L + j) * n + slot0;
+    const W* a1 = a + ((2 * cti + 1) * (size_t)L + j) * n + slot0;
+    const W* b0 = b + ((2 * cti) * (size_t)L + j) * n + slot0;
+    const W* b1 = b + ((2 * cti + 1) * (size_t)L + j) * n + slot0;
     const W* hj = hint + (size_t)j * n + slot0;                // + ((i*2 + c)*L)*n
     const size_t hstride = (size_t)L * n;
 
+    // One dword per 128-byte line of the next item's a0, a1, b0, b1 half-rows (thread t owns line t of each),
+    // fetched by LDS-DMA into `sink`: no VGPRs, nothing waits for it, and by the time the next item starts its
+    // tensor part the lines sit in L2 / Infinity Cache instead of HBM.  (Without it that part stalls on HBM:
+    // aliasing the inputs to cache-resident data was worth +11 % in a traffic experiment.)
+    auto prefetch_next = [&](unsigned nitem) {
+        if (nitem >= nitems) return;
+        int j2, hf2;
+        size_t ct2;
+        decode(nitem, j2, hf2, ct2);
+        if (ct2 >= nct) return;
+        const size_t off = (size_t)hf2 * M + (size_t)threadIdx.x * 32;
+        const W* rows[4] = {a + ((2 * ct2) * (size_t)L + j2) * n + off, a + ((2 * ct2 + 1) * (size_t)L + j2) * n + off,
+                            b + ((2 * ct2) * (size_t)L + j2) * n + off, b + ((2 * ct2 + 1) * (size_t)L + j2) * n + off};
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)rows[x],
+                                             (__attribute__((address_space(3))) void*)(sink + x * T + ((int)threadIdx.x & ~63)),
+                                             4, 0, 0);
+    };
+
+    KS_STAMP_INIT();
     W acc0[32], acc1[32];
-    {   // c0, c1 and the diagonal digit (i == j): d_j = c2_j (mod q_j), no transform needed
+    {   // c0, c1 and the diagonal digit (i == j): d_j = c2_j (mod q_j), no transform needed.
+        // Eight 4-coefficient slices, software-pipelined: the six 16-byte loads of slice s+1 are in flight
+        // while slice s is multiplied out (issuing them one slice at a time exposed the HBM latency eight
+        // times per workgroup: 20 % of the kernel in the phase stamps).
         const W* h0 = hj + (size_t)(2 * j) * hstride;
         const W* h1 = hj + (size_t)(2 * j + 1) * hstride;
+        V in[2][6];
+        auto issue = [&](int s, V (&v)[6]) {
+            const int idx = ((int)threadIdx.x + T * (s >> 2)) * 16 + (s & 3) * 4;
+            v[0] = *reinterpret_cast<const V*>(a0 + idx); v[1] = *reinterpret_cast<const V*>(a1 + idx);
+            v[2] = *reinterpret_cast<const V*>(b0 + idx); v[3] = *reinterpret_cast<const V*>(b1 + idx);
+            v[4] = *reinterpret_cast<const V*>(h0 + idx); v[5] = *reinterpret_cast<const V*>(h1 + idx);
+        };
+        issue(0, in[0]);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
+        for (int s = 0; s < 8; ++s) {
+            if (s + 1 < 8) issue(s + 1, in[(s + 1) & 1]);
+            const V(&v)[6] = in[s & 1];
 #pragma unroll
-            for (int k = 0; k < 16; k += 4) {
-                const int idx = ((int)threadIdx.x + T * g) * 16 + k;
-                V va0 = *reinterpret_cast<const V*>(a0 + idx), va1 = *reinterpret_cast<const V*>(a1 + idx);
-                V vb0 = *reinterpret_cast<const V*>(b0 + idx), vb1 = *reinterpret_cast<const V*>(b1 + idx);
-                V vh0 = *reinterpret_cast<const V*>(h0 + idx), vh1 = *reinterpret_cast<const V*>(h1 + idx);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const W x0 = csub(mont_mul_lazy(va0[e], sr2, q, qni), q);          // a0 s R
-                    const W x1 = csub(mont_mul_lazy(va1[e], sr2, q, qni), q);          // a1 s R
-                    const W c2 = csub(mont_mul_lazy(vb1[e], x1, q, qni), q);           // a1 b1 s
-                    // sums of two products (< 2 q^2 < 2^32 q) share one Montgomery reduction
-                    acc0[g * 16 + k + e] = csub(mont_red_lazy((u64)x0 * vb0[e] + (u64)c2 * vh0[e], q, qni), q);
-                    const W t1 = csub(mont_red_lazy((u64)x0 * vb1[e] + (u64)x1 * vb0[e], q, qni), q);
-                    const W t2 = csub(mont_mul_lazy(c2, vh1[e], q, qni), q);
-                    acc1[g * 16 + k + e] = csub(t1 + t2, q);
-                }
-                __builtin_amdgcn_sched_barrier(0);   // keep one 4-coefficient slice of loads live at a time
+            for (int e = 0; e < 4; ++e) {
+                const W x0 = csub(mont_mul_lazy(v[0][e], sr2, q, qni), q);          // a0 s R
+                const W x1 = csub(mont_mul_lazy(v[1][e], sr2, q, qni), q);          // a1 s R
+                const W c2 = csub(mont_mul_lazy(v[3][e], x1, q, qni), q);           // a1 b1 s
+                // sums of two products (< 2 q^2 < 2^32 q) share one Montgomery reduction
+                acc0[s * 4 + e] = csub(mont_red_lazy((u64)x0 * v[2][e] + (u64)c2 * v[4][e], q, qni), q);
+                const W t1 = csub(mont_red_lazy((u64)x0 * v[3][e] + (u64)x1 * v[2][e], q, qni), q);
+                const W t2 = csub(mont_mul_lazy(c2, v[5][e], q, qni), q);
+                acc1[s * 4 + e] = csub(t1 + t2, q);
             }
+            __builtin_amdgcn_sched_barrier(0);   // at most two slices of loads live
         }
     }
-
+    KS_STAMP(0);                                  // tensor part (c0, c1, diagonal digit)
+    const int i_last = (j == L - 1) ? L - 2 : L - 1;
     for (int i = 0; i < L; ++i) {
         if (i == j) continue;
-        const int32_t* d = digits + (ct * (size_t)L + i) * n;
+        const int32_t* d = digits + ((ct & dbg_mask) * (size_t)L + i) * n;    // dbg_mask = ~0u except in traffic experiments
         // Nothing below depends on i except d and the hint rows; keep addresses and twiddles from being
         // hoisted out of the digit loop (that costs ~250 spilled VGPRs).
-        const W* twf = R.twf[j];
+        auto twf = fwd_tw(R, j);                        // Plantard constants (shared-twiddle passes)
+        const W* twm = R.twf[j];                        // Montgomery words (per-lane last pass)
         int tid = threadIdx.x;
-        asm volatile("" : "+s"(twf), "+v"(tid));
+        asm volatile("" : "+s"(twf), "+s"(twm), "+v"(tid));
         __syncthreads();      // previous transform's last pass has finished reading LDS
+        KS_STAMP(1);                              // barrier before pass G
 
         // ---- global stages 0..2, HBM/L2 -> registers -> LDS
         {
-            const W w1 = twf[1], w2 = twf[2 + hf], w3a = twf[4 + 2 * hf], w3b = twf[5 + 2 * hf];
+            const auto w1 = twf[1], w2 = twf[2 + hf], w3a = twf[4 + 2 * hf], w3b = twf[5 + 2 * hf];
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const int lo4 = (tid + T * g) * 4;                    // coefficients lo4..lo4+3 of each eighth
@@ -116,7 +220,7 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
                             yr = mont_mul_lazy((W)((W)zy[e] + R.dig_off[j]), m.r1, q, qni);
                         }
                         const W xx = csub(xr, q);
-                        const W t = csub(mont_mul_lazy(yr, w1, q, qni), q);
+                        const W t = tw_mul(yr, w1, q, qni);
                         u[k][e] = hf ? xx + (q - t) : xx + t;
                     }
                 }
@@ -132,10 +236,15 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     *reinterpret_cast<V*>(&lds[swz<LOGM>(k * (N / 8) + lo4)]) = u[k];
+#if ALCH_KS_GBARRIER
                 __builtin_amdgcn_sched_barrier(0);
+#endif
             }
         }
+        KS_STAMP(2);                              // pass G (global loads + stages 0..2 + LDS write)
         __syncthreads();
+        KS_STAMP(3);                              // barrier after pass G
+        if (i == i_last) prefetch_next(item + gridDim.x);
 
         // ---- remaining stages: sub-transform of size n/2, local stages 2 .. LOGM-1
         const W* h0 = hj + (size_t)(2 * i) * hstride;
@@ -155,21 +264,27 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         NoEpilogue none;
         constexpr int NP = (LOGM - 2) / 4;
         if constexpr (NP == 1) {
-            ntt_pass<LOGM, LT, W, 2, 4, false, true, true>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, epi);
+            ntt_pass<LOGM, LT, W, 2, 4, false, true, true>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, epi);
         } else if constexpr (NP == 2) {
-            ntt_pass<LOGM, LT, W, 2, 4, false, false, true>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
+            ntt_pass<LOGM, LT, W, 2, 4, false, false, ALCH_KS_SERIAL>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
             __syncthreads();
-            ntt_pass<LOGM, LT, W, 6, 4, false, true, true>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, epi);
+            ntt_pass<LOGM, LT, W, 6, 4, false, true, true>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, epi);
         } else {
             static_assert(NP <= 3, "at most 3 LDS passes");
-            ntt_pass<LOGM, LT, W, 2, 4, false, false, true>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
+            ntt_pass<LOGM, LT, W, 2, 4, false, false, ALCH_KS_SERIAL>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
+            KS_STAMP(4);                          // LDS pass 1
             __syncthreads();
-            ntt_pass<LOGM, LT, W, 6, 4, false, false, true>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
+            KS_STAMP(5);
+            ntt_pass<LOGM, LT, W, 6, 4, false, false, ALCH_KS_SERIAL>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
+            KS_STAMP(6);                          // LDS pass 2
             __syncthreads();
-            ntt_pass<LOGM, LT, W, 10, 4, false, true, true>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, epi);
+            KS_STAMP(7);
+            ntt_pass<LOGM, LT, W, 10, 4, false, true, true>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, epi);
+            KS_STAMP(8);                          // last pass + hint multiply-accumulate
         }
     }
 
+    KS_STAMP(9);
     W* o0 = out + ((2 * ct) * (size_t)L + j) * n + slot0;
     W* o1 = out + ((2 * ct + 1) * (size_t)L + j) * n + slot0;
 #pragma unroll
@@ -184,6 +299,9 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
             *reinterpret_cast<V*>(o1 + idx) = v1;
         }
     }
+    KS_STAMP(10);                                 // result stores issued
+    KS_STAMP_FLUSH();
+    }  // item loop: the next item touches LDS only after the barrier that opens its first pass G
 }
 
 }  // namespace alch

@@ -10,6 +10,7 @@
 //                  mod q_j), so only L-1 transforms run per limb.  Accumulators stay in registers.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <type_traits>
 #include "ntt_engine.hpp"
 
@@ -27,7 +28,22 @@ struct DevRing {
     W dig_off[MAXL];     // multiple of q_j >= max_i (q_i-1)/2: makes a signed digit non-negative
     const W* twf[MAXL];  // forward twiddles (device, Montgomery form), n words
     const W* twi[MAXL];  // inverse twiddles
+    const u64* twp[MAXL]; // forward twiddles as Plantard constants (32-bit rings only), n x 8 bytes
 };
+
+// Forward-transform twiddle table of limb j.  ALCH_USE_PLANTARD=1 switches 32-bit rings to Plantard constants
+// (9-instruction butterfly instead of 10, two-word twiddles).  Measured on MI355X (interleaved A/B runs of
+// bench.py): 9 % fewer VALU instructions in k_ks_accum_half but 2 % LOWER throughput -- the early passes get
+// faster and the hint/digit-load phases slower by the same amount -- so the default stays Montgomery.
+#ifndef ALCH_USE_PLANTARD
+#define ALCH_USE_PLANTARD 0
+#endif
+#if ALCH_USE_PLANTARD
+__device__ __forceinline__ const u64* fwd_tw(const DevRing<u32>& R, int j) { return R.twp[j]; }
+#else
+__device__ __forceinline__ const u32* fwd_tw(const DevRing<u32>& R, int j) { return R.twf[j]; }
+#endif
+__device__ __forceinline__ const u64* fwd_tw(const DevRing<u64>& R, int j) { return R.twf[j]; }
 
 template <typename W> struct Scal { W v[MAXL]; };   // per-limb scalars passed by value
 
@@ -89,7 +105,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::T) k_crt(DevRing<W> R, W* __restric
 
     stage_in<LOGN, W>(lds, [&](int idx) { return *reinterpret_cast<const V*>(poly + idx); });
     __syncthreads();
-    if constexpr (!INVERSE) ntt_forward<LOGN, W, false>(lds, R.twf[j], q, qni, (int)threadIdx.x, NoEpilogue());
+    if constexpr (!INVERSE) ntt_forward<LOGN, W, false>(lds, fwd_tw(R, j), R.twf[j], q, qni, (int)threadIdx.x, NoEpilogue());
     else ntt_inverse<LOGN, W, false>(lds, R.twi[j], q, qni, R.ninv_m[j], R.w1ninv_m[j], (int)threadIdx.x, NoEpilogue());
 #pragma unroll
     for (int r = 0; r < G::E / VL; ++r) {
@@ -231,10 +247,11 @@ k_ks_accum(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
         // Neither the twiddles nor the LDS addresses depend on i; unless both are made opaque here the
         // compiler hoists every pass's address arithmetic and twiddle loads out of the digit loop and
         // spills ~250 VGPRs per lane.
-        const W* twf = R.twf[j];
+        auto twf = fwd_tw(R, j);
+        const W* twm = R.twf[j];
         int tid = threadIdx.x;
-        asm volatile("" : "+s"(twf), "+v"(tid));
-        ntt_forward<LOGN, W, true, true>(lds, twf, q, qni, tid, [&acc0, &acc1, h0, h1, q, qni](int g, int base, W* x) {
+        asm volatile("" : "+s"(twf), "+s"(twm), "+v"(tid));
+        ntt_forward<LOGN, W, true, true>(lds, twf, twm, q, qni, tid, [&acc0, &acc1, h0, h1, q, qni](int g, int base, W* x) {
 #pragma unroll
             for (int k = 0; k < 16; k += VL) {
                 V vh0 = *reinterpret_cast<const V*>(h0 + base + k), vh1 = *reinterpret_cast<const V*>(h1 + base + k);
@@ -301,20 +318,23 @@ inline hipError_t run_call(const NttCall<W>& c) {
     case OP_KS_ACCUM: {
         if constexpr (std::is_same<W, u32>::value && (LOGN == 15 || LOGN == 11)) {
             // two workgroups per (ciphertext, limb): see kernel_ks_half.hpp
+            static const unsigned dbg_mask = getenv("ALCH_EXP_DIGMASK") ? (unsigned)strtoul(getenv("ALCH_EXP_DIGMASK"), nullptr, 0) : 0xFFFFFFFFu;
             const size_t groups = (c.nct + 7) / 8;
-            const unsigned grid = (unsigned)(groups * 16 * (size_t)R.L);
-            const size_t half_lds = lds_bytes / 2;
+            const unsigned nitems = (unsigned)(groups * 16 * (size_t)R.L);
+            static const unsigned persist = getenv("ALCH_KS_GRID") ? (unsigned)atoi(getenv("ALCH_KS_GRID")) : 1024u;  // 4 per CU: 2 resident + 2 queued (measured best of 256/512/1024)
+            const unsigned grid = nitems < persist ? nitems : persist;
             constexpr int TH = 1 << (LOGN - 6);
+            const size_t half_lds = lds_bytes / 2 + 16 * (size_t)TH;      // + prefetch landing zone
             if (c.balanced) {
                 auto k = k_ks_accum_half<LOGN, true>;
                 if ((e = set_lds(k, half_lds)) != hipSuccess) return e;
                 hipLaunchKernelGGL(k, dim3(grid), dim3(TH), half_lds, c.stream, R, c.a, c.b, (const int32_t*)c.digits,
-                                   c.hint, c.out, (unsigned)c.nct, c.spre_r2);
+                                   c.hint, c.out, (unsigned)c.nct, nitems, c.spre_r2, dbg_mask);
             } else {
                 auto k = k_ks_accum_half<LOGN, false>;
                 if ((e = set_lds(k, half_lds)) != hipSuccess) return e;
                 hipLaunchKernelGGL(k, dim3(grid), dim3(TH), half_lds, c.stream, R, c.a, c.b, (const int32_t*)c.digits,
-                                   c.hint, c.out, (unsigned)c.nct, c.spre_r2);
+                                   c.hint, c.out, (unsigned)c.nct, nitems, c.spre_r2, dbg_mask);
             }
             break;
         }

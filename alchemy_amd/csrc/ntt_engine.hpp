@@ -52,7 +52,7 @@ template <> struct Vec4<u64> { typedef u64 type __attribute__((ext_vector_type(2
 // lane of the wave wants the same words (UNIFORM), the index is made wave-uniform so the loads become
 // scalar (s_load) and the twiddles live in SGPRs.
 template <typename W, int CNT, bool UNIFORM>
-__device__ __forceinline__ void load_tw(const W* __restrict__ tw, int first, W (&w)[CNT]) {
+__device__ __forceinline__ void load_tw(const W* __restrict__ tw, int first, W (&w)[CNT]) {   // W: table word
     if constexpr (UNIFORM) {
         const int f = __builtin_amdgcn_readfirstlane(first);
 #pragma unroll
@@ -90,8 +90,10 @@ struct NoEpilogue {
 // `prefix`: the transform may be a sub-transform of a larger one whose leading stages ran elsewhere
 // (k_ks_accum_half: prefix = 2 + half); group h of stage s then uses twiddle (prefix << s) + h.  A whole
 // transform has prefix 1.
-template <int LOGN, int LOGT, typename W, int S0, int NS, bool INVERSE, bool KEEP, bool SERIAL, typename Epi>
-__device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const W* __restrict__ tw, W q, W qni,
+// TW is the twiddle table's word type: W for Montgomery twiddles, u64 for the Plantard constants the
+// forward transform of 32-bit rings uses (bfly_fwd overloads pick the arithmetic from it).
+template <int LOGN, int LOGT, typename W, int S0, int NS, bool INVERSE, bool KEEP, bool SERIAL, typename TW, typename Epi>
+__device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const TW* __restrict__ tw, W q, W qni,
                                          W ninv_m, W w1ninv_m, int t, int prefix, Epi&& epi) {
     typedef Geo<LOGN, LOGT> G;
     constexpr int R = 1 << NS;
@@ -129,13 +131,13 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const W* __restric
 #pragma unroll
             for (int r = 0; r < NS; ++r) {
                 const int half = R >> (r + 1);
-                W w[1 << 3];
-                if (r == 0) { W t1[1]; load_tw<W, 1, UNIFORM>(tw, gm, t1); w[0] = t1[0]; }
-                else if (r == 1) { W t2[2]; load_tw<W, 2, UNIFORM>(tw, gm << 1, t2); w[0] = t2[0]; w[1] = t2[1]; }
-                else if (r == 2) { W t4[4]; load_tw<W, 4, UNIFORM>(tw, gm << 2, t4);
+                TW w[1 << 3];
+                if (r == 0) { TW t1[1]; load_tw<TW, 1, UNIFORM>(tw, gm, t1); w[0] = t1[0]; }
+                else if (r == 1) { TW t2[2]; load_tw<TW, 2, UNIFORM>(tw, gm << 1, t2); w[0] = t2[0]; w[1] = t2[1]; }
+                else if (r == 2) { TW t4[4]; load_tw<TW, 4, UNIFORM>(tw, gm << 2, t4);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) w[c] = t4[c]; }
-                else { W t8[8]; load_tw<W, 8, UNIFORM>(tw, gm << 3, t8);
+                else { TW t8[8]; load_tw<TW, 8, UNIFORM>(tw, gm << 3, t8);
 #pragma unroll
                     for (int c = 0; c < 8; ++c) w[c] = t8[c]; }
 #pragma unroll
@@ -148,13 +150,13 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const W* __restric
 #pragma unroll
             for (int r = NS - 1; r >= 0; --r) {
                 const int half = R >> (r + 1);
-                W w[1 << 3];
-                if (r == 0) { W t1[1]; load_tw<W, 1, UNIFORM>(tw, gm, t1); w[0] = t1[0]; }
-                else if (r == 1) { W t2[2]; load_tw<W, 2, UNIFORM>(tw, gm << 1, t2); w[0] = t2[0]; w[1] = t2[1]; }
-                else if (r == 2) { W t4[4]; load_tw<W, 4, UNIFORM>(tw, gm << 2, t4);
+                TW w[1 << 3];
+                if (r == 0) { TW t1[1]; load_tw<TW, 1, UNIFORM>(tw, gm, t1); w[0] = t1[0]; }
+                else if (r == 1) { TW t2[2]; load_tw<TW, 2, UNIFORM>(tw, gm << 1, t2); w[0] = t2[0]; w[1] = t2[1]; }
+                else if (r == 2) { TW t4[4]; load_tw<TW, 4, UNIFORM>(tw, gm << 2, t4);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) w[c] = t4[c]; }
-                else { W t8[8]; load_tw<W, 8, UNIFORM>(tw, gm << 3, t8);
+                else { TW t8[8]; load_tw<TW, 8, UNIFORM>(tw, gm << 3, t8);
 #pragma unroll
                     for (int c = 0; c < 8; ++c) w[c] = t8[c]; }
 #pragma unroll
@@ -203,27 +205,31 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const W* __restric
 // tid = threadIdx.x (passed in so that a caller looping over transforms can make it opaque per iteration
 // and stop the compiler from hoisting every pass's LDS addresses out of its loop).
 // Callers must __syncthreads() after filling LDS; the function syncs between passes.
-template <int LOGN, typename W, bool KEEP_LAST, bool SERIAL = false, typename Epi>
-__device__ __forceinline__ void ntt_forward(W* lds, const W* tw, W q, W qni, int tid, Epi&& epi) {
+template <int LOGN, typename W, bool KEEP_LAST, bool SERIAL = false, typename TW, typename Epi>
+__device__ __forceinline__ void ntt_forward(W* lds, const TW* tw, const W* twm, W q, W qni, int tid, Epi&& epi) {
+    // tw : twiddle table for the passes whose twiddles are shared by many lanes (Plantard constants on 32-bit
+    //      rings: one instruction less per butterfly, fetched by scalar or broadcast loads);
+    // twm: Montgomery table for the last pass, where every lane needs its own 15 twiddles and two-word
+    //      constants would double the per-lane load traffic and register pressure.
     typedef Geo<LOGN> G;
     constexpr int P = G::NPASS, F = G::NS0, LT = G::LOGT;
     NoEpilogue none;
     if constexpr (P == 1) {
-        ntt_pass<LOGN, LT, W, 0, F, false, KEEP_LAST, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, 1, epi);
+        ntt_pass<LOGN, LT, W, 0, F, false, KEEP_LAST, SERIAL>(lds, twm, q, qni, (W)0, (W)0, tid, 1, epi);
     } else {
         ntt_pass<LOGN, LT, W, 0, F, false, false, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, 1, none);
         __syncthreads();
         if constexpr (P == 2) {
-            ntt_pass<LOGN, LT, W, F, 4, false, KEEP_LAST, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, 1, epi);
+            ntt_pass<LOGN, LT, W, F, 4, false, KEEP_LAST, SERIAL>(lds, twm, q, qni, (W)0, (W)0, tid, 1, epi);
         } else {
             ntt_pass<LOGN, LT, W, F, 4, false, false, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, 1, none);
             __syncthreads();
             if constexpr (P == 3) {
-                ntt_pass<LOGN, LT, W, F + 4, 4, false, KEEP_LAST, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, 1, epi);
+                ntt_pass<LOGN, LT, W, F + 4, 4, false, KEEP_LAST, SERIAL>(lds, twm, q, qni, (W)0, (W)0, tid, 1, epi);
             } else {
                 ntt_pass<LOGN, LT, W, F + 4, 4, false, false, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, 1, none);
                 __syncthreads();
-                ntt_pass<LOGN, LT, W, F + 8, 4, false, KEEP_LAST, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, 1, epi);
+                ntt_pass<LOGN, LT, W, F + 8, 4, false, KEEP_LAST, SERIAL>(lds, twm, q, qni, (W)0, (W)0, tid, 1, epi);
             }
         }
     }
