@@ -740,7 +740,8 @@ static int do_mul_relin(alch_ring* r, const alch_hint* hint, const void* a, cons
     c.balanced = r->balanced;
     scal_to_mont<W>(r, s_pre, 2, c.spre_r2);
     const size_t ct_words = 2 * elem_words(r);
-    const bool two = batch > chunk;
+    static const bool one_stream = getenv("ALCH_ONE_STREAM") != nullptr;
+    const bool two = batch > chunk && !one_stream;
     if (two) {
         HIP_TRY(hipEventRecord(r->ev_fork, r->stream));
         HIP_TRY(hipStreamWaitEvent(r->aux, r->ev_fork, 0));

@@ -121,46 +121,68 @@ __global__ void __launch_bounds__(Geo<LOGN>::T) k_crt(DevRing<W> R, W* __restric
 template <int LOGN, typename W>
 __global__ void __launch_bounds__(Geo<LOGN>::T)
 k_tensor_intt(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
-              typename Signed<W>::type* __restrict__ digits, Scal<W> spre) {
+              typename Signed<W>::type* __restrict__ digits, unsigned nitems, Scal<W> spre) {
     typedef Geo<LOGN> G;
     typedef typename Vec4<W>::type V;
     typedef typename Signed<W>::type SW;
     constexpr int VL = Vec4<W>::LANES;
+    constexpr int NV = G::E / VL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W* lds = reinterpret_cast<W*>(smem);
     const int L = R.L;
-    const size_t ct = blockIdx.x / (unsigned)L;
-    const int i = (int)(blockIdx.x % (unsigned)L);
-    const ModP<W> m = R.mod[i];
-    const W q = m.q, qni = m.qni;
-    const W sr2 = spre.v[i];
-    const W* a1 = a + ((2 * ct + 1) * (size_t)L + i) * (size_t)G::N;
-    const W* b1 = b + ((2 * ct + 1) * (size_t)L + i) * (size_t)G::N;
-
-    stage_in<LOGN, W>(lds, [&](int idx) {
-        V x = *reinterpret_cast<const V*>(a1 + idx);
-        V y = *reinterpret_cast<const V*>(b1 + idx);
-        V v;
+    // Persistent workgroups (one polynomial fills the CU's LDS, so one workgroup per CU is resident): the
+    // a1/b1 coefficients of the NEXT item are loaded into registers while the current transform runs, which
+    // hides the HBM latency that a one-workgroup CU cannot hide by switching workgroups.
+    V pa[NV], pb[NV];
+    auto issue = [&](unsigned item) {
+        const size_t ct = item / (unsigned)L;
+        const int i = (int)(item % (unsigned)L);
+        const W* a1 = a + ((2 * ct + 1) * (size_t)L + i) * (size_t)G::N;
+        const W* b1 = b + ((2 * ct + 1) * (size_t)L + i) * (size_t)G::N;
 #pragma unroll
-        for (int e = 0; e < VL; ++e) {
-            W xs = csub(mont_mul_lazy(x[e], sr2, q, qni), q);       // a1 * s * R
-            v[e] = mont_mul_lazy(y[e], xs, q, qni);                  // a1 * b1 * s   in [0,2q)
+        for (int r = 0; r < NV; ++r) {
+            const int idx = ((int)threadIdx.x + G::T * r) * VL;
+            pa[r] = *reinterpret_cast<const V*>(a1 + idx);
+            pb[r] = *reinterpret_cast<const V*>(b1 + idx);
         }
-        return v;
-    });
-    __syncthreads();
-    SW* d = digits + (ct * (size_t)L + i) * (size_t)G::N;
-    constexpr int RR = 1 << G::NS0;
-    constexpr int STRIDE = G::N / RR;
-    const W half = (q - 1) >> 1;
-    ntt_inverse<LOGN, W, true>(lds, R.twi[i], q, qni, R.ninv_m[i], R.w1ninv_m[i], (int)threadIdx.x, [&](int, int base, W* x) {
+    };
+    unsigned item = blockIdx.x;
+    if (item < nitems) issue(item);
+    for (; item < nitems; item += gridDim.x) {
+        const size_t ct = item / (unsigned)L;
+        const int i = (int)(item % (unsigned)L);
+        const ModP<W> m = R.mod[i];
+        const W q = m.q, qni = m.qni;
+        const W sr2 = spre.v[i];
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));          // keep LDS address arithmetic inside the item loop (VGPR pressure)
 #pragma unroll
-        for (int k = 0; k < RR; ++k) {
-            W v = csub(x[k], q);
-            SW z = v > half ? (SW)v - (SW)q : (SW)v;                 // centred lift (Lol `lift`)
-            d[base + k * STRIDE] = z;
+        for (int r = 0; r < NV; ++r) {
+            const int idx = (tid + G::T * r) * VL;
+            V v;
+#pragma unroll
+            for (int e = 0; e < VL; ++e) {
+                W xs = csub(mont_mul_lazy(pa[r][e], sr2, q, qni), q);     // a1 * s * R
+                v[e] = mont_mul_lazy(pb[r][e], xs, q, qni);                // a1 * b1 * s   in [0,2q)
+            }
+            *reinterpret_cast<V*>(&lds[swz<LOGN>(idx)]) = v;
         }
-    });
+        __syncthreads();
+        if (item + gridDim.x < nitems) issue(item + gridDim.x);
+        SW* d = digits + (ct * (size_t)L + i) * (size_t)G::N;
+        constexpr int RR = 1 << G::NS0;
+        constexpr int STRIDE = G::N / RR;
+        const W half = (q - 1) >> 1;
+        ntt_inverse<LOGN, W, true>(lds, R.twi[i], q, qni, R.ninv_m[i], R.w1ninv_m[i], tid, [&](int, int base, W* x) {
+#pragma unroll
+            for (int k = 0; k < RR; ++k) {
+                W v = csub(x[k], q);
+                SW z = v > half ? (SW)v - (SW)q : (SW)v;                 // centred lift (Lol `lift`)
+                d[base + k * STRIDE] = z;
+            }
+        });
+        __syncthreads();                       // every lane has read its last-pass inputs before LDS is refilled
+    }
 }
 
 // ---- fused kernel B: digit transforms + key-switch inner product ------------------------------------
@@ -311,8 +333,21 @@ inline hipError_t run_call(const NttCall<W>& c) {
     case OP_TENSOR_INTT: {
         auto k = k_tensor_intt<LOGN, W>;
         if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)(c.nct * (size_t)R.L)), dim3(G::T), lds_bytes, c.stream, R, c.a, c.b,
-                           (SW*)c.digits, c.spre_r2);
+        const unsigned nitems = (unsigned)(c.nct * (size_t)R.L);
+        // resident workgroups per CU: LDS (160 KiB), waves (32 per CU), at most 8
+        unsigned per_cu = (unsigned)(163840 / (lds_bytes ? lds_bytes : 1));
+        const unsigned by_waves = 32u / (unsigned)((G::T + 63) / 64);
+        if (per_cu > by_waves) per_cu = by_waves;
+        if (per_cu > 8) per_cu = 8;
+        if (per_cu < 1) per_cu = 1;
+        // ALCH_TI_GRID: 0 = one workgroup per item (default; measured 1-2 % faster than persisting), -1 = one
+        // resident set of persistent workgroups, n > 0 = n persistent workgroups
+        static const int ti_grid = getenv("ALCH_TI_GRID") ? atoi(getenv("ALCH_TI_GRID")) : 0;
+        unsigned grid = nitems < 256u * per_cu ? nitems : 256u * per_cu;
+        if (ti_grid == 0) grid = nitems;
+        else if (ti_grid > 0 && (unsigned)ti_grid < nitems) grid = (unsigned)ti_grid;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), lds_bytes, c.stream, R, c.a, c.b, (SW*)c.digits, nitems,
+                           c.spre_r2);
         break;
     }
     case OP_KS_ACCUM: {

@@ -1,0 +1,51 @@
+"""GPU: the launch-structure knobs of ct_mul_relin must not change results -- multi-chunk batches on two
+streams, tiny chunks, persistent workgroup grids smaller than the item count, persistent tensor kernel.
+Each configuration runs in its own process (the knobs are read once per process) and is compared with the
+oracle."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = textwrap.dedent("""
+    import sys, numpy as np
+    sys.path.insert(0, %r)
+    import alchemy_amd as A
+    from oracle import cref
+    qs = [2147352577, 2146959361, 2146041857, 2145976321]
+    logn, batch = int(sys.argv[1]), int(sys.argv[2])
+    n = 1 << logn
+    g, o = A.Ring(2 * n, qs), cref.Ring(n, qs)
+    rng = np.random.default_rng(5)
+    rnd = lambda c: np.stack([np.stack([rng.integers(0, q, size=n, dtype=np.int64) for q in qs], axis=1) for _ in range(c)])
+    hint, a, b = rnd(8), rnd(2 * batch), rnd(2 * batch)
+    gh, ga, gb, gout = g.hint_load(hint), g.upload(a), g.upload(b), g.alloc(2 * batch)
+    g.ct_mul_relin(gh, ga, gb, gout, batch)
+    got = gout.download()
+    for ct in range(batch):
+        w0, w1 = o.ct_mul_relin(list(hint), a[2*ct], a[2*ct+1], b[2*ct], b[2*ct+1])
+        assert np.array_equal(got[2*ct], w0) and np.array_equal(got[2*ct+1], w1), ct
+    print("OK")
+""" % ROOT)
+
+
+@pytest.mark.parametrize("env,logn,batch", [
+    ({"ALCH_CHUNK": "8"}, 11, 37),                              # 5 chunks, two streams, ragged last chunk
+    ({"ALCH_CHUNK": "8", "ALCH_ONE_STREAM": "1"}, 11, 21),
+    ({"ALCH_CHUNK": "16", "ALCH_KS_GRID": "24"}, 11, 40),       # persistent grid smaller than the item count
+    ({"ALCH_CHUNK": "8", "ALCH_KS_GRID": "8", "ALCH_TI_GRID": "8"}, 15, 9),
+    ({"ALCH_TI_GRID": "-1"}, 11, 5),
+    ({}, 15, 3),
+])
+def test_launch_structure_does_not_change_results(env, logn, batch):
+    e = dict(os.environ, **env)
+    out = subprocess.run([sys.executable, "-c", WORKER, str(logn), str(batch)], env=e, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.strip().endswith("OK")
