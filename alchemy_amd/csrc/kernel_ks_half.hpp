@@ -83,19 +83,22 @@ __device__ __forceinline__ u32 mont_red_lazy(u64 p, u32 q, u32 qni) {       // p
     return (u32)((p + (u64)m * q) >> 32);
 }
 
-template <int LOGN, bool BALANCED>
-__global__ void __launch_bounds__(1 << (LOGN - 6), 4)
+// EPT = coefficients (and accumulator pairs) per thread: 32 -> n/64 threads, <= 128 VGPRs, 4 waves per SIMD.
+// EPT = 16 (n/32 threads, <= 64 VGPRs, 8 waves per SIMD) builds and is bit-exact, but spills 61 VGPRs and ran
+// 30 % SLOWER on MI355X (294 k vs 418 k op/s), so it is not dispatched.
+template <int LOGN, bool BALANCED, int EPT = 32>
+__global__ void __launch_bounds__((1 << (LOGN - 1)) / EPT, EPT == 32 ? 4 : 8)
 k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict__ b,
                 const int32_t* __restrict__ digits, const u32* __restrict__ hint, u32* __restrict__ out,
                 unsigned nct, unsigned nitems, Scal<u32> spre, unsigned dbg_mask) {
     typedef u32 W;
-    constexpr int LOGM = LOGN - 1, M = 1 << LOGM, N = 1 << LOGN, LT = LOGN - 6, T = 1 << LT;
+    constexpr int LOGM = LOGN - 1, M = 1 << LOGM, N = 1 << LOGN, LT = (EPT == 32) ? LOGN - 6 : LOGN - 5, T = 1 << LT;
     typedef Geo<LOGM, LT> G;
-    static_assert(G::E == 32, "32 coefficients per thread");
+    static_assert(G::E == EPT && (EPT == 32 || EPT == 16), "16 or 32 coefficients per thread");
     static_assert((LOGM - 2) % 4 == 0, "remaining stages must split into radix-16 passes");
     typedef u32 V __attribute__((ext_vector_type(4)));
     typedef int32_t SV __attribute__((ext_vector_type(4)));
-    constexpr int NG = 2;
+    constexpr int NG = EPT / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W* lds = reinterpret_cast<W*>(smem);
     const int L = R.L;
@@ -124,7 +127,7 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     const W sr2 = spre.v[j];
     const size_t n = (size_t)N;
     const size_t slot0 = (size_t)hf * M;
-    const size_t cti = (dbg_mask == 0xFFFFFFF7u) ? (ct & 7) : ct;      // traffic experiment: alias the inputs
+    const size_t cti = (dbg_mask & 1u) ? (ct & 7) : ct;                // traffic experiment: alias the inputs
     const W* a0 = a + ((2 * cti) * (size_t)L + j) * n + slot0;
     const W* a1 = a + ((2 * cti + 1) * (size_t)L + j) * n + slot0;
     const W* b0 = b + ((2 * cti) * (size_t)L + j) * n + slot0;
@@ -142,18 +145,19 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         size_t ct2;
         decode(nitem, j2, hf2, ct2);
         if (ct2 >= nct) return;
+        if (EPT == 16 && threadIdx.x >= (unsigned)(M / 32)) return;     // one lane per 128-byte line
         const size_t off = (size_t)hf2 * M + (size_t)threadIdx.x * 32;
         const W* rows[4] = {a + ((2 * ct2) * (size_t)L + j2) * n + off, a + ((2 * ct2 + 1) * (size_t)L + j2) * n + off,
                             b + ((2 * ct2) * (size_t)L + j2) * n + off, b + ((2 * ct2 + 1) * (size_t)L + j2) * n + off};
 #pragma unroll
         for (int x = 0; x < 4; ++x)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)rows[x],
-                                             (__attribute__((address_space(3))) void*)(sink + x * T + ((int)threadIdx.x & ~63)),
+                                             (__attribute__((address_space(3))) void*)(sink + x * (M / 32) + ((int)threadIdx.x & ~63)),
                                              4, 0, 0);
     };
 
     KS_STAMP_INIT();
-    W acc0[32], acc1[32];
+    W acc0[EPT], acc1[EPT];
     {   // c0, c1 and the diagonal digit (i == j): d_j = c2_j (mod q_j), no transform needed.
         // Eight 4-coefficient slices, software-pipelined: the six 16-byte loads of slice s+1 are in flight
         // while slice s is multiplied out (issuing them one slice at a time exposed the HBM latency eight
@@ -169,8 +173,8 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         };
         issue(0, in[0]);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            if (s + 1 < 8) issue(s + 1, in[(s + 1) & 1]);
+        for (int s = 0; s < EPT / 4; ++s) {
+            if (s + 1 < EPT / 4) issue(s + 1, in[(s + 1) & 1]);
             const V(&v)[6] = in[s & 1];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -190,7 +194,7 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     const int i_last = (j == L - 1) ? L - 2 : L - 1;
     for (int i = 0; i < L; ++i) {
         if (i == j) continue;
-        const int32_t* d = digits + ((ct & dbg_mask) * (size_t)L + i) * n;    // dbg_mask = ~0u except in traffic experiments
+        const int32_t* d = digits + (((dbg_mask & 2u) ? (ct & 7) : ct) * (size_t)L + i) * n;   // dbg_mask: traffic experiments only
         // Nothing below depends on i except d and the hint rows; keep addresses and twiddles from being
         // hoisted out of the digit loop (that costs ~250 spilled VGPRs).
         auto twf = fwd_tw(R, j);                        // Plantard constants (shared-twiddle passes)
@@ -247,8 +251,9 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         if (i == i_last) prefetch_next(item + gridDim.x);
 
         // ---- remaining stages: sub-transform of size n/2, local stages 2 .. LOGM-1
-        const W* h0 = hj + (size_t)(2 * i) * hstride;
-        const W* h1 = hj + (size_t)(2 * i + 1) * hstride;
+        const int ih = (dbg_mask & 8u) ? j : i;                         // traffic experiment: alias the hint rows
+        const W* h0 = hj + (size_t)(2 * ih) * hstride;
+        const W* h1 = hj + (size_t)(2 * ih + 1) * hstride;
         auto epi = [&acc0, &acc1, h0, h1, q, qni](int g, int base, W* x) {
 #pragma unroll
             for (int k = 0; k < 16; k += 4) {
@@ -285,8 +290,9 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     }
 
     KS_STAMP(9);
-    W* o0 = out + ((2 * ct) * (size_t)L + j) * n + slot0;
-    W* o1 = out + ((2 * ct + 1) * (size_t)L + j) * n + slot0;
+    const size_t cto = (dbg_mask & 4u) ? (ct & 7) : ct;                // traffic experiment: alias the outputs
+    W* o0 = out + ((2 * cto) * (size_t)L + j) * n + slot0;
+    W* o1 = out + ((2 * cto + 1) * (size_t)L + j) * n + slot0;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
 #pragma unroll

@@ -353,7 +353,7 @@ inline hipError_t run_call(const NttCall<W>& c) {
     case OP_KS_ACCUM: {
         if constexpr (std::is_same<W, u32>::value && (LOGN == 15 || LOGN == 11)) {
             // two workgroups per (ciphertext, limb): see kernel_ks_half.hpp
-            static const unsigned dbg_mask = getenv("ALCH_EXP_DIGMASK") ? (unsigned)strtoul(getenv("ALCH_EXP_DIGMASK"), nullptr, 0) : 0xFFFFFFFFu;
+            static const unsigned dbg_mask = getenv("ALCH_EXP_FLAGS") ? (unsigned)strtoul(getenv("ALCH_EXP_FLAGS"), nullptr, 0) : 0u;   // 1 inputs, 2 digits, 4 outputs, 8 hints aliased (wrong results, timing only)
             const size_t groups = (c.nct + 7) / 8;
             const unsigned nitems = (unsigned)(groups * 16 * (size_t)R.L);
             static const unsigned persist = getenv("ALCH_KS_GRID") ? (unsigned)atoi(getenv("ALCH_KS_GRID")) : 1024u;  // 4 per CU: 2 resident + 2 queued (measured best of 256/512/1024)
