@@ -23,7 +23,8 @@ SYMBOLS = [
     "alch_divg_pow", "alch_divg_dec", "alch_divg_crt", "alch_decompose_triv", "alch_buf_alloc", "alch_buf_free",
     "alch_buf_elems", "alch_buf_upload", "alch_buf_download", "alch_buf_fill_uniform", "alch_buf_crt",
     "alch_buf_crtinv", "alch_buf_mul", "alch_buf_add", "alch_buf_checksum", "alch_hint_load", "alch_hint_from_buf",
-    "alch_hint_free", "alch_ct_mul_relin", "alch_buf_rescale_drop0",
+    "alch_hint_free", "alch_ct_mul_relin", "alch_buf_rescale_drop0", "alch_buf_sub", "alch_buf_scale",
+    "alch_buf_decompose_triv", "alch_buf_rescale_add0",
 ]
 
 
@@ -85,6 +86,10 @@ def load_library():
         "alch_hint_free": [VP],
         "alch_ct_mul_relin": [VP, VP, VP, VP, VP, C.c_size_t, PU64, C.c_uint],
         "alch_buf_rescale_drop0": [VP, VP, C.c_size_t],
+        "alch_buf_rescale_add0": [VP, VP, C.c_size_t],
+        "alch_buf_sub": [VP, VP, VP, C.c_size_t],
+        "alch_buf_scale": [VP, VP, C.c_size_t, PU64],
+        "alch_buf_decompose_triv": [VP, C.c_size_t, VP, C.c_size_t],
     }
     for name, args in sig.items():
         fn = getattr(l, name)
@@ -273,6 +278,18 @@ class Buf:
 
     def rescale_drop0_into(self, dst: "Buf", count: int):
         _check(self.ring._l.alch_buf_rescale_drop0(self._h, dst._h, count))
+
+    def rescale_add0_into(self, dst: "Buf", count: int):
+        _check(self.ring._l.alch_buf_rescale_add0(self._h, dst._h, count))
+
+    def sub(self, a: "Buf", b: "Buf", count: int):
+        _check(self.ring._l.alch_buf_sub(self._h, a._h, b._h, count))
+
+    def scale(self, src: "Buf", count: int, s):
+        _check(self.ring._l.alch_buf_scale(self._h, src._h, count, _pu64(s)))
+
+    def decompose_triv_into(self, src_index: int, dst: "Buf", dst_first: int = 0):
+        _check(self.ring._l.alch_buf_decompose_triv(self._h, src_index, dst._h, dst_first))
 
 
 class Hint:

@@ -180,6 +180,18 @@ __global__ void k_rescale_drop0(DevRing<W> R, const W* src, W* dst, size_t elems
     }
 }
 
+// Rescale b -> (a,b): dst limb 0 = 0, dst limb j+1 = q_a * src limb j.  qa_m[j+1] = q_a mod q_{j+1} (Montgomery).
+template <typename W>
+__global__ void k_rescale_add0(DevRing<W> Rd, const W* src, W* dst, size_t elems, Scal<W> qa_m) {
+    const size_t n = (size_t)1 << Rd.logn;
+    const size_t L = (size_t)Rd.L;
+    const size_t total = elems * L * n;
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < total; w += (size_t)gridDim.x * blockDim.x) {
+        const size_t k = w % n, j = (w / n) % L, e = w / (n * L);
+        dst[w] = j == 0 ? (W)0 : mont_mul(src[(e * (L - 1) + (j - 1)) * n + k], qa_m.v[j], Rd.mod[j]);
+    }
+}
+
 template <typename W>
 __global__ void k_checksum(const W* data, size_t words, u64* sum) {
     u64 acc = 0;
@@ -551,6 +563,7 @@ static int buf_pointwise(alch_buf* dst, const alch_buf* a, const alch_buf* b, si
 
 extern "C" int alch_buf_mul(alch_buf* d, const alch_buf* a, const alch_buf* b, size_t count) { return buf_pointwise(d, a, b, count, PW_MUL); }
 extern "C" int alch_buf_add(alch_buf* d, const alch_buf* a, const alch_buf* b, size_t count) { return buf_pointwise(d, a, b, count, PW_ADD); }
+extern "C" int alch_buf_sub(alch_buf* d, const alch_buf* a, const alch_buf* b, size_t count) { return buf_pointwise(d, a, b, count, PW_SUB); }
 
 extern "C" int alch_buf_checksum(const alch_buf* b, size_t first, size_t count, uint64_t* sum) {
     if (!b || !sum) return fail(ALCH_E_INVALID, "null argument");
@@ -693,6 +706,28 @@ static int hint_from_device(alch_ring* r, int gadget, const void* src_crt, alch_
     return rc;
 }
 
+extern "C" int alch_buf_scale(alch_buf* dst, const alch_buf* src, size_t count, const uint64_t* s) {
+    if (!dst || !src || !s) return fail(ALCH_E_INVALID, "null argument");
+    if (dst->ring != src->ring) return fail(ALCH_E_INVALID, "buffers belong to different rings");
+    if (count > dst->n_elems || count > src->n_elems) return fail(ALCH_E_INVALID, "count out of bounds");
+    alch_ring* r = dst->ring;
+    return r->word == 4 ? do_scale<u32>(r, dst->dptr, src->dptr, count, s) : do_scale<u64>(r, dst->dptr, src->dptr, count, s);
+}
+
+extern "C" int alch_buf_decompose_triv(const alch_buf* src, size_t src_index, alch_buf* dst, size_t dst_first) {
+    if (!src || !dst) return fail(ALCH_E_INVALID, "null buffer");
+    if (src->ring != dst->ring) return fail(ALCH_E_INVALID, "buffers belong to different rings");
+    alch_ring* r = src->ring;
+    if (src_index >= src->n_elems || dst_first + (size_t)r->L > dst->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
+    const char* c = reinterpret_cast<const char*>(src->dptr) + src_index * elem_bytes(r);
+    char* dig = reinterpret_cast<char*>(dst->dptr) + dst_first * elem_bytes(r);
+    const size_t total = (size_t)r->L * elem_words(r);
+    if (r->word == 4) hipLaunchKernelGGL((k_decompose_triv<u32>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d32, (const u32*)c, (u32*)dig);
+    else hipLaunchKernelGGL((k_decompose_triv<u64>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d64, (const u64*)c, (u64*)dig);
+    HIP_TRY(hipGetLastError());
+    return ALCH_OK;
+}
+
 extern "C" int alch_hint_load(alch_ring* r, int gadget, const int64_t* host_crt, alch_hint** out) {
     if (!r || !host_crt || !out) return fail(ALCH_E_INVALID, "null argument");
     ScratchBuf s;
@@ -825,5 +860,30 @@ extern "C" int alch_buf_rescale_drop0(const alch_buf* src, alch_buf* dst, size_t
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(rs->stream));
+    return ALCH_OK;
+}
+
+extern "C" int alch_buf_rescale_add0(const alch_buf* src, alch_buf* dst, size_t count) {
+    if (!src || !dst) return fail(ALCH_E_INVALID, "null buffer");
+    alch_ring* rs = src->ring;
+    alch_ring* rd = dst->ring;
+    if (rd->L != rs->L + 1 || rd->n != rs->n || rd->word != rs->word)
+        return fail(ALCH_E_INVALID, "destination ring must be the source ring plus one limb in front");
+    for (int j = 0; j < rs->L; ++j)
+        if (rs->q[j] != rd->q[j + 1]) return fail(ALCH_E_INVALID, "destination limbs 1..L must equal the source limbs");
+    if (count > src->n_elems || count > dst->n_elems) return fail(ALCH_E_INVALID, "count out of bounds");
+    uint64_t qa[MAXL] = {0};
+    for (int j = 1; j < rd->L; ++j) qa[j] = rd->q[0] % rd->q[j];
+    const size_t total = count * (size_t)rd->L * rd->n;
+    HIP_TRY(hipStreamSynchronize(rs->stream));
+    if (rd->word == 4) {
+        Scal<u32> sm; scal_to_mont<u32>(rd, qa, 1, sm);
+        hipLaunchKernelGGL((k_rescale_add0<u32>), dim3(ew_grid(total)), dim3(256), 0, rd->stream, rd->d32, (const u32*)src->dptr, (u32*)dst->dptr, count, sm);
+    } else {
+        Scal<u64> sm; scal_to_mont<u64>(rd, qa, 1, sm);
+        hipLaunchKernelGGL((k_rescale_add0<u64>), dim3(ew_grid(total)), dim3(256), 0, rd->stream, rd->d64, (const u64*)src->dptr, (u64*)dst->dptr, count, sm);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(rd->stream));
     return ALCH_OK;
 }

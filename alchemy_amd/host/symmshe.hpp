@@ -11,6 +11,7 @@
 //   operator+      SymmSHE (+)  = E's add_                 (Eval.hs:58-60)
 //   keySwitchQuadCirc                                      (Eval.hs:133)
 //   modSwitchDrop0 one limb of modSwitch (rescale (a,b)->b)(Eval.hs:130)
+//   modSwitchAdd0  the other direction (rescale b->(a,b))   (Eval.hs:130; PT2CT.hs:177)
 //   genSK, ksQuadCircHint, encrypt, decrypt                (KeysHints.hs:93-96,101-113; PT2CT.hs:84-99)
 //   mulRelinBatch  the fused device path for PT2CT's  keySwitchQuad_ hint $: (x *: y)  (PT2CT.hs:172-177)
 //
@@ -241,6 +242,30 @@ inline CT modSwitchDrop0(const CT& ct_, const Ring& dst) {
         check(alch_buf_upload(bs, i, 1, p.data().data()), "alch_buf_upload");
     }
     check(alch_buf_rescale_drop0(bs, bd, ct.c.size()), "alch_buf_rescale_drop0");
+    for (size_t i = 0; i < ct.c.size(); ++i) {
+        Cyc x(dst, Basis::Pow);
+        check(alch_buf_download(bd, i, 1, x.data().data()), "alch_buf_download");
+        o.c.push_back(std::move(x));
+    }
+    alch_buf_free(bs);
+    alch_buf_free(bd);
+    return o;
+}
+
+// The other direction of modSwitch: Rescale b -> (a,b) into a ring with one more limb in front (the first
+// modSwitch_ of PT2CT's mul_, PT2CT.hs:177: zq_in -> the hint's modulus).
+inline CT modSwitchAdd0(const CT& ct_, const Ring& dst) {
+    CT ct = toMSD(ct_);
+    const Ring& src = ct.c[0].ring();
+    alch_buf *bs = nullptr, *bd = nullptr;
+    check(alch_buf_alloc(src.handle(), ct.c.size(), &bs), "alch_buf_alloc");
+    check(alch_buf_alloc(dst.handle(), ct.c.size(), &bd), "alch_buf_alloc");
+    CT o{Encoding::MSD, ct.k, ct.l, ct.p, {}};
+    for (size_t i = 0; i < ct.c.size(); ++i) {
+        Cyc p = ct.c[i].advisePow();
+        check(alch_buf_upload(bs, i, 1, p.data().data()), "alch_buf_upload");
+    }
+    check(alch_buf_rescale_add0(bs, bd, ct.c.size()), "alch_buf_rescale_add0");
     for (size_t i = 0; i < ct.c.size(); ++i) {
         Cyc x(dst, Basis::Pow);
         check(alch_buf_download(bd, i, 1, x.data().data()), "alch_buf_download");

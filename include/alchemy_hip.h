@@ -123,6 +123,12 @@ int alch_buf_crt(alch_buf *buf, size_t first, size_t count);
 int alch_buf_crtinv(alch_buf *buf, size_t first, size_t count);
 int alch_buf_mul(alch_buf *dst, const alch_buf *a, const alch_buf *b, size_t count);
 int alch_buf_add(alch_buf *dst, const alch_buf *a, const alch_buf *b, size_t count);
+int alch_buf_sub(alch_buf *dst, const alch_buf *a, const alch_buf *b, size_t count);
+/* dst = src * s_j per limb (toLSD / toMSD scalars of SymmSHE, any basis); dst may equal src. */
+int alch_buf_scale(alch_buf *dst, const alch_buf *src, size_t count, const uint64_t *s);
+/* Device-resident Lol `decompose` (TrivGad) + `reduce`: element `src_index` of src (Pow basis) -> L digit
+ * elements written to dst[dst_first .. dst_first+L) (Pow basis). */
+int alch_buf_decompose_triv(const alch_buf *src, size_t src_index, alch_buf *dst, size_t dst_first);
 /* 64-bit order-independent checksum of elements [first, first+count): sum over words of
  * splitmix64(position ^ value<<20) -- used by the full-size parity tests. */
 int alch_buf_checksum(const alch_buf *buf, size_t first, size_t count, uint64_t *sum);
@@ -153,6 +159,9 @@ int alch_ct_mul_relin(alch_ring *ring, const alch_hint *hint, const alch_buf *a,
  * Rescale (a,b) -> b on Pow-basis elements: src lives in ring_src (L limbs), dst in ring_dst whose
  * limbs are ring_src's limbs 1..L-1:  dst_j = q_0^-1 * (src_j - reduce(lift src_0)). */
 int alch_buf_rescale_drop0(const alch_buf *src, alch_buf *dst, size_t count);
+/* Rescale b -> (a,b) (modSwitch up, PT2CT.hs:177 first modSwitch_): dst lives in a ring whose limbs 1..L are
+ * src's limbs and whose limb 0 is the added modulus q_a:  dst_0 = 0,  dst_{j+1} = q_a * src_j.  Any basis. */
+int alch_buf_rescale_add0(const alch_buf *src, alch_buf *dst, size_t count);
 
 #ifdef __cplusplus
 }

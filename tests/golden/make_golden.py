@@ -132,6 +132,35 @@ def gen_arithmetic():
     })
 
 
+def gen_full_mul():
+    """The complete PT2CT mul_ (PT2CT.hs:172-177): modSwitch . keySwitchQuad hint . modSwitch $ (x * y) with the
+    hint one limb longer than the operands (KSPNoise for TrivGad, PT2CT.hs:139) and the result shorter.
+    Limb order: outermost pair component first, so zq_in and zq_out are suffixes of the hint's limb list."""
+    cases = []
+    for seed, (n, npt, p, qs_h, l_in, l_out) in enumerate([
+            (16, 2, 7, [1073750017, 8392193, 268440577], 2, 1),          # Arithmetic.hs moduli: 2 -> 3 -> 1 limbs
+            (32, 4, 2, [40961, 65537, 12289, 114689, 147457], 4, 3)]):   # HomomRLWR's shape 4 -> 5 -> 3
+        rng = random.Random(4000 + seed)
+        qs_in, qs_out = qs_h[len(qs_h) - l_in:], qs_h[len(qs_h) - l_out:]
+        sk = M.gen_sk(n, 3.0, rng)
+        pa = [rng.randrange(p) for _ in range(npt)]
+        pb = [rng.randrange(p) for _ in range(npt)]
+        x = M.encrypt(sk, pa, p, qs_in, 3.0, rng)
+        y = M.encrypt(sk, pb, p, qs_in, 3.0, rng)
+        hint = M.ks_quad_circ_hint(sk, qs_h, 3.0, rng, "triv")
+        prod = M.ct_mul(x, y)
+        up = M.mod_switch_up(prod, qs_h[:len(qs_h) - l_in])
+        ks = M.key_switch_quad_circ(hint, up)
+        res = M.mod_switch_down(ks, len(qs_h) - l_out)
+        want = M.negacyclic_mul(pa, pb, p)
+        assert M.decrypt(sk, res, npt) == want, "model: full mul_ does not decrypt"
+        cases.append({"n": n, "npt": npt, "p": p, "qs_hint": qs_h, "l_in": l_in, "l_out": l_out, "sk": sk,
+                      "pa": pa, "pb": pb, "want_pt": want, "x": ct_to_json(x), "y": ct_to_json(y),
+                      "hint": [[h0, h1] for h0, h1 in hint.h], "up": ct_to_json(up), "ks": ct_to_json(ks),
+                      "result": ct_to_json(res)})
+    dump("full_mul_small.json", {"cases": cases})
+
+
 def gen_digests():
     """Full-size digests (SHA-256 of little-endian int64, limb-major) from the C restatement, which the
     small fixtures above pin to the exact model.  Inputs follow the synthetic-residue rule shared by
@@ -167,4 +196,5 @@ if __name__ == "__main__":
     gen_decompose()
     gen_mul_relin()
     gen_arithmetic()
+    gen_full_mul()
     gen_digests()
