@@ -21,6 +21,15 @@
 #ifndef ALCH_KS_GBARRIER
 #define ALCH_KS_GBARRIER 1
 #endif
+#ifndef ALCH_KS_SETPRIO
+#define ALCH_KS_SETPRIO 0
+#endif
+// timing experiment only (wrong results): drop every workgroup barrier of the kernel
+#ifdef ALCH_EXP_NOBARRIER
+#define KS_SYNC() ((void)0)
+#else
+#define KS_SYNC() __syncthreads()
+#endif
 
 namespace alch {
 
@@ -116,11 +125,45 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         hf_ = (int)(which & 1u);
         ct_ = (size_t)grp * 8u + (rem & 7u);
     };
+    // experiment: delay a subset of the workgroups by ~half an item so that the two workgroups of a CU stop
+    // running identical phases at identical times (dbg_mask bits 16..23 = bit of blockIdx that selects the subset + 1)
+    if (dbg_mask >> 16) {
+        const unsigned bit = ((dbg_mask >> 16) & 0xFF) - 1;
+        if ((blockIdx.x >> bit) & 1u)
+            for (int s = 0; s < 16; ++s) __builtin_amdgcn_s_sleep(127);
+    }
+    // Results of an item are stored at the start of the NEXT item, right after that item's first two slices of
+    // tensor-input loads have been issued: vmcnt retires in order, so stores issued first would have to drain
+    // to HBM before the next item's loads could be consumed.  (Spreading the stores over all eight slices was
+    // measured 15 % slower.)
+    W acc0[EPT], acc1[EPT];
+    W* po0 = nullptr;
+    W* po1 = nullptr;
+    int prot = 0;
+    auto store_slice = [&](int r) {               // slice r of the previous item's results
+        if (po0 == nullptr) return;
+        const int idx = ((int)threadIdx.x + T * ((r + prot) & (EPT / 4 - 1))) * 4;
+        V v0, v1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v0[e] = acc0[r * 4 + e]; v1[e] = acc1[r * 4 + e]; }
+        *reinterpret_cast<V*>(po0 + idx) = v0;
+        *reinterpret_cast<V*>(po1 + idx) = v1;
+    };
+    auto flush_stores = [&]() {
+#pragma unroll
+        for (int r = 0; r < EPT / 4; ++r) store_slice(r);
+        po0 = nullptr;
+    };
     for (unsigned item = blockIdx.x; item < nitems; item += gridDim.x) {
     int j, hf;
     size_t ct;
     decode(item, j, hf, ct);
     if (ct >= nct) continue;
+    // Workgroups run identical code in lockstep over rows that are 64 KiB-aligned, so reading every row from
+    // its start makes all of them hit the same HBM channels at the same time (measured: the tensor-input and
+    // result streams of this kernel moved only ~2 TB/s).  Each item therefore walks its EPT/4 lane-contiguous
+    // 16-byte slices starting from a different one: slice r lives at chunk (r + rot) mod (EPT/4).
+    const int rot = (int)((item ^ (item >> 3)) & (EPT / 4 - 1));
 
     const ModP<W> m = R.mod[j];
     const W q = m.q, qni = m.qni;
@@ -157,7 +200,6 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     };
 
     KS_STAMP_INIT();
-    W acc0[EPT], acc1[EPT];
     {   // c0, c1 and the diagonal digit (i == j): d_j = c2_j (mod q_j), no transform needed.
         // Eight 4-coefficient slices, software-pipelined: the six 16-byte loads of slice s+1 are in flight
         // while slice s is multiplied out (issuing them one slice at a time exposed the HBM latency eight
@@ -166,15 +208,20 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         const W* h1 = hj + (size_t)(2 * j + 1) * hstride;
         V in[2][6];
         auto issue = [&](int s, V (&v)[6]) {
-            const int idx = ((int)threadIdx.x + T * (s >> 2)) * 16 + (s & 3) * 4;
+            const int idx = ((int)threadIdx.x + T * ((s + rot) & (EPT / 4 - 1))) * 4;   // lane-contiguous 16-byte pieces
             v[0] = *reinterpret_cast<const V*>(a0 + idx); v[1] = *reinterpret_cast<const V*>(a1 + idx);
             v[2] = *reinterpret_cast<const V*>(b0 + idx); v[3] = *reinterpret_cast<const V*>(b1 + idx);
             v[4] = *reinterpret_cast<const V*>(h0 + idx); v[5] = *reinterpret_cast<const V*>(h1 + idx);
         };
         issue(0, in[0]);
+        issue(1, in[1]);
+        flush_stores();                       // previous item's results: behind this item's first loads
+        if (dbg_mask & 1024u) {
+#pragma unroll
+            for (int s = 0; s < EPT; ++s) { acc0[s] = 0; acc1[s] = 0; }
+        } else {
 #pragma unroll
         for (int s = 0; s < EPT / 4; ++s) {
-            if (s + 1 < EPT / 4) issue(s + 1, in[(s + 1) & 1]);
             const V(&v)[6] = in[s & 1];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -187,13 +234,15 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
                 const W t2 = csub(mont_mul_lazy(c2, v[5][e], q, qni), q);
                 acc1[s * 4 + e] = csub(t1 + t2, q);
             }
+            if (s + 2 < EPT / 4) issue(s + 2, in[s & 1]);     // refill the buffer just consumed
             __builtin_amdgcn_sched_barrier(0);   // at most two slices of loads live
+        }
         }
     }
     KS_STAMP(0);                                  // tensor part (c0, c1, diagonal digit)
     const int i_last = (j == L - 1) ? L - 2 : L - 1;
     for (int i = 0; i < L; ++i) {
-        if (i == j) continue;
+        if (i == j || (dbg_mask & 512u)) continue;
         const int32_t* d = digits + (((dbg_mask & 2u) ? (ct & 7) : ct) * (size_t)L + i) * n;   // dbg_mask: traffic experiments only
         // Nothing below depends on i except d and the hint rows; keep addresses and twiddles from being
         // hoisted out of the digit loop (that costs ~250 spilled VGPRs).
@@ -201,20 +250,31 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         const W* twm = R.twf[j];                        // Montgomery words (per-lane last pass)
         int tid = threadIdx.x;
         asm volatile("" : "+s"(twf), "+s"(twm), "+v"(tid));
-        __syncthreads();      // previous transform's last pass has finished reading LDS
+        KS_SYNC();      // previous transform's last pass has finished reading LDS
         KS_STAMP(1);                              // barrier before pass G
 
         // ---- global stages 0..2, HBM/L2 -> registers -> LDS
-        {
+        if (!(dbg_mask & 256u)) {
             const auto w1 = twf[1], w2 = twf[2 + hf], w3a = twf[4 + 2 * hf], w3b = twf[5 + 2 * hf];
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const int lo4 = (tid + T * g) * 4;                    // coefficients lo4..lo4+3 of each eighth
                 V u[4];
+#if ALCH_KS_SETPRIO
+                __builtin_amdgcn_s_setprio(3);
+#endif
+                SV zxs[4], zys[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    SV zx = *reinterpret_cast<const SV*>(d + k * (N / 8) + lo4);
-                    SV zy = *reinterpret_cast<const SV*>(d + (k + 4) * (N / 8) + lo4);
+                    zxs[k] = *reinterpret_cast<const SV*>(d + k * (N / 8) + lo4);
+                    zys[k] = *reinterpret_cast<const SV*>(d + (k + 4) * (N / 8) + lo4);
+                }
+#if ALCH_KS_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const SV zx = zxs[k], zy = zys[k];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         W xr, yr;
@@ -246,7 +306,7 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
             }
         }
         KS_STAMP(2);                              // pass G (global loads + stages 0..2 + LDS write)
-        __syncthreads();
+        KS_SYNC();
         KS_STAMP(3);                              // barrier after pass G
         if (i == i_last) prefetch_next(item + gridDim.x);
 
@@ -254,60 +314,55 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         const int ih = (dbg_mask & 8u) ? j : i;                         // traffic experiment: alias the hint rows
         const W* h0 = hj + (size_t)(2 * ih) * hstride;
         const W* h1 = hj + (size_t)(2 * ih + 1) * hstride;
-        auto epi = [&acc0, &acc1, h0, h1, q, qni](int g, int base, W* x) {
-#pragma unroll
-            for (int k = 0; k < 16; k += 4) {
-                V vh0 = *reinterpret_cast<const V*>(h0 + base + k), vh1 = *reinterpret_cast<const V*>(h1 + base + k);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc0[g * 16 + k + e] = csub(acc0[g * 16 + k + e] + csub(mont_mul_lazy(x[k + e], vh0[e], q, qni), q), q);
-                    acc1[g * 16 + k + e] = csub(acc1[g * 16 + k + e] + csub(mont_mul_lazy(x[k + e], vh1[e], q, qni), q), q);
-                }
-            }
-        };
         const int prefix = 2 + hf;
         NoEpilogue none;
         constexpr int NP = (LOGM - 2) / 4;
         if constexpr (NP == 1) {
-            ntt_pass<LOGM, LT, W, 2, 4, false, true, true>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, epi);
+            ntt_pass<LOGM, LT, W, 2, 4, false, false, true>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, none);
         } else if constexpr (NP == 2) {
             ntt_pass<LOGM, LT, W, 2, 4, false, false, ALCH_KS_SERIAL>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
-            __syncthreads();
-            ntt_pass<LOGM, LT, W, 6, 4, false, true, true>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, epi);
+            KS_SYNC();
+            ntt_pass<LOGM, LT, W, 6, 4, false, false, true>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, none);
         } else {
             static_assert(NP <= 3, "at most 3 LDS passes");
-            ntt_pass<LOGM, LT, W, 2, 4, false, false, ALCH_KS_SERIAL>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
+            if (!(dbg_mask & 16u)) ntt_pass<LOGM, LT, W, 2, 4, false, false, ALCH_KS_SERIAL>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
             KS_STAMP(4);                          // LDS pass 1
-            __syncthreads();
+            KS_SYNC();
             KS_STAMP(5);
-            ntt_pass<LOGM, LT, W, 6, 4, false, false, ALCH_KS_SERIAL>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
+            if (!(dbg_mask & 32u)) ntt_pass<LOGM, LT, W, 6, 4, false, false, ALCH_KS_SERIAL>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
             KS_STAMP(6);                          // LDS pass 2
-            __syncthreads();
+            KS_SYNC();
             KS_STAMP(7);
-            ntt_pass<LOGM, LT, W, 10, 4, false, true, true>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, epi);
-            KS_STAMP(8);                          // last pass + hint multiply-accumulate
+            if (!(dbg_mask & 64u)) ntt_pass<LOGM, LT, W, 10, 4, false, false, true>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, none);
         }
+        // hint multiply-accumulate, in the lane-contiguous slot layout: the transform result goes through LDS
+        // once more so that hint loads (and the tensor inputs / result stores, which share the layout) are
+        // fully coalesced 1 KiB wave accesses instead of 16-byte pieces at a 64-byte lane stride.
+        KS_SYNC();
+        if (!(dbg_mask & 128u))
+#pragma unroll
+        for (int r = 0; r < EPT / 4; ++r) {
+            const int idx = (tid + T * ((r + rot) & (EPT / 4 - 1))) * 4;
+            const V x = *reinterpret_cast<const V*>(&lds[swz<LOGM>(idx)]);
+            const V vh0 = *reinterpret_cast<const V*>(h0 + idx), vh1 = *reinterpret_cast<const V*>(h1 + idx);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0[r * 4 + e] = csub(acc0[r * 4 + e] + csub(mont_mul_lazy(x[e], vh0[e], q, qni), q), q);
+                acc1[r * 4 + e] = csub(acc1[r * 4 + e] + csub(mont_mul_lazy(x[e], vh1[e], q, qni), q), q);
+            }
+        }
+        KS_STAMP(8);                              // last pass + hint multiply-accumulate
     }
 
     KS_STAMP(9);
     const size_t cto = (dbg_mask & 4u) ? (ct & 7) : ct;                // traffic experiment: alias the outputs
     W* o0 = out + ((2 * cto) * (size_t)L + j) * n + slot0;
     W* o1 = out + ((2 * cto + 1) * (size_t)L + j) * n + slot0;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-#pragma unroll
-        for (int k = 0; k < 16; k += 4) {
-            const int idx = ((int)threadIdx.x + T * g) * 16 + k;
-            V v0, v1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v0[e] = acc0[g * 16 + k + e]; v1[e] = acc1[g * 16 + k + e]; }
-            *reinterpret_cast<V*>(o0 + idx) = v0;
-            *reinterpret_cast<V*>(o1 + idx) = v1;
-        }
-    }
+    if (!(dbg_mask & 2048u)) { po0 = o0; po1 = o1; prot = rot; }
     KS_STAMP(10);                                 // result stores issued
     KS_STAMP_FLUSH();
     }  // item loop: the next item touches LDS only after the barrier that opens its first pass G
+    flush_stores();
 }
 
 }  // namespace alch

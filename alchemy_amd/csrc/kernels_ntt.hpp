@@ -141,7 +141,9 @@ k_tensor_intt(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
         const W* b1 = b + ((2 * ct + 1) * (size_t)L + i) * (size_t)G::N;
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
-            const int idx = ((int)threadIdx.x + G::T * r) * VL;
+            // rotated start per item: lockstep workgroups must not all read the same offset of their
+            // 128 KiB-aligned rows at the same time (HBM channel conflicts)
+            const int idx = ((int)threadIdx.x + G::T * ((r + (int)(item ^ (item >> 3))) & (NV - 1))) * VL;
             pa[r] = *reinterpret_cast<const V*>(a1 + idx);
             pb[r] = *reinterpret_cast<const V*>(b1 + idx);
         }
@@ -158,7 +160,7 @@ k_tensor_intt(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
         asm volatile("" : "+v"(tid));          // keep LDS address arithmetic inside the item loop (VGPR pressure)
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
-            const int idx = (tid + G::T * r) * VL;
+            const int idx = (tid + G::T * ((r + (int)(item ^ (item >> 3))) & (NV - 1))) * VL;
             V v;
 #pragma unroll
             for (int e = 0; e < VL; ++e) {

@@ -114,6 +114,9 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const TW* __restri
         const int sb = swz<LOGN>(base);
         W x[R];
         // ---- load
+#ifdef ALCH_PASS_SETPRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
         if constexpr (LB == 0 && R >= VL) {
 #pragma unroll
             for (int k = 0; k < R; k += VL) {
@@ -125,6 +128,9 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const TW* __restri
 #pragma unroll
             for (int k = 0; k < R; ++k) x[k] = lds[sb ^ swz<LOGN>(k << LB)];
         }
+#ifdef ALCH_PASS_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // ---- butterflies
         const int gm = (prefix << S0) + h;
         if constexpr (!INVERSE) {
