@@ -21,9 +21,6 @@
 #ifndef ALCH_KS_GBARRIER
 #define ALCH_KS_GBARRIER 1
 #endif
-#ifndef ALCH_KS_SETPRIO
-#define ALCH_KS_SETPRIO 0
-#endif
 // timing experiment only (wrong results): drop every workgroup barrier of the kernel
 #ifdef ALCH_EXP_NOBARRIER
 #define KS_SYNC() ((void)0)
@@ -125,13 +122,6 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         hf_ = (int)(which & 1u);
         ct_ = (size_t)grp * 8u + (rem & 7u);
     };
-    // experiment: delay a subset of the workgroups by ~half an item so that the two workgroups of a CU stop
-    // running identical phases at identical times (dbg_mask bits 16..23 = bit of blockIdx that selects the subset + 1)
-    if (dbg_mask >> 16) {
-        const unsigned bit = ((dbg_mask >> 16) & 0xFF) - 1;
-        if ((blockIdx.x >> bit) & 1u)
-            for (int s = 0; s < 16; ++s) __builtin_amdgcn_s_sleep(127);
-    }
     // Results of an item are stored at the start of the NEXT item, right after that item's first two slices of
     // tensor-input loads have been issued: vmcnt retires in order, so stores issued first would have to drain
     // to HBM before the next item's loads could be consumed.  (Spreading the stores over all eight slices was
@@ -260,18 +250,12 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
             for (int g = 0; g < NG; ++g) {
                 const int lo4 = (tid + T * g) * 4;                    // coefficients lo4..lo4+3 of each eighth
                 V u[4];
-#if ALCH_KS_SETPRIO
-                __builtin_amdgcn_s_setprio(3);
-#endif
                 SV zxs[4], zys[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     zxs[k] = *reinterpret_cast<const SV*>(d + k * (N / 8) + lo4);
                     zys[k] = *reinterpret_cast<const SV*>(d + (k + 4) * (N / 8) + lo4);
                 }
-#if ALCH_KS_SETPRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const SV zx = zxs[k], zy = zys[k];

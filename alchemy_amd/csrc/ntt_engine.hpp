@@ -92,7 +92,10 @@ struct NoEpilogue {
 // transform has prefix 1.
 // TW is the twiddle table's word type: W for Montgomery twiddles, u64 for the Plantard constants the
 // forward transform of 32-bit rings uses (bfly_fwd overloads pick the arithmetic from it).
-template <int LOGN, int LOGT, typename W, int S0, int NS, bool INVERSE, bool KEEP, bool SERIAL, typename TW, typename Epi>
+// FOLD: an inverse pass that contains stage 0 folds n^-1 into it; a sub-transform (prefix != 1) whose local
+// stage 0 is not the transform's stage 0 passes FOLD = false.
+template <int LOGN, int LOGT, typename W, int S0, int NS, bool INVERSE, bool KEEP, bool SERIAL, typename TW, typename Epi,
+          bool FOLD = true>
 __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const TW* __restrict__ tw, W q, W qni,
                                          W ninv_m, W w1ninv_m, int t, int prefix, Epi&& epi) {
     typedef Geo<LOGN, LOGT> G;
@@ -114,9 +117,6 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const TW* __restri
         const int sb = swz<LOGN>(base);
         W x[R];
         // ---- load
-#ifdef ALCH_PASS_SETPRIO
-        __builtin_amdgcn_s_setprio(3);
-#endif
         if constexpr (LB == 0 && R >= VL) {
 #pragma unroll
             for (int k = 0; k < R; k += VL) {
@@ -128,9 +128,6 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const TW* __restri
 #pragma unroll
             for (int k = 0; k < R; ++k) x[k] = lds[sb ^ swz<LOGN>(k << LB)];
         }
-#ifdef ALCH_PASS_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         // ---- butterflies
         const int gm = (prefix << S0) + h;
         if constexpr (!INVERSE) {
@@ -168,7 +165,7 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const TW* __restri
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     if (k & half) continue;
-                    if (S0 == 0 && r == 0) {
+                    if (FOLD && S0 == 0 && r == 0) {
                         // last stage of crtInv (single twiddle tw[1]): fold in n^-1
                         W a = csub(x[k], q), b = csub(x[k + half], q);
                         x[k] = mont_mul_lazy((W)(a + b), ninv_m, q, qni);

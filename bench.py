@@ -112,13 +112,17 @@ def main():
         # per-GPU achieved algorithmic bandwidth from the HIP-event time of the K launches on the stream
         per_gpu_ops_s = B * args.steps / (ev_ms_max * 1e-3)
         achieved = per_gpu_ops_s * (ALGO_BYTES_PER_OP + HINT_BYTES / B) / 1e9
-        traffic = None
+        # physical HBM-side bytes per op from the committed PMC passes (profiles/traffic_latest.json: separate
+        # FETCH_SIZE and WRITE_SIZE runs of this script, gfx950 FETCH_SIZE correction applied), turned into
+        # a rate with this run's op rate so that it compares with `achieved`
+        traffic = traffic_per_op = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_op")
+                traffic_per_op = float(json.load(open(tpath))["hbm_bytes_per_op"])
+                traffic = per_gpu_ops_s * traffic_per_op / 1e9
             except Exception:
-                traffic = None
+                traffic = traffic_per_op = None
         line = {
             "metric": "ctxt-mul+relinearize/sec at n=2^15, 4 RNS limbs",
             "value": value, "unit": "ctxt-mul+relin/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -130,10 +134,12 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "sharding": f"dp{world} by ciphertext, no collective",
                        "moduli": CFG3_QS, "device_word_bytes": ring.word_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_bytes_per_op": traffic_per_op,
                          "note": "achieved = ops/s per GPU (HIP events over the timed launches) x 6,291,456 B "
                                  "algorithmic bytes per op at the reference's 8-byte word (SURVEY 8d); "
-                                 "traffic = PMC HBM bytes per op (profiles/), device words are 4 bytes"},
+                                 "traffic = physical GB/s = PMC (FETCH_SIZE x2 + WRITE_SIZE) bytes per op from profiles/traffic_latest.json x "
+                                 "this run's ops/s; the device stores 4-byte words and moves intermediates (digits, hint, "
+                                 "re-read operands) on top of the 3.1 MB it must move per op"},
             "hip_event_ms_per_step": ev_ms_max / args.steps,
             "out_checksum": f"{checksum:016x}",
         }
