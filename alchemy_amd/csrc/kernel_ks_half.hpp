@@ -25,7 +25,7 @@
 #ifdef ALCH_EXP_NOBARRIER
 #define KS_SYNC() ((void)0)
 #else
-#define KS_SYNC() __syncthreads()
+#define KS_SYNC() lds_barrier()
 #endif
 
 namespace alch {
@@ -108,10 +108,10 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W* lds = reinterpret_cast<W*>(smem);
     const int L = R.L;
-    W* sink = lds + M;                                     // 4*T words: landing zone of the input prefetch
     // Persistent workgroups: the grid is two workgroups per CU and each loops over work items
-    // (ciphertext, limb j, half), so there is no partial last wave of workgroups and a workgroup knows its next
-    // item early enough to prefetch that item's tensor inputs towards the caches.
+    // (ciphertext, limb j, half): no partial last wave of workgroups, and the result stores of one item can be
+    // issued behind the first loads of the next.  (An LDS-DMA prefetch of the next item's inputs towards L2 was
+    // tried and measured 1 % slower late in the item, 6 % slower early: it only adds traffic.)
     // Item numbering is XCD-aware (speed only): the 2L items of one ciphertext agree mod 8, and gridDim is a
     // multiple of 8, so they run on one XCD and its L2 serves the digits they all read.
     const unsigned per = 16u * (unsigned)L;
@@ -168,27 +168,6 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     const W* hj = hint + (size_t)j * n + slot0;                // + ((i*2 + c)*L)*n
     const size_t hstride = (size_t)L * n;
 
-    // One dword per 128-byte line of the next item's a0, a1, b0, b1 half-rows (thread t owns line t of each),
-    // fetched by LDS-DMA into `sink`: no VGPRs, nothing waits for it, and by the time the next item starts its
-    // tensor part the lines sit in L2 / Infinity Cache instead of HBM.  (Without it that part stalls on HBM:
-    // aliasing the inputs to cache-resident data was worth +11 % in a traffic experiment.)
-    auto prefetch_next = [&](unsigned nitem) {
-        if (nitem >= nitems) return;
-        int j2, hf2;
-        size_t ct2;
-        decode(nitem, j2, hf2, ct2);
-        if (ct2 >= nct) return;
-        if (EPT == 16 && threadIdx.x >= (unsigned)(M / 32)) return;     // one lane per 128-byte line
-        const size_t off = (size_t)hf2 * M + (size_t)threadIdx.x * 32;
-        const W* rows[4] = {a + ((2 * ct2) * (size_t)L + j2) * n + off, a + ((2 * ct2 + 1) * (size_t)L + j2) * n + off,
-                            b + ((2 * ct2) * (size_t)L + j2) * n + off, b + ((2 * ct2 + 1) * (size_t)L + j2) * n + off};
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)rows[x],
-                                             (__attribute__((address_space(3))) void*)(sink + x * (M / 32) + ((int)threadIdx.x & ~63)),
-                                             4, 0, 0);
-    };
-
     KS_STAMP_INIT();
     {   // c0, c1 and the diagonal digit (i == j): d_j = c2_j (mod q_j), no transform needed.
         // Eight 4-coefficient slices, software-pipelined: the six 16-byte loads of slice s+1 are in flight
@@ -230,7 +209,6 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         }
     }
     KS_STAMP(0);                                  // tensor part (c0, c1, diagonal digit)
-    const int i_last = (j == L - 1) ? L - 2 : L - 1;
     for (int i = 0; i < L; ++i) {
         if (i == j || (dbg_mask & 512u)) continue;
         const int32_t* d = digits + (((dbg_mask & 2u) ? (ct & 7) : ct) * (size_t)L + i) * n;   // dbg_mask: traffic experiments only
@@ -292,7 +270,6 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         KS_STAMP(2);                              // pass G (global loads + stages 0..2 + LDS write)
         KS_SYNC();
         KS_STAMP(3);                              // barrier after pass G
-        if (i == i_last) prefetch_next(item + gridDim.x);
 
         // ---- remaining stages: sub-transform of size n/2, local stages 2 .. LOGM-1
         const int ih = (dbg_mask & 8u) ? j : i;                         // traffic experiment: alias the hint rows

@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::T) k_crt(DevRing<W> R, W* __restric
     const W q = R.mod[j].q, qni = R.mod[j].qni;
 
     stage_in<LOGN, W>(lds, [&](int idx) { return *reinterpret_cast<const V*>(poly + idx); });
-    __syncthreads();
+    lds_barrier();
     if constexpr (!INVERSE) ntt_forward<LOGN, W, false>(lds, fwd_tw(R, j), R.twf[j], q, qni, (int)threadIdx.x, NoEpilogue());
     else ntt_inverse<LOGN, W, false>(lds, R.twi[j], q, qni, R.ninv_m[j], R.w1ninv_m[j], (int)threadIdx.x, NoEpilogue());
 #pragma unroll
@@ -169,7 +169,7 @@ k_tensor_intt(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
             }
             *reinterpret_cast<V*>(&lds[swz<LOGN>(idx)]) = v;
         }
-        __syncthreads();
+        lds_barrier();
         if (item + gridDim.x < nitems) issue(item + gridDim.x);
         SW* d = digits + (ct * (size_t)L + i) * (size_t)G::N;
         const W half = (q - 1) >> 1;
@@ -186,7 +186,7 @@ k_tensor_intt(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
                 if (!(dbg & 4u)) d[base + k * STRIDE] = z;
             }
         });
-        __syncthreads();                       // every lane has read its last-pass inputs before LDS is refilled
+        lds_barrier();                       // every lane has read its last-pass inputs before LDS is refilled
     }
 }
 
@@ -257,7 +257,7 @@ k_ks_accum(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
     for (int i = 0; i < L; ++i) {
         if (i == j) continue;
         const SW* d = digits + (ct * (size_t)L + i) * n;
-        __syncthreads();      // previous transform's last pass has finished reading LDS
+        lds_barrier();      // previous transform's last pass has finished reading LDS
         stage_in<LOGN, W>(lds, [&](int idx) {
             SV z = *reinterpret_cast<const SV*>(d + idx);
             V v;
@@ -268,7 +268,7 @@ k_ks_accum(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
             }
             return v;
         });
-        __syncthreads();
+        lds_barrier();
         const W* h0 = hj + (size_t)(2 * i) * hstride;
         const W* h1 = hj + (size_t)(2 * i + 1) * hstride;
         // Neither the twiddles nor the LDS addresses depend on i; unless both are made opaque here the
@@ -362,10 +362,10 @@ inline hipError_t run_call(const NttCall<W>& c) {
             static const unsigned dbg_mask = getenv("ALCH_EXP_FLAGS") ? (unsigned)strtoul(getenv("ALCH_EXP_FLAGS"), nullptr, 0) : 0u;   // 1 inputs, 2 digits, 4 outputs, 8 hints aliased (wrong results, timing only)
             const size_t groups = (c.nct + 7) / 8;
             const unsigned nitems = (unsigned)(groups * 16 * (size_t)R.L);
-            static const unsigned persist = getenv("ALCH_KS_GRID") ? (unsigned)atoi(getenv("ALCH_KS_GRID")) : 1024u;  // 4 per CU: 2 resident + 2 queued (measured best of 256/512/1024)
+            static const unsigned persist = getenv("ALCH_KS_GRID") ? (unsigned)atoi(getenv("ALCH_KS_GRID")) : 2048u;  // measured: 512 -> 438k, 1024 -> 447k, 2048..4096 -> 458k, one item per workgroup -> 453k op/s
             const unsigned grid = nitems < persist ? nitems : persist;
             constexpr int TH = 1 << (LOGN - 6);
-            const size_t half_lds = lds_bytes / 2 + 16 * (size_t)TH;      // + prefetch landing zone
+            const size_t half_lds = lds_bytes / 2;
             if (c.balanced) {
                 auto k = k_ks_accum_half<LOGN, true>;
                 if ((e = set_lds(k, half_lds)) != hipSuccess) return e;

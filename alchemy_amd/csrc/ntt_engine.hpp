@@ -46,6 +46,16 @@ template <typename W> struct Vec4;
 template <> struct Vec4<u32> { typedef u32 type __attribute__((ext_vector_type(4))); static constexpr int LANES = 4; };
 template <> struct Vec4<u64> { typedef u64 type __attribute__((ext_vector_type(2))); static constexpr int LANES = 2; };
 
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() is also a fence for global memory, so hipcc puts
+// `s_waitcnt vmcnt(0)` in front of it whenever vector-memory operations are outstanding -- which drains every
+// prefetch (register loads for the next work item, LDS-DMA touches) at the next pass boundary.  The transforms
+// exchange data through LDS only, so they wait for LDS traffic alone and let global loads stay in flight.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // ---- twiddles of one butterfly stage ---------------------------------------------------------------
 // Local stage r of a pass needs the CNT = 2^r consecutive table words tw[first .. first+CNT), first a
 // multiple of CNT: one vector load per four words instead of one dword load per butterfly.  When every
@@ -221,22 +231,22 @@ __device__ __forceinline__ void ntt_forward(W* lds, const TW* tw, const W* twm, 
         ntt_pass<LOGN, LT, W, 0, F, false, KEEP_LAST, SERIAL>(lds, twm, q, qni, (W)0, (W)0, tid, 1, epi);
     } else {
         ntt_pass<LOGN, LT, W, 0, F, false, false, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, 1, none);
-        __syncthreads();
+        lds_barrier();
         if constexpr (P == 2) {
             ntt_pass<LOGN, LT, W, F, 4, false, KEEP_LAST, SERIAL>(lds, twm, q, qni, (W)0, (W)0, tid, 1, epi);
         } else {
             ntt_pass<LOGN, LT, W, F, 4, false, false, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, 1, none);
-            __syncthreads();
+            lds_barrier();
             if constexpr (P == 3) {
                 ntt_pass<LOGN, LT, W, F + 4, 4, false, KEEP_LAST, SERIAL>(lds, twm, q, qni, (W)0, (W)0, tid, 1, epi);
             } else {
                 ntt_pass<LOGN, LT, W, F + 4, 4, false, false, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, 1, none);
-                __syncthreads();
+                lds_barrier();
                 ntt_pass<LOGN, LT, W, F + 8, 4, false, KEEP_LAST, SERIAL>(lds, twm, q, qni, (W)0, (W)0, tid, 1, epi);
             }
         }
     }
-    if constexpr (!KEEP_LAST) __syncthreads();
+    if constexpr (!KEEP_LAST) lds_barrier();
 }
 
 // crtInv: CRT slots in LDS -> coefficients, n^-1 applied.  With KEEP_LAST the final pass (stages [0, NS0),
@@ -248,11 +258,11 @@ __device__ __forceinline__ void ntt_inverse(W* lds, const W* twi, W q, W qni, W 
     typedef Geo<LOGN> G;
     constexpr int P = G::NPASS, F = G::NS0, LT = G::LOGT;
     NoEpilogue none;
-    if constexpr (P >= 4) { ntt_pass<LOGN, LT, W, F + 8, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, none); __syncthreads(); }
-    if constexpr (P >= 3) { ntt_pass<LOGN, LT, W, F + 4, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, none); __syncthreads(); }
-    if constexpr (P >= 2) { ntt_pass<LOGN, LT, W, F, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, none); __syncthreads(); }
+    if constexpr (P >= 4) { ntt_pass<LOGN, LT, W, F + 8, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, none); lds_barrier(); }
+    if constexpr (P >= 3) { ntt_pass<LOGN, LT, W, F + 4, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, none); lds_barrier(); }
+    if constexpr (P >= 2) { ntt_pass<LOGN, LT, W, F, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, none); lds_barrier(); }
     ntt_pass<LOGN, LT, W, 0, F, true, KEEP_LAST, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, epi);
-    if constexpr (!KEEP_LAST) __syncthreads();
+    if constexpr (!KEEP_LAST) lds_barrier();
 }
 
 }  // namespace alch
