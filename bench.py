@@ -53,13 +53,17 @@ def main():
     import torch
     from alchemy_amd import Ring, shard
 
-    rank, local_rank, world, dist = shard.init_distributed()
+    # ALCH_DIST_BACKEND=gloo + ALCH_FORCE_DEVICE=0 rehearse the multi-rank path on a one-GPU box (several ranks
+    # sharing cuda:0); the driver's real runs use nccl (= RCCL) with one rank per GPU.
+    rank, local_rank, world, dist = shard.init_distributed(os.environ.get("ALCH_DIST_BACKEND"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = int(os.environ.get("ALCH_FORCE_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    red_dev = None if os.environ.get("ALCH_DIST_BACKEND") == "gloo" else dev
 
     ring = Ring(2 << LOGN, CFG3_QS)
     B = args.batch
@@ -91,8 +95,8 @@ def main():
     shard.barrier(dist)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    wall_max = shard.max_over_ranks(wall, dist, dev)
-    ev_ms_max = shard.max_over_ranks(ev_ms, dist, dev)
+    wall_max = shard.max_over_ranks(wall, dist, red_dev)
+    ev_ms_max = shard.max_over_ranks(ev_ms, dist, red_dev)
     checksum = out.checksum(0, 2)
 
     pow_ops = None
