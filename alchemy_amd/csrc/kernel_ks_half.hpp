@@ -21,6 +21,9 @@
 #ifndef ALCH_KS_GBARRIER
 #define ALCH_KS_GBARRIER 1
 #endif
+#ifndef ALCH_KS_HINT_PREFETCH
+#define ALCH_KS_HINT_PREFETCH 1
+#endif
 // timing experiment only (wrong results): drop every workgroup barrier of the kernel
 #ifdef ALCH_EXP_NOBARRIER
 #define KS_SYNC() ((void)0)
@@ -299,18 +302,35 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         // hint multiply-accumulate, in the lane-contiguous slot layout: the transform result goes through LDS
         // once more so that hint loads (and the tensor inputs / result stores, which share the layout) are
         // fully coalesced 1 KiB wave accesses instead of 16-byte pieces at a 64-byte lane stride.
+        // The hint rows of the first two slices are requested before the barrier (LDS-only barriers let global
+        // loads stay in flight), the rest two slices ahead of their use.
+        V ph0[2], ph1[2];
+        auto hint_issue = [&](int r, V& a0v, V& a1v) {
+            const int idx = (tid + T * ((r + rot) & (EPT / 4 - 1))) * 4;
+            a0v = *reinterpret_cast<const V*>(h0 + idx);
+            a1v = *reinterpret_cast<const V*>(h1 + idx);
+        };
+#if ALCH_KS_HINT_PREFETCH
+        hint_issue(0, ph0[0], ph1[0]);
+        hint_issue(1, ph0[1], ph1[1]);
+#endif
         KS_SYNC();
+#if !ALCH_KS_HINT_PREFETCH
+        hint_issue(0, ph0[0], ph1[0]);
+        hint_issue(1, ph0[1], ph1[1]);
+#endif
         if (!(dbg_mask & 128u))
 #pragma unroll
         for (int r = 0; r < EPT / 4; ++r) {
             const int idx = (tid + T * ((r + rot) & (EPT / 4 - 1))) * 4;
             const V x = *reinterpret_cast<const V*>(&lds[swz<LOGM>(idx)]);
-            const V vh0 = *reinterpret_cast<const V*>(h0 + idx), vh1 = *reinterpret_cast<const V*>(h1 + idx);
+            const V vh0 = ph0[r & 1], vh1 = ph1[r & 1];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc0[r * 4 + e] = csub(acc0[r * 4 + e] + csub(mont_mul_lazy(x[e], vh0[e], q, qni), q), q);
                 acc1[r * 4 + e] = csub(acc1[r * 4 + e] + csub(mont_mul_lazy(x[e], vh1[e], q, qni), q), q);
             }
+            if (r + 2 < EPT / 4) hint_issue(r + 2, ph0[r & 1], ph1[r & 1]);
         }
         KS_STAMP(8);                              // last pass + hint multiply-accumulate
     }

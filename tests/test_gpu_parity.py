@@ -7,6 +7,9 @@ from conftest import ARITH_QS, CFG2_Q60, CFG3_QS
 
 pytestmark = pytest.mark.gpu
 
+# eight limbs, all = 1 mod 4096: balanced 31-bit primes and small unbalanced ones
+EIGHT_QS = [2147389441, 2147377153, 2147352577, 2147295233, 2147217409, 2147205121, 2147196929, 2147082241]
+EIGHT_SMALL_QS = [12289, 40961, 61441, 65537, 86017, 114689, 147457, 151553]
 # all = 1 mod 2^16, wildly different sizes
 UNBAL_QS = [2147352577, 65537, 786433]
 
@@ -94,6 +97,8 @@ def _mul_relin_case(oracle_lib, n, qs, batch, seed, s_pre=None, pow_basis=False)
     (15, CFG3_QS, 11),
     # unbalanced moduli (a digit of one limb exceeds another limb's modulus): general reduce path
     (11, UNBAL_QS, 3), (15, UNBAL_QS, 2), (8, [1073750017, 8392193], 2),
+    # limb-count extremes on the two-workgroup kernel: one limb (no digit transform at all) and the maximum of 8
+    (15, CFG3_QS[:1], 3), (11, CFG3_QS[:1], 9), (11, EIGHT_QS, 2), (11, EIGHT_SMALL_QS, 3),
 ])
 def test_ct_mul_relin_crt_basis(oracle_lib, logn, qs, batch):
     _mul_relin_case(oracle_lib, 1 << logn, qs, batch, seed=1000 + logn)
