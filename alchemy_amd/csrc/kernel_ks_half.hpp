@@ -21,8 +21,8 @@
 #ifndef ALCH_KS_GBARRIER
 #define ALCH_KS_GBARRIER 1
 #endif
-#ifndef ALCH_KS_HINT_PREFETCH
-#define ALCH_KS_HINT_PREFETCH 1
+#ifndef ALCH_KS_HINT_DEPTH
+#define ALCH_KS_HINT_DEPTH 6
 #endif
 // timing experiment only (wrong results): drop every workgroup barrier of the kernel
 #ifdef ALCH_EXP_NOBARRIER
@@ -302,35 +302,32 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         // hint multiply-accumulate, in the lane-contiguous slot layout: the transform result goes through LDS
         // once more so that hint loads (and the tensor inputs / result stores, which share the layout) are
         // fully coalesced 1 KiB wave accesses instead of 16-byte pieces at a 64-byte lane stride.
-        // The hint rows of the first two slices are requested before the barrier (LDS-only barriers let global
-        // loads stay in flight), the rest two slices ahead of their use.
-        V ph0[2], ph1[2];
+        // The hint rows of the first HD slices are requested before the barrier (LDS-only barriers let global loads
+        // stay in flight), the rest HD slices ahead of their use: the rows come from L2 / Infinity Cache, whose
+        // latency a shallower pipeline does not cover (measured: depth 2 -> 448k, 4 -> 463k, 6 -> 468k op/s).
+        // (Running the digit loads of pass G one group ahead the same way spilled ~150 VGPRs: -20 %.)
+        constexpr int HD = ALCH_KS_HINT_DEPTH;          // slices of hint rows in flight (2 x 16 B per lane each)
+        V ph0[HD], ph1[HD];
         auto hint_issue = [&](int r, V& a0v, V& a1v) {
             const int idx = (tid + T * ((r + rot) & (EPT / 4 - 1))) * 4;
             a0v = *reinterpret_cast<const V*>(h0 + idx);
             a1v = *reinterpret_cast<const V*>(h1 + idx);
         };
-#if ALCH_KS_HINT_PREFETCH
-        hint_issue(0, ph0[0], ph1[0]);
-        hint_issue(1, ph0[1], ph1[1]);
-#endif
+#pragma unroll
+        for (int r = 0; r < HD; ++r) hint_issue(r, ph0[r], ph1[r]);
         KS_SYNC();
-#if !ALCH_KS_HINT_PREFETCH
-        hint_issue(0, ph0[0], ph1[0]);
-        hint_issue(1, ph0[1], ph1[1]);
-#endif
         if (!(dbg_mask & 128u))
 #pragma unroll
         for (int r = 0; r < EPT / 4; ++r) {
             const int idx = (tid + T * ((r + rot) & (EPT / 4 - 1))) * 4;
             const V x = *reinterpret_cast<const V*>(&lds[swz<LOGM>(idx)]);
-            const V vh0 = ph0[r & 1], vh1 = ph1[r & 1];
+            const V vh0 = ph0[r % HD], vh1 = ph1[r % HD];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 acc0[r * 4 + e] = csub(acc0[r * 4 + e] + csub(mont_mul_lazy(x[e], vh0[e], q, qni), q), q);
                 acc1[r * 4 + e] = csub(acc1[r * 4 + e] + csub(mont_mul_lazy(x[e], vh1[e], q, qni), q), q);
             }
-            if (r + 2 < EPT / 4) hint_issue(r + 2, ph0[r & 1], ph1[r & 1]);
+            if (r + HD < EPT / 4) hint_issue(r + HD, ph0[r % HD], ph1[r % HD]);
         }
         KS_STAMP(8);                              // last pass + hint multiply-accumulate
     }
