@@ -21,6 +21,9 @@
 #ifndef ALCH_KS_GBARRIER
 #define ALCH_KS_GBARRIER 1
 #endif
+#ifndef ALCH_KS_INIT_DEPTH
+#define ALCH_KS_INIT_DEPTH 2
+#endif
 #ifndef ALCH_KS_HINT_DEPTH
 #define ALCH_KS_HINT_DEPTH 6
 #endif
@@ -178,7 +181,8 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         // times per workgroup: 20 % of the kernel in the phase stamps).
         const W* h0 = hj + (size_t)(2 * j) * hstride;
         const W* h1 = hj + (size_t)(2 * j + 1) * hstride;
-        V in[2][6];
+        constexpr int ID = ALCH_KS_INIT_DEPTH;         // slices of tensor inputs in flight (6 x 16 B per lane each)
+        V in[ID][6];
         auto issue = [&](int s, V (&v)[6]) {
             const int idx = ((int)threadIdx.x + T * ((s + rot) & (EPT / 4 - 1))) * 4;   // lane-contiguous 16-byte pieces
             v[0] = *reinterpret_cast<const V*>(a0 + idx); v[1] = *reinterpret_cast<const V*>(a1 + idx);
@@ -188,13 +192,16 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         issue(0, in[0]);
         issue(1, in[1]);
         flush_stores();                       // previous item's results: behind this item's first loads
+#pragma unroll
+        for (int s = 2; s < ID; ++s) issue(s, in[s]);
+        (void)0;
         if (dbg_mask & 1024u) {
 #pragma unroll
             for (int s = 0; s < EPT; ++s) { acc0[s] = 0; acc1[s] = 0; }
         } else {
 #pragma unroll
         for (int s = 0; s < EPT / 4; ++s) {
-            const V(&v)[6] = in[s & 1];
+            const V(&v)[6] = in[s % ID];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const W x0 = csub(mont_mul_lazy(v[0][e], sr2, q, qni), q);          // a0 s R
@@ -206,7 +213,7 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
                 const W t2 = csub(mont_mul_lazy(c2, v[5][e], q, qni), q);
                 acc1[s * 4 + e] = csub(t1 + t2, q);
             }
-            if (s + 2 < EPT / 4) issue(s + 2, in[s & 1]);     // refill the buffer just consumed
+            if (s + ID < EPT / 4) issue(s + ID, in[s % ID]);  // refill the buffer just consumed
             __builtin_amdgcn_sched_barrier(0);   // at most two slices of loads live
         }
         }
