@@ -117,6 +117,35 @@ __global__ void __launch_bounds__(Geo<LOGN>::T) k_crt(DevRing<W> R, W* __restric
     }
 }
 
+#ifndef ALCH_TI_STAMP_LANE
+#define ALCH_TI_STAMP_LANE 960
+#endif
+#ifdef ALCH_STAMPS
+__device__ unsigned long long g_ti_stamps[1024 * 16];
+#define TI_STAMP(ph)                                                                              \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long _t;                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        _ta[ph] += _t - _tp;                                                                      \
+        _tp = _t;                                                                                 \
+    } while (0)
+}  // namespace alch
+extern "C" __attribute__((visibility("default"), used)) int alch_debug_stamps_a(unsigned long long* out16) {
+    static unsigned long long host[1024 * 16];
+    if (hipDeviceSynchronize() != hipSuccess) return -6;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(alch::g_ti_stamps), sizeof host) != hipSuccess) return -6;
+    for (int p = 0; p < 16; ++p) { out16[p] = 0; for (int w = 0; w < 1024; ++w) out16[p] += host[w * 16 + p]; }
+    for (auto& v : host) v = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(alch::g_ti_stamps), host, sizeof host) != hipSuccess) return -6;
+    return 0;
+}
+namespace alch {
+#else
+#define TI_STAMP(ph) do {} while (0)
+#endif
+
 // ---- fused kernel A: tensor c2 + crtInv + centred lift ---------------------------------------------
 template <int LOGN, typename W>
 __global__ void __launch_bounds__(Geo<LOGN>::T)
@@ -148,6 +177,10 @@ k_tensor_intt(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
             pb[r] = *reinterpret_cast<const V*>(b1 + idx);
         }
     };
+#ifdef ALCH_STAMPS
+    unsigned long long _ta[8] = {0}, _tp;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_tp)::"memory");
+#endif
     unsigned item = blockIdx.x;
     if (item < nitems) issue(item);
     for (; item < nitems; item += gridDim.x) {
@@ -169,25 +202,48 @@ k_tensor_intt(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
             }
             *reinterpret_cast<V*>(&lds[swz<LOGN>(idx)]) = v;
         }
+        TI_STAMP(0);                            // loads + c2 + LDS write
         lds_barrier();
-        if (item + gridDim.x < nitems) issue(item + gridDim.x);
+        TI_STAMP(1);
         SW* d = digits + (ct * (size_t)L + i) * (size_t)G::N;
         const W half = (q - 1) >> 1;
         // The digit is stored straight from the last (strided) pass: 32 dword stores per lane, each wave store
         // 256 contiguous bytes.  Routing the result through LDS for 16-byte stores was measured 4 % slower.
         constexpr int RR = 1 << G::NS0;
         constexpr int STRIDE = G::N / RR;
-        if (!(dbg & 2u))
-        ntt_inverse<LOGN, W, true>(lds, R.twi[i], q, qni, R.ninv_m[i], R.w1ninv_m[i], tid, [&](int, int base, W* x) {
+        auto epi = [&](int, int base, W* x) {
 #pragma unroll
             for (int k = 0; k < RR; ++k) {
                 W v = csub(x[k], q);
                 SW z = v > half ? (SW)v - (SW)q : (SW)v;
                 if (!(dbg & 4u)) d[base + k * STRIDE] = z;
             }
-        });
+        };
+#ifdef ALCH_STAMPS
+        if constexpr (LOGN == 15) {            // ntt_inverse spelled out so that the passes can be stamped
+            NoEpilogue none;
+            const W* twi = R.twi[i];
+            ntt_pass<LOGN, G::LOGT, W, 11, 4, true, false, false>(lds, twi, q, qni, R.ninv_m[i], R.w1ninv_m[i], tid, 1, none);
+            TI_STAMP(2); lds_barrier(); TI_STAMP(3);
+            ntt_pass<LOGN, G::LOGT, W, 7, 4, true, false, false>(lds, twi, q, qni, R.ninv_m[i], R.w1ninv_m[i], tid, 1, none);
+            TI_STAMP(2); lds_barrier(); TI_STAMP(3);
+            if (item + gridDim.x < nitems) issue(item + gridDim.x);
+            ntt_pass<LOGN, G::LOGT, W, 3, 4, true, false, false>(lds, twi, q, qni, R.ninv_m[i], R.w1ninv_m[i], tid, 1, none);
+            TI_STAMP(2); lds_barrier(); TI_STAMP(3);
+            ntt_pass<LOGN, G::LOGT, W, 0, 3, true, true, false>(lds, twi, q, qni, R.ninv_m[i], R.w1ninv_m[i], tid, 1, epi);
+            TI_STAMP(4);
+        } else
+#endif
+        if (!(dbg & 2u))
+        ntt_inverse<LOGN, W, true>(lds, R.twi[i], q, qni, R.ninv_m[i], R.w1ninv_m[i], tid, epi,
+                                   [&]() { if (item + gridDim.x < nitems) issue(item + gridDim.x); });
         lds_barrier();                       // every lane has read its last-pass inputs before LDS is refilled
+        TI_STAMP(5);
     }
+#ifdef ALCH_STAMPS
+    if (threadIdx.x == ALCH_TI_STAMP_LANE)
+        for (int p = 0; p < 8; ++p) atomicAdd(&g_ti_stamps[(blockIdx.x & 1023) * 16 + p], _ta[p]);
+#endif
 }
 
 // ---- fused kernel B: digit transforms + key-switch inner product ------------------------------------
@@ -345,9 +401,10 @@ inline hipError_t run_call(const NttCall<W>& c) {
         if (per_cu > by_waves) per_cu = by_waves;
         if (per_cu > 8) per_cu = 8;
         if (per_cu < 1) per_cu = 1;
-        // ALCH_TI_GRID: 0 = one workgroup per item (default; measured 1-2 % faster than persisting), -1 = one
-        // resident set of persistent workgroups, n > 0 = n persistent workgroups
-        static const int ti_grid = getenv("ALCH_TI_GRID") ? atoi(getenv("ALCH_TI_GRID")) : 0;
+        // ALCH_TI_GRID: -1 = one resident set of persistent workgroups (default: kernel time -4 % once the next
+        // item's loads are issued behind the last vector-twiddle pass), 0 = one workgroup per item, n > 0 = n
+        // persistent workgroups
+        static const int ti_grid = getenv("ALCH_TI_GRID") ? atoi(getenv("ALCH_TI_GRID")) : -1;
         unsigned grid = nitems < 256u * per_cu ? nitems : 256u * per_cu;
         if (ti_grid == 0) grid = nitems;
         else if (ti_grid > 0 && (unsigned)ti_grid < nitems) grid = (unsigned)ti_grid;

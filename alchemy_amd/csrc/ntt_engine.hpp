@@ -252,15 +252,28 @@ __device__ __forceinline__ void ntt_forward(W* lds, const TW* tw, const W* twm, 
 // crtInv: CRT slots in LDS -> coefficients, n^-1 applied.  With KEEP_LAST the final pass (stages [0, NS0),
 // groups of R = 2^NS0 coefficients of stride n/R) hands each group to epi(g, base, x):
 // x[k] = coefficient base + k * (n/R), lazy in [0,2q).
-template <int LOGN, typename W, bool KEEP_LAST, bool SERIAL = false, typename Epi>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `hook()` runs once, right before the first pass whose twiddles are wave-uniform (scalar loads): from there on
+// the transform issues no vector-memory loads, so global loads started in the hook (a prefetch for the next
+// work item) are never waited for by this transform -- vmcnt retires in order, and a later twiddle load would
+// otherwise drag the whole prefetch's HBM latency into the pass.
+template <int LOGN, typename W, bool KEEP_LAST, bool SERIAL = false, typename Epi, typename Hook = NoHook>
 __device__ __forceinline__ void ntt_inverse(W* lds, const W* twi, W q, W qni, W ninv_m, W w1ninv_m, int tid,
-                                            Epi&& epi) {
+                                            Epi&& epi, Hook&& hook = NoHook()) {
     typedef Geo<LOGN> G;
     constexpr int P = G::NPASS, F = G::NS0, LT = G::LOGT;
     NoEpilogue none;
-    if constexpr (P >= 4) { ntt_pass<LOGN, LT, W, F + 8, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, none); lds_barrier(); }
-    if constexpr (P >= 3) { ntt_pass<LOGN, LT, W, F + 4, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, none); lds_barrier(); }
-    if constexpr (P >= 2) { ntt_pass<LOGN, LT, W, F, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, none); lds_barrier(); }
+    // pass over stages [S0, S0+4) has LB = LOGN - S0 - 4; uniform twiddles need LB >= 6 (and a full wave)
+    constexpr bool U3 = (LOGN - (F + 8) - 4 >= 6), U2 = (LOGN - (F + 4) - 4 >= 6), U1 = (LOGN - F - 4 >= 6);
+    bool hooked = false;
+    if constexpr (P >= 4) { if (U3 && !hooked) { hook(); hooked = true; }
+        ntt_pass<LOGN, LT, W, F + 8, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, none); lds_barrier(); }
+    if constexpr (P >= 3) { if (U2 && !hooked) { hook(); hooked = true; }
+        ntt_pass<LOGN, LT, W, F + 4, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, none); lds_barrier(); }
+    if constexpr (P >= 2) { if (U1 && !hooked) { hook(); hooked = true; }
+        ntt_pass<LOGN, LT, W, F, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, none); lds_barrier(); }
+    if (!hooked) hook();
     ntt_pass<LOGN, LT, W, 0, F, true, KEEP_LAST, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, epi);
     if constexpr (!KEEP_LAST) lds_barrier();
 }
