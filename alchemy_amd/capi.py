@@ -42,6 +42,29 @@ def lib_path() -> str:
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.  Two HIP runtimes in one process fight over the device
+    (whichever initialises second reports "no HIP device"), so when torch is installed but not imported yet its
+    runtime is loaded first: libalchemy_hip.so's libamdhip64.so.7 dependency then resolves to that same object,
+    and a later `import torch` reuses it.  Programs without torch (the C++ / Haskell hosts) use ROCm's runtime."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """Load the HIP library; raises (never falls back) when it has not been built."""
     global _lib
@@ -51,6 +74,7 @@ def load_library():
     if not os.path.exists(path):
         raise AlchemyError(ALCH_E_NO_DEVICE, f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)")
+    _share_hip_runtime_with_torch()
     l = C.CDLL(path)
     P64, PU64, VP = C.POINTER(C.c_int64), C.POINTER(C.c_uint64), C.c_void_p
     l.alch_last_error.restype = C.c_char_p
