@@ -24,7 +24,7 @@ SYMBOLS = [
     "alch_buf_elems", "alch_buf_upload", "alch_buf_download", "alch_buf_fill_uniform", "alch_buf_crt",
     "alch_buf_crtinv", "alch_buf_mul", "alch_buf_add", "alch_buf_checksum", "alch_hint_load", "alch_hint_from_buf",
     "alch_hint_free", "alch_ct_mul_relin", "alch_buf_rescale_drop0", "alch_buf_sub", "alch_buf_scale",
-    "alch_buf_decompose_triv", "alch_buf_rescale_add0",
+    "alch_buf_decompose_triv", "alch_buf_rescale_add0", "alch_decompose_base2",
 ]
 
 
@@ -94,6 +94,7 @@ def load_library():
         "alch_mulg_pow": [VP, P64], "alch_mulg_dec": [VP, P64], "alch_mulg_crt": [VP, P64],
         "alch_divg_pow": [VP, P64], "alch_divg_dec": [VP, P64], "alch_divg_crt": [VP, P64],
         "alch_decompose_triv": [VP, P64, P64],
+        "alch_decompose_base2": [VP, P64, P64, C.POINTER(C.c_int)],
         "alch_buf_alloc": [VP, C.c_size_t, C.POINTER(VP)],
         "alch_buf_free": [VP],
         "alch_buf_elems": [VP, C.POINTER(C.c_size_t)],
@@ -221,6 +222,14 @@ class Ring:
         out = np.zeros((self.L, self.n, self.L), dtype=np.int64)
         _check(self._l.alch_decompose_triv(self._h, _p64(c), _p64(out)))
         return [out[i] for i in range(self.L)]
+
+    def decompose_base2(self, c_pow):
+        c = np.ascontiguousarray(c_pow, dtype=np.int64)
+        nd = C.c_int()
+        _check(self._l.alch_decompose_base2(self._h, None, None, C.byref(nd)))
+        out = np.zeros((nd.value, self.n, self.L), dtype=np.int64)
+        _check(self._l.alch_decompose_base2(self._h, _p64(c), _p64(out), C.byref(nd)))
+        return [out[i] for i in range(nd.value)]
 
     # --- device-resident
     def alloc(self, n_elems: int) -> "Buf":

@@ -159,6 +159,37 @@ __global__ void k_decompose_triv(DevRing<W> R, const W* c, W* digits) {
     }
 }
 
+// BaseBGad 2 decompose + reduce of one Pow-basis element.  One thread per (source limb i, coefficient k) walks
+// the ceil(log2 q_i) digits (balanced remainder in {0,-1}, top digit absorbs the rest) and writes each one
+// reduced into every limb.  first_digit[i] = index of limb i's first digit, kd[i] = its digit count.
+template <typename W>
+__global__ void k_decompose_base2(DevRing<W> R, const W* c, W* digits, Scal<u32> first_digit, Scal<u32> kd) {
+    typedef typename Signed<W>::type SW;
+    const size_t n = (size_t)1 << R.logn;
+    const size_t L = (size_t)R.L;
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < L * n; w += (size_t)gridDim.x * blockDim.x) {
+        const size_t k = w % n, i = w / n;
+        const W qi = R.mod[i].q;
+        const W x = c[i * n + k];
+        SW v = x > ((qi - 1) >> 1) ? (SW)x - (SW)qi : (SW)x;
+        for (u32 t = 0; t < kd.v[i]; ++t) {
+            SW d;
+            if (t + 1 < kd.v[i]) {
+                d = v & 1 ? (SW)-1 : (SW)0;          // v mod 2 in {0,1}; remainder 1 is taken as -1 (2r >= b)
+                v = (v - d) / 2;
+            } else {
+                d = v;
+            }
+            W* out = digits + (size_t)(first_digit.v[i] + t) * L * n;
+            for (size_t j = 0; j < L; ++j) {
+                SW r = d % (SW)R.mod[j].q;
+                if (r < 0) r += (SW)R.mod[j].q;
+                out[j * n + k] = (W)r;
+            }
+        }
+    }
+}
+
 // Rescale (a,b) -> b: dst limb j-1 = q_0^-1 (src_j - reduce(lift src_0)).  q0inv_m[j] = q_0^-1 mod q_j (Montgomery).
 template <typename W>
 __global__ void k_rescale_drop0(DevRing<W> R, const W* src, W* dst, size_t elems, Scal<W> q0inv_m) {
@@ -677,6 +708,33 @@ extern "C" int alch_decompose_triv(alch_ring* r, const int64_t* c_pow, int64_t* 
     else hipLaunchKernelGGL((k_decompose_triv<u64>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d64, (const u64*)s.b->dptr, (u64*)dig);
     HIP_TRY(hipGetLastError());
     return alch_buf_download(s.b, 1, (size_t)r->L, digits);
+}
+
+extern "C" int alch_decompose_base2(alch_ring* r, const int64_t* c_pow, int64_t* digits, int* n_digits) {
+    if (!r) return fail(ALCH_E_INVALID, "null ring");
+    Scal<u32> first, kd;
+    int D = 0;
+    for (int j = 0; j < MAXL; ++j) { first.v[j] = 0; kd.v[j] = 0; }
+    for (int i = 0; i < r->L; ++i) {
+        int k = 0;
+        for (u64 v = 1; v < r->q[i]; v <<= 1) ++k;
+        first.v[i] = (u32)D;
+        kd.v[i] = (u32)k;
+        D += k;
+    }
+    if (n_digits) *n_digits = D;
+    if (!digits) return ALCH_OK;
+    if (!c_pow) return fail(ALCH_E_INVALID, "null argument");
+    ScratchBuf s;
+    int rc = alch_buf_alloc(r, 1 + (size_t)D, &s.b);
+    if (rc != ALCH_OK) return rc;
+    if ((rc = alch_buf_upload(s.b, 0, 1, c_pow)) != ALCH_OK) return rc;
+    char* dig = reinterpret_cast<char*>(s.b->dptr) + elem_bytes(r);
+    const size_t total = elem_words(r);
+    if (r->word == 4) hipLaunchKernelGGL((k_decompose_base2<u32>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d32, (const u32*)s.b->dptr, (u32*)dig, first, kd);
+    else hipLaunchKernelGGL((k_decompose_base2<u64>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d64, (const u64*)s.b->dptr, (u64*)dig, first, kd);
+    HIP_TRY(hipGetLastError());
+    return alch_buf_download(s.b, 1, (size_t)D, digits);
 }
 
 // ------------------------------------------------------------------------------------------------------

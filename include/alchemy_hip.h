@@ -58,7 +58,7 @@ typedef struct alch_hint alch_hint;
 
 /* gadgets (Crypto/Alchemy/Interpreter/PT2CT.hs:139-140) */
 #define ALCH_GAD_TRIV 0            /* TrivGad: one digit per limb, centred lift                 */
-#define ALCH_GAD_BASE2 1           /* BaseBGad 2 (host decompose only in this round)            */
+#define ALCH_GAD_BASE2 1           /* BaseBGad 2 (alch_decompose_base2; no fused key switch yet) */
 
 const char *alch_last_error(void);
 /* Library/ABI version: (major<<16)|minor. */
@@ -106,6 +106,10 @@ int alch_divg_crt(alch_ring *ring, int64_t *a);
  * keySwitchQuadCirc, Eval.hs:133): c in the Pow basis; digits = L consecutive ring elements (each
  * n*L int64, Pow basis), digit i = centred lift of limb i reduced into every limb. */
 int alch_decompose_triv(alch_ring *ring, const int64_t *c_pow, int64_t *digits);
+/* The same for BaseBGad 2 (PT2CT.hs:140): per limb i, ceil(log2 q_i) balanced binary digits of the centred lift,
+ * least significant first, the top digit absorbing the remainder; digits of limb 0 first.  *n_digits receives
+ * their number D = sum_i ceil(log2 q_i); `digits` must hold D ring elements (pass NULL to query D only). */
+int alch_decompose_base2(alch_ring *ring, const int64_t *c_pow, int64_t *digits, int *n_digits);
 
 /* ---- device-resident ring-element arrays --------------------------------------------------------
  * What a Haskell `ForeignPtr`-wrapped tensor would hold; upload/download do the AoS <-> limb-major

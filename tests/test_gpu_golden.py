@@ -39,6 +39,9 @@ def test_golden_decompose_and_rescale():
         g = _ring(n, qs)
         c = to_aos(case["c"])
         assert [from_aos(d) for d in g.decompose_triv(c)] == case["triv_reduced"]
+        b2 = g.decompose_base2(c)
+        assert len(b2) == case["base2_count"]
+        assert [from_aos(d) for d in b2] == case["base2_reduced"]          # BaseBGad 2
         # device-resident decompose
         src, dst = g.upload(c[None]), g.alloc(len(qs))
         src.decompose_triv_into(0, dst, 0)
