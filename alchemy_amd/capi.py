@@ -24,7 +24,7 @@ SYMBOLS = [
     "alch_buf_elems", "alch_buf_upload", "alch_buf_download", "alch_buf_fill_uniform", "alch_buf_crt",
     "alch_buf_crtinv", "alch_buf_mul", "alch_buf_add", "alch_buf_checksum", "alch_hint_load", "alch_hint_from_buf",
     "alch_hint_free", "alch_ct_mul_relin", "alch_buf_rescale_drop0", "alch_buf_sub", "alch_buf_scale",
-    "alch_buf_decompose_triv", "alch_buf_rescale_add0", "alch_decompose_base2",
+    "alch_buf_decompose_triv", "alch_buf_rescale_add0", "alch_decompose_base2", "alch_ct_mul_full",
 ]
 
 
@@ -110,6 +110,7 @@ def load_library():
         "alch_hint_from_buf": [VP, C.c_int, VP, C.POINTER(VP)],
         "alch_hint_free": [VP],
         "alch_ct_mul_relin": [VP, VP, VP, VP, VP, C.c_size_t, PU64, C.c_uint],
+        "alch_ct_mul_full": [VP, VP, VP, VP, C.c_size_t, PU64, C.c_uint],
         "alch_buf_rescale_drop0": [VP, VP, C.c_size_t],
         "alch_buf_rescale_add0": [VP, VP, C.c_size_t],
         "alch_buf_sub": [VP, VP, VP, C.c_size_t],
@@ -257,6 +258,12 @@ class Ring:
     def ct_mul_relin(self, hint: "Hint", a: "Buf", b: "Buf", out: "Buf", batch: int, s_pre=None, flags: int = 0):
         sp = _pu64(s_pre) if s_pre is not None else None
         _check(self._l.alch_ct_mul_relin(self._h, hint._h, a._h, b._h, out._h, batch, sp, flags))
+
+
+def ct_mul_full(hint: "Hint", a: "Buf", b: "Buf", out: "Buf", batch: int, s_pre=None, flags: int = 0):
+    """PT2CT's whole mul_: modSwitch . keySwitchQuadCirc hint . modSwitch $ a * b (rings come from the handles)."""
+    sp = _pu64(s_pre) if s_pre is not None else None
+    _check(load_library().alch_ct_mul_full(hint._h, a._h, b._h, out._h, batch, sp, flags))
 
 
 class Buf:

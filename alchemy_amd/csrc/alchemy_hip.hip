@@ -41,6 +41,9 @@ struct alch_ring {
     size_t ws_host_bytes = 0;
     u64* ws_sum = nullptr;                     // checksum accumulator
     size_t chunk = 1024;                       // ciphertexts per (tensor_intt, ks_accum) launch pair
+    void* ws_full = nullptr;                   // ct_mul_full scratch: per pipeline digits + key-switched chunk + stash
+    size_t ws_full_bytes = 0;
+    hipEvent_t ev_x = nullptr;                 // cross-ring ordering (ct_mul_full)
 };
 
 struct alch_buf {
@@ -370,6 +373,8 @@ extern "C" int alch_ring_destroy(alch_ring* r) {
     if (r->tables_p) (void)hipFree(r->tables_p);
     if (r->ws_digits) (void)hipFree(r->ws_digits);
     if (r->ws_in) (void)hipFree(r->ws_in);
+    if (r->ws_full) (void)hipFree(r->ws_full);
+    if (r->ev_x) (void)hipEventDestroy(r->ev_x);
     if (r->ws_host) (void)hipFree(r->ws_host);
     if (r->ws_sum) (void)hipFree(r->ws_sum);
     if (r->ev0) (void)hipEventDestroy(r->ev0);
@@ -890,6 +895,134 @@ extern "C" int alch_ct_mul_relin(alch_ring* r, const alch_hint* hint, const alch
                       : do_mul_relin<u64>(r, hint, pa, pb, out->dptr, batch, s_pre);
     if (rc != ALCH_OK) return rc;
     if (flags & ALCH_POW_OUT) return buf_crt(out, 0, 2 * batch, true);
+    return ALCH_OK;
+}
+
+// ---- the complete mul_: (*) . modSwitch up . keySwitchQuadCirc . modSwitch down -------------------------------
+template <typename W>
+static int do_mul_full(alch_ring* rh, alch_ring* rin, alch_ring* rout, const alch_hint* hint, const void* a, const void* b,
+                       void* out, size_t batch, const uint64_t* s_pre, bool pow_out) {
+    typedef typename Signed<W>::type SW;
+    const int dup = rh->L - rin->L, ddn = rh->L - rout->L;
+    const size_t n = rh->n;
+    // per pipeline: digits [chunk][L_in][n] signed | key-switched chunk [chunk][2][Lh][n] | stash [slots][ddn][n] signed
+    const size_t chunk = std::min(rh->chunk, (batch + 7) / 8 * 8);
+    const unsigned slots = 512;
+    const size_t dig_bytes = chunk * (size_t)rin->L * n * sizeof(SW);
+    const size_t ks_bytes = chunk * 2 * (size_t)rh->L * n * sizeof(W);
+    const size_t stash_bytes = (size_t)slots * (size_t)ddn * n * sizeof(SW);
+    const size_t pipe_bytes = dig_bytes + ks_bytes + stash_bytes;
+    int rc = ensure_ws(&rh->ws_full, &rh->ws_full_bytes, 2 * pipe_bytes);
+    if (rc != ALCH_OK) return rc;
+
+    // s_pre times the moduli the first modSwitch adds
+    uint64_t s_eff[MAXL];
+    for (int j = 0; j < rin->L; ++j) {
+        u64 v = s_pre ? s_pre[j] % rin->q[j] : 1;
+        for (int u = 0; u < dup; ++u) v = h_mulmod(v, rh->q[u] % rin->q[j], rin->q[j]);
+        s_eff[j] = v;
+    }
+    NttCall<W> c{};
+    c.hint = reinterpret_cast<const W*>(hint->dptr);
+    c.balanced = rh->balanced;
+    scal_to_mont<W>(rin, s_eff, 2, c.spre_r2);
+    c.drop.ddn = ddn;
+    c.drop.balanced = 1;
+    const int bits = 8 * (int)sizeof(W);
+    for (int u = 0; u < ddn; ++u)
+        for (int t = 0; t < rh->L; ++t) {
+            c.drop.qinv_m[u][t] = 0;
+            if (t <= u) continue;
+            const u64 qt = rh->q[t], qu = rh->q[u];
+            if ((qu - 1) / 2 >= qt) c.drop.balanced = 0;
+            const u64 inv = h_powmod(qu % qt, qt - 2, qt);
+            c.drop.qinv_m[u][t] = (W)h_mulmod(inv, h_powmod(2, (u64)bits, qt), qt);
+        }
+    c.stash_slots = slots;
+    c.pow_out = pow_out;
+
+    static const bool one_stream = getenv("ALCH_ONE_STREAM") != nullptr;
+    const bool two = batch > chunk && !one_stream;
+    if (two) {
+        HIP_TRY(hipEventRecord(rh->ev_fork, rh->stream));
+        HIP_TRY(hipStreamWaitEvent(rh->aux, rh->ev_fork, 0));
+    }
+    const size_t in_words = 2 * (size_t)rin->L * n, out_words = 2 * (size_t)rout->L * n;
+    size_t idx = 0;
+    for (size_t done = 0; done < batch; done += chunk, ++idx) {
+        const size_t now = std::min(chunk, batch - done);
+        const bool odd = two && (idx & 1);
+        char* base = reinterpret_cast<char*>(rh->ws_full) + (odd ? pipe_bytes : 0);
+        c.stream = odd ? rh->aux : rh->stream;
+        c.nct = now;
+        // (*) 's quadratic coefficient, scaled, crtInv, TrivGad digits -- on the operands' ring
+        c.op = OP_TENSOR_INTT;
+        c.ring = &dev_ring<W>(rin);
+        c.a = reinterpret_cast<const W*>(a) + done * in_words;
+        c.b = reinterpret_cast<const W*>(b) + done * in_words;
+        c.digits = base;
+        hipError_t e = dispatch(rh->logn, c);
+        if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("tensor_intt launch: ") + hipGetErrorString(e));
+        // key switch on the hint's ring
+        c.op = OP_KS_ACCUM;
+        c.ring = &dev_ring<W>(rh);
+        c.dup = dup;
+        c.out = reinterpret_cast<W*>(base + dig_bytes);
+        e = dispatch(rh->logn, c);
+        if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("ks_accum launch: ") + hipGetErrorString(e));
+        // modSwitch down
+        c.op = OP_RESCALE_OUT;
+        c.a = reinterpret_cast<const W*>(base + dig_bytes);
+        c.out = reinterpret_cast<W*>(out) + done * out_words;
+        c.stash = base + dig_bytes + ks_bytes;
+        e = dispatch(rh->logn, c);
+        if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("rescale_out launch: ") + hipGetErrorString(e));
+    }
+    if (two) {
+        HIP_TRY(hipEventRecord(rh->ev_join, rh->aux));
+        HIP_TRY(hipStreamWaitEvent(rh->stream, rh->ev_join, 0));
+    }
+    return ALCH_OK;
+}
+
+static bool is_suffix_ring(const alch_ring* small, const alch_ring* big) {
+    if (small->m != big->m || small->word != big->word || small->L >= big->L) return false;
+    for (int j = 0; j < small->L; ++j)
+        if (small->q[j] != big->q[big->L - small->L + j]) return false;
+    return true;
+}
+
+extern "C" int alch_ct_mul_full(const alch_hint* hint, const alch_buf* a, const alch_buf* b, alch_buf* out, size_t batch,
+                                const uint64_t* s_pre, unsigned flags) {
+    if (!hint || !a || !b || !out) return fail(ALCH_E_INVALID, "null argument");
+    alch_ring* rh = hint->ring;
+    alch_ring* rin = a->ring;
+    alch_ring* rout = out->ring;
+    if (b->ring != rin) return fail(ALCH_E_INVALID, "operands belong to different rings");
+    if (hint->gadget != ALCH_GAD_TRIV) return fail(ALCH_E_UNSUPPORTED, "only TrivGad hints");
+    if (!is_suffix_ring(rin, rh)) return fail(ALCH_E_INVALID, "operand moduli must be the last limbs of the hint's ring (same word size)");
+    if (!is_suffix_ring(rout, rh)) return fail(ALCH_E_INVALID, "output moduli must be the last limbs of the hint's ring (same word size)");
+    if (rh->L - rout->L > MAXDROP) return fail(ALCH_E_UNSUPPORTED, "at most 3 limbs dropped per call");
+    if (flags & ~(unsigned)ALCH_POW_OUT) return fail(ALCH_E_UNSUPPORTED, "only ALCH_POW_OUT is accepted");
+    if (batch == 0) return ALCH_OK;
+    if (a->n_elems < 2 * batch || b->n_elems < 2 * batch || out->n_elems < 2 * batch)
+        return fail(ALCH_E_INVALID, "buffers must hold 2*batch ring elements");
+    if (!rh->ev_x) HIP_TRY(hipEventCreateWithFlags(&rh->ev_x, hipEventDisableTiming));
+    if (rin->stream != rh->stream) {
+        HIP_TRY(hipEventRecord(rh->ev_x, rin->stream));
+        HIP_TRY(hipStreamWaitEvent(rh->stream, rh->ev_x, 0));
+    }
+    if (rout->stream != rh->stream && rout->stream != rin->stream) {
+        HIP_TRY(hipEventRecord(rh->ev_x, rout->stream));
+        HIP_TRY(hipStreamWaitEvent(rh->stream, rh->ev_x, 0));
+    }
+    const bool pow_out = (flags & ALCH_POW_OUT) != 0;
+    int rc = rh->word == 4 ? do_mul_full<u32>(rh, rin, rout, hint, a->dptr, b->dptr, out->dptr, batch, s_pre, pow_out)
+                           : do_mul_full<u64>(rh, rin, rout, hint, a->dptr, b->dptr, out->dptr, batch, s_pre, pow_out);
+    if (rc != ALCH_OK) return rc;
+    HIP_TRY(hipEventRecord(rh->ev_x, rh->stream));
+    if (rin->stream != rh->stream) HIP_TRY(hipStreamWaitEvent(rin->stream, rh->ev_x, 0));
+    if (rout->stream != rh->stream) HIP_TRY(hipStreamWaitEvent(rout->stream, rh->ev_x, 0));
     return ALCH_OK;
 }
 

@@ -98,11 +98,17 @@ __device__ __forceinline__ u32 mont_red_lazy(u64 p, u32 q, u32 qni) {       // p
 // EPT = coefficients (and accumulator pairs) per thread: 32 -> n/64 threads, <= 128 VGPRs, 4 waves per SIMD.
 // EPT = 16 (n/32 threads, <= 64 VGPRs, 8 waves per SIMD) builds and is bit-exact, but spills 61 VGPRs and ran
 // 30 % SLOWER on MI355X (294 k vs 418 k op/s), so it is not dispatched.
-template <int LOGN, bool BALANCED, int EPT = 32>
+//
+// UP (the full PT2CT mul_, PT2CT.hs:177): the operands live `dup` limbs below the hint's ring -- R is the hint's
+// ring with L limbs, a/b/digits belong to its last L - dup limbs.  modSwitch up puts 0 into the added limbs
+// and q_added * x into the others (a scalar, folded into spre by the host), so an added limb j < dup starts
+// from c0 = c1 = 0, has no diagonal digit and transforms all L - dup digits; hint row of source digit i is
+// i + dup (the digits of the added limbs are zero and are skipped).
+template <int LOGN, bool BALANCED, int EPT = 32, bool UP = false>
 __global__ void __launch_bounds__((1 << (LOGN - 1)) / EPT, EPT == 32 ? 4 : 8)
 k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict__ b,
                 const int32_t* __restrict__ digits, const u32* __restrict__ hint, u32* __restrict__ out,
-                unsigned nct, unsigned nitems, Scal<u32> spre, unsigned dbg_mask) {
+                unsigned nct, unsigned nitems, Scal<u32> spre, unsigned dbg_mask, int dup_) {
     typedef u32 W;
     constexpr int LOGM = LOGN - 1, M = 1 << LOGM, N = 1 << LOGN, LT = (EPT == 32) ? LOGN - 6 : LOGN - 5, T = 1 << LT;
     typedef Geo<LOGM, LT> G;
@@ -114,6 +120,8 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W* lds = reinterpret_cast<W*>(smem);
     const int L = R.L;
+    const int dup = UP ? dup_ : 0;
+    const int Ls = L - dup;                         // limbs of the operands and number of digits
     // Persistent workgroups: the grid is two workgroups per CU and each loops over work items
     // (ciphertext, limb j, half): no partial last wave of workgroups, and the result stores of one item can be
     // issued behind the first loads of the next.  (An LDS-DMA prefetch of the next item's inputs towards L2 was
@@ -163,19 +171,25 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
 
     const ModP<W> m = R.mod[j];
     const W q = m.q, qni = m.qni;
-    const W sr2 = spre.v[j];
+    const int js = j - dup;                         // this limb in the operands' ring; < 0: added by modSwitch
+    const W sr2 = spre.v[js < 0 ? 0 : js];
     const size_t n = (size_t)N;
     const size_t slot0 = (size_t)hf * M;
     const size_t cti = (dbg_mask & 1u) ? (ct & 7) : ct;                // traffic experiment: alias the inputs
-    const W* a0 = a + ((2 * cti) * (size_t)L + j) * n + slot0;
-    const W* a1 = a + ((2 * cti + 1) * (size_t)L + j) * n + slot0;
-    const W* b0 = b + ((2 * cti) * (size_t)L + j) * n + slot0;
-    const W* b1 = b + ((2 * cti + 1) * (size_t)L + j) * n + slot0;
+    const size_t jsz = (size_t)(js < 0 ? 0 : js);
+    const W* a0 = a + ((2 * cti) * (size_t)Ls + jsz) * n + slot0;
+    const W* a1 = a + ((2 * cti + 1) * (size_t)Ls + jsz) * n + slot0;
+    const W* b0 = b + ((2 * cti) * (size_t)Ls + jsz) * n + slot0;
+    const W* b1 = b + ((2 * cti + 1) * (size_t)Ls + jsz) * n + slot0;
     const W* hj = hint + (size_t)j * n + slot0;                // + ((i*2 + c)*L)*n
     const size_t hstride = (size_t)L * n;
 
     KS_STAMP_INIT();
-    {   // c0, c1 and the diagonal digit (i == j): d_j = c2_j (mod q_j), no transform needed.
+    if (UP && js < 0) {
+        flush_stores();
+#pragma unroll
+        for (int s = 0; s < EPT; ++s) { acc0[s] = 0; acc1[s] = 0; }
+    } else {   // c0, c1 and the diagonal digit (i == j): d_j = c2_j (mod q_j), no transform needed.
         // Eight 4-coefficient slices, software-pipelined: the six 16-byte loads of slice s+1 are in flight
         // while slice s is multiplied out (issuing them one slice at a time exposed the HBM latency eight
         // times per workgroup: 20 % of the kernel in the phase stamps).
@@ -219,9 +233,9 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         }
     }
     KS_STAMP(0);                                  // tensor part (c0, c1, diagonal digit)
-    for (int i = 0; i < L; ++i) {
-        if (i == j || (dbg_mask & 512u)) continue;
-        const int32_t* d = digits + (((dbg_mask & 2u) ? (ct & 7) : ct) * (size_t)L + i) * n;   // dbg_mask: traffic experiments only
+    for (int i = 0; i < Ls; ++i) {
+        if (i == js || (dbg_mask & 512u)) continue;
+        const int32_t* d = digits + (((dbg_mask & 2u) ? (ct & 7) : ct) * (size_t)Ls + i) * n;   // dbg_mask: traffic experiments only
         // Nothing below depends on i except d and the hint rows; keep addresses and twiddles from being
         // hoisted out of the digit loop (that costs ~250 spilled VGPRs).
         auto twf = fwd_tw(R, j);                        // Plantard constants (shared-twiddle passes)
@@ -282,7 +296,7 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         KS_STAMP(3);                              // barrier after pass G
 
         // ---- remaining stages: sub-transform of size n/2, local stages 2 .. LOGM-1
-        const int ih = (dbg_mask & 8u) ? j : i;                         // traffic experiment: alias the hint rows
+        const int ih = (dbg_mask & 8u) ? j : i + dup;                         // traffic experiment: alias the hint rows
         const W* h0 = hj + (size_t)(2 * ih) * hstride;
         const W* h1 = hj + (size_t)(2 * ih + 1) * hstride;
         const int prefix = 2 + hf;

@@ -1,0 +1,96 @@
+// k_rescale_out: the modSwitch that closes PT2CT's mul_ (PT2CT.hs:177, Eval.hs:130), fused with the transforms
+// it forces.
+//
+// Input: a key-switched ciphertext component on the hint's ring (L limbs, CRT basis).  `Rescale (a,b) -> b`
+// works coefficient-wise in the Pow (= Dec, two-power index) basis, one dropped limb at a time, outermost first:
+//     y_t = (x_t - reduce(lift x_0)) * q_0^-1  (t = 1..L-1),   z_t = (y_t - reduce(lift y_1)) * q_1^-1  (t = 2..), ...
+// One workgroup owns one (ciphertext, component) and walks its limbs in order, each limb-polynomial whole in LDS:
+//   crtInv -> (last pass, values in registers) apply the drops of all earlier dropped limbs ->
+//     dropped limb : keep the centred lift for the later limbs,
+//     kept limb    : crt again in place and store (or store the Pow-basis value when the caller asked for it).
+// The last inverse pass gives every lane the same coefficient indices for every limb, so the lifted residues of
+// the dropped limbs are a per-lane private stash: written and read back by the same lane (global scratch,
+// `ddn * n` signed words per resident workgroup, L2-resident), no cross-lane ordering needed.
+// Cost per component: L crtInv + (L - ddn) crt, one read of L and one write of L - ddn limb-polynomials.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ntt_engine.hpp"
+
+namespace alch {
+
+template <int LOGN, typename W>
+__global__ void __launch_bounds__(Geo<LOGN>::T)
+k_rescale_out(DevRing<W> R, const W* __restrict__ src, W* __restrict__ out, typename Signed<W>::type* stash,
+              unsigned nitems, DropTab<W> D, int pow_out) {
+    typedef Geo<LOGN> G;
+    typedef typename Vec4<W>::type V;
+    typedef typename Signed<W>::type SW;
+    constexpr int VL = Vec4<W>::LANES;
+    constexpr int RR = 1 << G::NS0;                 // coefficients per group of the last inverse pass
+    constexpr int STRIDE = G::N / RR;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W* lds = reinterpret_cast<W*>(smem);
+    const int L = R.L, ddn = D.ddn, Lo = L - ddn;
+    SW* st = stash + (size_t)blockIdx.x * (size_t)ddn * G::N;
+
+    for (unsigned item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const W* x = src + (size_t)item * (size_t)L * G::N;          // item = 2*ct + component
+        W* o = out + (size_t)item * (size_t)Lo * G::N;
+        for (int t = 0; t < L; ++t) {
+            const ModP<W> m = R.mod[t];
+            const W q = m.q, qni = m.qni;
+            const W half = (q - 1) >> 1;
+            const W* poly = x + (size_t)t * G::N;
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));       // keep each limb's address arithmetic inside the loop (VGPR pressure)
+            lds_barrier();                      // the previous limb's last pass / stores have finished with LDS
+            stage_in<LOGN, W>(lds, [&](int idx) { return *reinterpret_cast<const V*>(poly + idx); });
+            lds_barrier();
+            const int nd = t < ddn ? t : ddn;   // drops that apply to this limb
+            W* ot = o + (size_t)(t - ddn) * G::N;
+            auto epi = [&](int, int base, W* v) {
+#pragma unroll
+                for (int k = 0; k < RR; ++k) v[k] = csub(v[k], q);
+                for (int u = 0; u < nd; ++u) {
+                    const W qim = D.qinv_m[u][t];
+                    SW z[RR];
+#pragma unroll
+                    for (int k = 0; k < RR; ++k) z[k] = st[(size_t)u * G::N + base + k * STRIDE];
+#pragma unroll
+                    for (int k = 0; k < RR; ++k) {
+                        W r;
+                        if (D.balanced) r = z[k] < 0 ? (W)z[k] + q : (W)z[k];
+                        else { SW rr = z[k] % (SW)q; r = rr < 0 ? (W)(rr + (SW)q) : (W)rr; }
+                        v[k] = csub(mont_mul_lazy((W)(v[k] - r + q), qim, q, qni), q);
+                    }
+                }
+                if (t < ddn) {
+#pragma unroll
+                    for (int k = 0; k < RR; ++k)
+                        st[(size_t)t * G::N + base + k * STRIDE] = v[k] > half ? (SW)v[k] - (SW)q : (SW)v[k];
+                } else if (pow_out) {
+#pragma unroll
+                    for (int k = 0; k < RR; ++k) ot[base + k * STRIDE] = v[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < RR; ++k) lds[swz<LOGN>(base + k * STRIDE)] = v[k];   // the words this lane just read
+                }
+            };
+            ntt_inverse<LOGN, W, true>(lds, R.twi[t], q, qni, R.ninv_m[t], R.w1ninv_m[t], tid, epi);
+            if (t >= ddn && !pow_out) {
+                lds_barrier();
+                ntt_forward<LOGN, W, false>(lds, fwd_tw(R, t), R.twf[t], q, qni, tid, NoEpilogue());
+#pragma unroll
+                for (int r = 0; r < G::E / VL; ++r) {
+                    const int idx = (tid + G::T * r) * VL;
+                    V v = *reinterpret_cast<const V*>(&lds[swz<LOGN>(idx)]);
+#pragma unroll
+                    for (int e = 0; e < VL; ++e) v[e] = csub(v[e], q);
+                    *reinterpret_cast<V*>(ot + idx) = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace alch

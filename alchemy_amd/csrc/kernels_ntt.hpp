@@ -55,7 +55,15 @@ template <> struct Signed<u64> { typedef int64_t type; };
 #include "kernel_ks_half.hpp"
 namespace alch {
 
-enum OpKind { OP_CRT = 0, OP_CRTINV = 1, OP_TENSOR_INTT = 2, OP_KS_ACCUM = 3 };
+enum OpKind { OP_CRT = 0, OP_CRTINV = 1, OP_TENSOR_INTT = 2, OP_KS_ACCUM = 3, OP_RESCALE_OUT = 4 };
+
+constexpr int MAXDROP = 3;
+template <typename W>
+struct DropTab {
+    int ddn;                       // limbs dropped (outermost first), 1..MAXDROP
+    int balanced;                  // every centred residue of a dropped limb is smaller than every kept modulus
+    W qinv_m[MAXDROP][MAXL];       // q_u^-1 mod q_t in Montgomery form (t > u)
+};
 
 template <typename W>
 struct NttCall {
@@ -74,6 +82,12 @@ struct NttCall {
     size_t nct;            // ciphertexts in this launch (a, b, out, digits already offset to the first)
     Scal<W> spre_r2;       // s_j * R^2 mod q_j
     bool balanced;         // every |digit| < every q_j  ->  reduce is one add
+    // full mul_ (modSwitch . keySwitchQuad . modSwitch): see kernel_rescale_out.hpp
+    int dup;               // OP_KS_ACCUM: limbs the hint's ring has in front of the operands' ring
+    DropTab<W> drop;       // OP_RESCALE_OUT: limbs to drop and the q_u^-1 tables
+    void* stash;           // OP_RESCALE_OUT: Signed<W> [grid][ddn][n]
+    unsigned stash_slots;
+    bool pow_out;
 };
 
 // ---- staging helpers -------------------------------------------------------------------------------
@@ -251,7 +265,7 @@ template <int LOGN, typename W, bool BALANCED>
 __global__ void __launch_bounds__(Geo<LOGN>::T)
 k_ks_accum(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
            const typename Signed<W>::type* __restrict__ digits, const W* __restrict__ hint, W* __restrict__ out,
-           unsigned nct, Scal<W> spre) {
+           unsigned nct, Scal<W> spre, int dup) {
     typedef Geo<LOGN> G;
     typedef typename Vec4<W>::type V;
     typedef typename Signed<W>::type SW;
@@ -272,18 +286,24 @@ k_ks_accum(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
 
     const ModP<W> m = R.mod[j];
     const W q = m.q, qni = m.qni;
-    const W sr2 = spre.v[j];
+    // dup > 0: the operands live dup limbs below the hint's ring (see k_ks_accum_half)
+    const int Ls = L - dup, js = j - dup;
+    const size_t jsz = (size_t)(js < 0 ? 0 : js);
+    const W sr2 = spre.v[jsz];
     const size_t n = (size_t)G::N;
-    const W* a0 = a + ((2 * ct) * (size_t)L + j) * n;
-    const W* a1 = a + ((2 * ct + 1) * (size_t)L + j) * n;
-    const W* b0 = b + ((2 * ct) * (size_t)L + j) * n;
-    const W* b1 = b + ((2 * ct + 1) * (size_t)L + j) * n;
+    const W* a0 = a + ((2 * ct) * (size_t)Ls + jsz) * n;
+    const W* a1 = a + ((2 * ct + 1) * (size_t)Ls + jsz) * n;
+    const W* b0 = b + ((2 * ct) * (size_t)Ls + jsz) * n;
+    const W* b1 = b + ((2 * ct + 1) * (size_t)Ls + jsz) * n;
     const W* hj = hint + (size_t)j * n;                       // + ((i*2 + c)*L)*n
     const size_t hstride = (size_t)L * n;
 
     W acc0[G::E], acc1[G::E];
     // c0, c1 and the diagonal digit (i == j): d_j = c2_j (mod q_j), no transform needed
-    {
+    if (js < 0) {
+#pragma unroll
+        for (int s = 0; s < G::E; ++s) { acc0[s] = 0; acc1[s] = 0; }
+    } else {
         const W* h0 = hj + (size_t)(2 * j) * hstride;
         const W* h1 = hj + (size_t)(2 * j + 1) * hstride;
 #pragma unroll
@@ -310,9 +330,9 @@ k_ks_accum(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
         }
     }
 
-    for (int i = 0; i < L; ++i) {
-        if (i == j) continue;
-        const SW* d = digits + (ct * (size_t)L + i) * n;
+    for (int i = 0; i < Ls; ++i) {
+        if (i == js) continue;
+        const SW* d = digits + (ct * (size_t)Ls + i) * n;
         lds_barrier();      // previous transform's last pass has finished reading LDS
         stage_in<LOGN, W>(lds, [&](int idx) {
             SV z = *reinterpret_cast<const SV*>(d + idx);
@@ -325,8 +345,8 @@ k_ks_accum(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
             return v;
         });
         lds_barrier();
-        const W* h0 = hj + (size_t)(2 * i) * hstride;
-        const W* h1 = hj + (size_t)(2 * i + 1) * hstride;
+        const W* h0 = hj + (size_t)(2 * (i + dup)) * hstride;
+        const W* h1 = hj + (size_t)(2 * (i + dup) + 1) * hstride;
         // Neither the twiddles nor the LDS addresses depend on i; unless both are made opaque here the
         // compiler hoists every pass's address arithmetic and twiddle loads out of the digit loop and
         // spills ~250 VGPRs per lane.
@@ -362,6 +382,10 @@ k_ks_accum(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
         }
     }
 }
+
+}  // namespace alch
+#include "kernel_rescale_out.hpp"
+namespace alch {
 
 // ---- launcher ----------------------------------------------------------------------------------------
 template <typename K>
@@ -423,16 +447,28 @@ inline hipError_t run_call(const NttCall<W>& c) {
             const unsigned grid = nitems < persist ? nitems : persist;
             constexpr int TH = 1 << (LOGN - 6);
             const size_t half_lds = lds_bytes / 2;
-            if (c.balanced) {
+            if (c.dup > 0) {
+                if (c.balanced) {
+                    auto k = k_ks_accum_half<LOGN, true, 32, true>;
+                    if ((e = set_lds(k, half_lds)) != hipSuccess) return e;
+                    hipLaunchKernelGGL(k, dim3(grid), dim3(TH), half_lds, c.stream, R, c.a, c.b, (const int32_t*)c.digits,
+                                       c.hint, c.out, (unsigned)c.nct, nitems, c.spre_r2, dbg_mask, c.dup);
+                } else {
+                    auto k = k_ks_accum_half<LOGN, false, 32, true>;
+                    if ((e = set_lds(k, half_lds)) != hipSuccess) return e;
+                    hipLaunchKernelGGL(k, dim3(grid), dim3(TH), half_lds, c.stream, R, c.a, c.b, (const int32_t*)c.digits,
+                                       c.hint, c.out, (unsigned)c.nct, nitems, c.spre_r2, dbg_mask, c.dup);
+                }
+            } else if (c.balanced) {
                 auto k = k_ks_accum_half<LOGN, true>;
                 if ((e = set_lds(k, half_lds)) != hipSuccess) return e;
                 hipLaunchKernelGGL(k, dim3(grid), dim3(TH), half_lds, c.stream, R, c.a, c.b, (const int32_t*)c.digits,
-                                   c.hint, c.out, (unsigned)c.nct, nitems, c.spre_r2, dbg_mask);
+                                   c.hint, c.out, (unsigned)c.nct, nitems, c.spre_r2, dbg_mask, 0);
             } else {
                 auto k = k_ks_accum_half<LOGN, false>;
                 if ((e = set_lds(k, half_lds)) != hipSuccess) return e;
                 hipLaunchKernelGGL(k, dim3(grid), dim3(TH), half_lds, c.stream, R, c.a, c.b, (const int32_t*)c.digits,
-                                   c.hint, c.out, (unsigned)c.nct, nitems, c.spre_r2, dbg_mask);
+                                   c.hint, c.out, (unsigned)c.nct, nitems, c.spre_r2, dbg_mask, 0);
             }
             break;
         }
@@ -442,13 +478,22 @@ inline hipError_t run_call(const NttCall<W>& c) {
             auto k = k_ks_accum<LOGN, W, true>;
             if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
             hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), lds_bytes, c.stream, R, c.a, c.b, (const SW*)c.digits,
-                               c.hint, c.out, (unsigned)c.nct, c.spre_r2);
+                               c.hint, c.out, (unsigned)c.nct, c.spre_r2, c.dup);
         } else {
             auto k = k_ks_accum<LOGN, W, false>;
             if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
             hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), lds_bytes, c.stream, R, c.a, c.b, (const SW*)c.digits,
-                               c.hint, c.out, (unsigned)c.nct, c.spre_r2);
+                               c.hint, c.out, (unsigned)c.nct, c.spre_r2, c.dup);
         }
+        break;
+    }
+    case OP_RESCALE_OUT: {
+        auto k = k_rescale_out<LOGN, W>;
+        if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
+        const unsigned nitems = (unsigned)(c.nct * 2);
+        const unsigned grid = nitems < c.stash_slots ? nitems : c.stash_slots;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), lds_bytes, c.stream, R, c.a, c.out, (SW*)c.stash, nitems, c.drop,
+                           c.pow_out ? 1 : 0);
         break;
     }
     }

@@ -159,6 +159,20 @@ int alch_hint_free(alch_hint *hint);
 int alch_ct_mul_relin(alch_ring *ring, const alch_hint *hint, const alch_buf *a, const alch_buf *b,
                       alch_buf *out, size_t batch, const uint64_t *s_pre, unsigned flags);
 
+/* The complete PT2CT mul_ (PT2CT.hs:160-177):  out[b] = modSwitch (keySwitchQuadCirc hint (modSwitch (a[b] * b[b])))
+ * -- SymmSHE (*) (Eval.hs:65-67), modSwitch to the hint's modulus (Eval.hs:130; PT2CTMulCtx'' "ModSwitchCtx_ ctin ->
+ * hintzq", PT2CT.hs:142-158), keySwitchQuadCirc (Eval.hs:133), modSwitch to the output modulus.  Three rings with
+ * the limb nesting of Noise.hs:82-89 (outermost = first): `hint` belongs to ring_h = (q_0 .. q_{Lh-1}); a and b
+ * to ring_in = its last L_in limbs (L_in < Lh: KSPNoise gives a TrivGad hint one extra limb, PT2CT.hs:139);
+ * out to ring_out = its last L_out limbs (L_out < Lh, at most 3 limbs dropped).  The rings are taken from the
+ * handles; work is queued on ring_h's stream after everything queued so far on the other two, which in turn wait
+ * for it.  s_pre[j] (j < L_in): toLSD scalars of both operands times the first modSwitch's toMSD scalar
+ * (p^-1 mod q when both operands are LSD), NULL = 1; the library itself multiplies in the added moduli
+ * (Rescale b -> (a,b): x -> (0, q_a x)) and performs both later toMSD as the identities they are.
+ * flags: ALCH_POW_OUT leaves the result in the Pow basis (what Lol's rescale produces); operands are CRT basis. */
+int alch_ct_mul_full(const alch_hint *hint, const alch_buf *a, const alch_buf *b, alch_buf *out, size_t batch,
+                     const uint64_t *s_pre, unsigned flags);
+
 /* ---- modSwitch building block (Eval.hs:130) ---------------------------------------
  * Rescale (a,b) -> b on Pow-basis elements: src lives in ring_src (L limbs), dst in ring_dst whose
  * limbs are ring_src's limbs 1..L-1:  dst_j = q_0^-1 * (src_j - reduce(lift src_0)). */

@@ -38,3 +38,40 @@ def hint_to_crt_aos(ring_oracle, hint_pow):
         out.append(ring_oracle.crt(to_aos(h0)))
         out.append(ring_oracle.crt(to_aos(h1)))
     return out
+
+
+def oracle_full_mul(oracle_lib, n, qs_h, l_in, l_out, hint_crt, a0, a1, b0, b1, s_pre=None, pow_out=False):
+    """PT2CT's whole mul_ (PT2CT.hs:172-177) composed from the C restatement's primitives:
+    modSwitch (keySwitchQuadCirc hint (modSwitch (a * b))) with operands on the last l_in limbs of qs_h, the hint on
+    all of qs_h and the result on the last l_out limbs.  Operands / hint / result in the CRT basis ((n, L) int64),
+    result in the Pow basis with pow_out.  Pinned to the exact model by tests/golden/full_mul_small.json."""
+    L = len(qs_h)
+    dup = L - l_in
+    o_in, o_h = oracle_lib.Ring(n, qs_h[dup:]), oracle_lib.Ring(n, qs_h)
+    s = list(s_pre) if s_pre is not None else [1] * l_in
+    # (*) and the encoding scalars
+    c = [o_in.mul(a0, b0), o_in.add(o_in.mul(a0, b1), o_in.mul(a1, b0)), o_in.mul(a1, b1)]
+    c = [o_in.scale(x, s) for x in c]
+    # modSwitch up: Rescale b -> (a, b):  x -> (0, q_a x)
+    mult = 1
+    for q in qs_h[:dup]:
+        mult *= q
+    up = []
+    for x in c:
+        scaled = o_in.scale(x, [mult % q for q in qs_h[dup:]])
+        up.append(np.ascontiguousarray(np.concatenate([np.zeros((n, dup), dtype=np.int64), scaled], axis=1)))
+    # keySwitchQuadCirc: [c0, c1] + sum_i crt(reduce d_i) * hint_i
+    digs = o_h.decompose_triv(o_h.crtinv(up[2]))
+    ks = [up[0], up[1]]
+    for i, d in enumerate(digs):
+        dc = o_h.crt(d)
+        ks[0] = o_h.add(ks[0], o_h.mul(dc, hint_crt[2 * i]))
+        ks[1] = o_h.add(ks[1], o_h.mul(dc, hint_crt[2 * i + 1]))
+    # modSwitch down: Rescale (a, b) -> b in the Pow basis, outermost limb first
+    out = []
+    for x in ks:
+        cur = o_h.crtinv(x)
+        for k in range(L, l_out, -1):
+            cur = oracle_lib.Ring(n, qs_h[L - k:]).rescale_drop0(cur)
+        out.append(cur if pow_out else oracle_lib.Ring(n, qs_h[L - l_out:]).crt(cur))
+    return out[0], out[1]

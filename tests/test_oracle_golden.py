@@ -147,3 +147,18 @@ def test_prop_key_switch_preserves_decryption(seed):
     assert M.decrypt(sk, M.key_switch_quad_circ(hint2, M.ct_mul(cta, ctb)), npt) == M.negacyclic_mul(pa, pb, p)
     # toMSD . toLSD = id
     assert M.to_lsd(M.to_msd(cta)).c == cta.c and M.to_lsd(M.to_msd(cta)).l == cta.l
+
+
+def test_full_mul_composition_matches_model(oracle_lib):
+    """helpers.oracle_full_mul (the checker of alch_ct_mul_full on the GPU) against the exact model's fixtures."""
+    from helpers import oracle_full_mul
+    for case in load_golden("full_mul_small.json")["cases"]:
+        n, p, qs_h, l_in, l_out = case["n"], case["p"], case["qs_hint"], case["l_in"], case["l_out"]
+        L = len(qs_h)
+        o_in, o_h = oracle_lib.Ring(n, qs_h[L - l_in:]), oracle_lib.Ring(n, qs_h)
+        x = [o_in.crt(to_aos(c)) for c in case["x"]["c"]]
+        y = [o_in.crt(to_aos(c)) for c in case["y"]["c"]]
+        hint = hint_to_crt_aos(o_h, case["hint"])
+        s = [pow(p, -1, q) for q in qs_h[L - l_in:]]          # fresh encryptions are LSD; modSwitch's toMSD
+        r0, r1 = oracle_full_mul(oracle_lib, n, qs_h, l_in, l_out, hint, x[0], x[1], y[0], y[1], s_pre=s, pow_out=True)
+        assert [from_aos(r0), from_aos(r1)] == case["result"]["c"]
