@@ -102,7 +102,7 @@ __device__ __forceinline__ u32 mont_red_lazy(u64 p, u32 q, u32 qni) {       // p
 // UP (the full PT2CT mul_, PT2CT.hs:177): the operands live `dup` limbs below the hint's ring -- R is the hint's
 // ring with L limbs, a/b/digits belong to its last L - dup limbs.  modSwitch up puts 0 into the added limbs
 // and q_added * x into the others (a scalar, folded into spre by the host), so an added limb j < dup starts
-// from c0 = c1 = 0, has no diagonal digit and transforms all L - dup digits; hint row of source digit i is
+// from c0 = c1 = 0, has a zero diagonal digit and transforms all L - dup digits; hint row of source digit i is
 // i + dup (the digits of the added limbs are zero and are skipped).
 template <int LOGN, bool BALANCED, int EPT = 32, bool UP = false>
 __global__ void __launch_bounds__((1 << (LOGN - 1)) / EPT, EPT == 32 ? 4 : 8)
@@ -172,7 +172,9 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     const ModP<W> m = R.mod[j];
     const W q = m.q, qni = m.qni;
     const int js = j - dup;                         // this limb in the operands' ring; < 0: added by modSwitch
-    const W sr2 = spre.v[js < 0 ? 0 : js];
+    // an added limb runs the same tensor code on limb 0's operands with scalar 0 (c0 = c1 = c2 = 0): a fifth of
+    // the items waste ~10 % of their time, and the kernel keeps one copy of the load/store pipeline
+    const W sr2 = js < 0 ? (W)0 : spre.v[js];
     const size_t n = (size_t)N;
     const size_t slot0 = (size_t)hf * M;
     const size_t cti = (dbg_mask & 1u) ? (ct & 7) : ct;                // traffic experiment: alias the inputs
@@ -185,11 +187,7 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     const size_t hstride = (size_t)L * n;
 
     KS_STAMP_INIT();
-    if (UP && js < 0) {
-        flush_stores();
-#pragma unroll
-        for (int s = 0; s < EPT; ++s) { acc0[s] = 0; acc1[s] = 0; }
-    } else {   // c0, c1 and the diagonal digit (i == j): d_j = c2_j (mod q_j), no transform needed.
+    {   // c0, c1 and the diagonal digit (i == j): d_j = c2_j (mod q_j), no transform needed.
         // Eight 4-coefficient slices, software-pipelined: the six 16-byte loads of slice s+1 are in flight
         // while slice s is multiplied out (issuing them one slice at a time exposed the HBM latency eight
         // times per workgroup: 20 % of the kernel in the phase stamps).

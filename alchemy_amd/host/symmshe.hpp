@@ -14,6 +14,7 @@
 //   modSwitchAdd0  the other direction (rescale b->(a,b))   (Eval.hs:130; PT2CT.hs:177)
 //   genSK, ksQuadCircHint, encrypt, decrypt                (KeysHints.hs:93-96,101-113; PT2CT.hs:84-99)
 //   mulRelinBatch  the fused device path for PT2CT's  keySwitchQuad_ hint $: (x *: y)  (PT2CT.hs:172-177)
+//   mulFullBatch   the fused device path for the whole mul_ with the longer hint modulus (PT2CT.hs:139,160-177)
 //
 // Everything numeric goes through the C ABI (device kernels); this file only sequences calls and keeps the
 // (enc, k, l) metadata.  Errors surface as std::runtime_error carrying alch_last_error().
@@ -397,6 +398,59 @@ inline std::vector<CT> mulRelinBatch(const Ring& r, const KSQuadCircHint& hint, 
     std::vector<CT> out;
     for (size_t i = 0; i < B; ++i) {
         CT o{Encoding::MSD, xs[i].k + ys[i].k + 1, lout, p, {Cyc(r, Basis::CRT), Cyc(r, Basis::CRT)}};
+        for (int c = 0; c < 2; ++c) check(alch_buf_download(bo, 2 * i + c, 1, o.c[c].data().data()), "alch_buf_download");
+        out.push_back(std::move(o));
+    }
+    alch_hint_free(dh);
+    alch_buf_free(ba); alch_buf_free(bb); alch_buf_free(bo); alch_buf_free(bh);
+    return out;
+}
+
+// PT2CT's whole mul_ on batches:  modSwitch_ .: keySwitchQuad_ hint .: modSwitch_ $: (x *: y)  (PT2CT.hs:172-177)
+// with the hint on a ring `rh` that has extra limbs in front of the operands' ring `rin` (KSPNoise, PT2CT.hs:139)
+// and the result on `rout`, the last limbs of rh.  One alch_ct_mul_full call (three kernel launches per chunk).
+// Returns MSD ciphertexts in the Pow basis (what Lol's rescale leaves), k = k1+k2+1, l = l1*l2*(-q_in mod p).
+inline std::vector<CT> mulFullBatch(const Ring& rin, const Ring& rh, const Ring& rout, const KSQuadCircHint& hint,
+                                    const std::vector<CT>& xs, const std::vector<CT>& ys) {
+    const size_t B = xs.size();
+    if (B == 0 || ys.size() != B) throw std::runtime_error("mulFullBatch: batch mismatch");
+    std::vector<uint64_t> s(rin.L(), 1);
+    uint64_t lx = xs[0].l, ly = ys[0].l;
+    const uint64_t p = xs[0].p;
+    const uint64_t negq = (p - qprod_mod(rin, p)) % p;
+    auto fold = [&](Encoding enc, uint64_t& l) {               // toLSD
+        if (enc == Encoding::MSD) {
+            for (int j = 0; j < rin.L(); ++j) s[j] = mulmod(s[j], p % rin.qs()[j], rin.qs()[j]);
+            l = mulmod(l, invmod(negq, p), p);
+        }
+    };
+    fold(xs[0].enc, lx);
+    fold(ys[0].enc, ly);
+    for (int j = 0; j < rin.L(); ++j) s[j] = mulmod(s[j], invmod(p % rin.qs()[j], rin.qs()[j]), rin.qs()[j]);   // first modSwitch's toMSD
+    const uint64_t lout = mulmod(mulmod(lx, ly, p), negq, p);
+
+    alch_buf *ba = nullptr, *bb = nullptr, *bo = nullptr, *bh = nullptr;
+    alch_hint* dh = nullptr;
+    check(alch_buf_alloc(rin.handle(), 2 * B, &ba), "alch_buf_alloc");
+    check(alch_buf_alloc(rin.handle(), 2 * B, &bb), "alch_buf_alloc");
+    check(alch_buf_alloc(rout.handle(), 2 * B, &bo), "alch_buf_alloc");
+    check(alch_buf_alloc(rh.handle(), 2 * (size_t)rh.L(), &bh), "alch_buf_alloc");
+    for (size_t i = 0; i < B; ++i) {
+        if (xs[i].c.size() != 2 || ys[i].c.size() != 2) throw std::runtime_error("mulFullBatch: linear ciphertexts only");
+        for (int c = 0; c < 2; ++c) {
+            check(alch_buf_upload(ba, 2 * i + c, 1, xs[i].c[c].adviseCRT().data().data()), "alch_buf_upload");
+            check(alch_buf_upload(bb, 2 * i + c, 1, ys[i].c[c].adviseCRT().data().data()), "alch_buf_upload");
+        }
+    }
+    for (int i = 0; i < rh.L(); ++i) {
+        check(alch_buf_upload(bh, 2 * i, 1, hint.h[i].first.adviseCRT().data().data()), "alch_buf_upload");
+        check(alch_buf_upload(bh, 2 * i + 1, 1, hint.h[i].second.adviseCRT().data().data()), "alch_buf_upload");
+    }
+    check(alch_hint_from_buf(rh.handle(), ALCH_GAD_TRIV, bh, &dh), "alch_hint_from_buf");
+    check(alch_ct_mul_full(dh, ba, bb, bo, B, s.data(), ALCH_POW_OUT), "alch_ct_mul_full");
+    std::vector<CT> out;
+    for (size_t i = 0; i < B; ++i) {
+        CT o{Encoding::MSD, xs[i].k + ys[i].k + 1, lout, p, {Cyc(rout, Basis::Pow), Cyc(rout, Basis::Pow)}};
         for (int c = 0; c < 2; ++c) check(alch_buf_download(bo, 2 * i + c, 1, o.c[c].data().data()), "alch_buf_download");
         out.push_back(std::move(o));
     }

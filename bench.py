@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CFG3_QS = [2147352577, 2146959361, 2146041857, 2145976321]
+FULL_EXTRA_Q = 2144796673                              # next prime = 1 mod 2^16 below CFG3_QS: the hint's extra limb (--full)
 LOGN = 15
 ALGO_BYTES_PER_OP = 6 * 4 * (1 << LOGN) * 8          # 6,291,456 B  
 HINT_BYTES = 2 * 4 * 4 * (1 << LOGN) * 8              # 8 MiB, counted once per batch
@@ -48,6 +49,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8192, help="ciphertext pairs per GPU per step (weak scaling)")
     ap.add_argument("--cpu-ops", type=int, default=384, help="ops in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--pow", action="store_true", help="also time the Pow-basis in/out variant (extra field)")
+    ap.add_argument("--full", action="store_true",
+                    help="also time PT2CT's whole mul_ (modSwitch . keySwitchQuad . modSwitch . (*)), 4 -> 5 -> 3 limbs")
     args = ap.parse_args()
 
     import torch
@@ -110,6 +113,31 @@ def main():
             ring.ct_mul_relin(hint, a, b, out, Bp, flags=ALCH_POW_IN | ALCH_POW_OUT)
         pow_ops = 3 * Bp / (ring.timer_stop() * 1e-3)
 
+    full = None
+    if args.full:
+        # operands on 4 limbs, TrivGad hint one limb longer (KSPNoise, PT2CT.hs:139), result on 3
+        from alchemy_amd import capi
+        qs_h = [FULL_EXTRA_Q] + CFG3_QS
+        rh, rout = Ring(2 << LOGN, qs_h), Ring(2 << LOGN, CFG3_QS[1:])
+        Bf = min(B, 4096)
+        hsrc = rh.alloc(2 * rh.L)
+        hsrc.fill_uniform(0xA1C4E5)
+        hint_h = rh.hint_from_buf(hsrc)
+        fout = rout.alloc(2 * Bf)
+        rh.sync()
+        capi.ct_mul_full(hint_h, a, b, fout, Bf)
+        rh.sync()
+        rh.timer_start()
+        for _ in range(3):
+            capi.ct_mul_full(hint_h, a, b, fout, Bf)
+        ops = 3 * Bf / (rh.timer_stop() * 1e-3)
+        # compulsory bytes at 8-byte words: two 4-limb linear ciphertexts in, one 3-limb out
+        algo = (2 * 2 * 4 + 2 * 3) * (1 << LOGN) * 8
+        full = {"ops_per_s": ops, "workload": "PT2CT mul_: (*) on 4 limbs, modSwitch to the 5-limb hint modulus, "
+                "keySwitchQuadCirc, modSwitch to 3 limbs; CRT-basis in/out", "moduli_hint": qs_h, "batch": Bf,
+                "algorithmic_bytes_per_op": algo, "achieved_GBs": ops * algo / 1e9,
+                "frac_of_hbm_peak": ops * algo / 1e9 / HBM_PEAK_GBS, "out_checksum": f"{fout.checksum(0, 2):016x}"}
+
     if rank == 0:
         total_ops = B * world * args.steps
         value = total_ops / wall_max
@@ -149,6 +177,8 @@ def main():
         }
         if pow_ops is not None:
             line["pow_basis_in_out_ops_per_s"] = pow_ops
+        if full is not None:
+            line["full_mul"] = full
         if world == 1 and args.cpu_ops > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_ops)
         else:

@@ -63,10 +63,24 @@ int main(int argc, char** argv) {
         printf("fused path == per-op path: %s\n", same ? "yes" : "NO");
         CT result2 = modSwitchDrop0(fused[0], ring1);
 
+        // The same product with the hint modulus KSPNoise asks for (PT2CT.hs:139: one more limb, here q3 in front):
+        // modSwitch up, key switch on three limbs, modSwitch down to q1 -- per op and as one alch_ct_mul_full call.
+        Ring ring3(m, {1073750017, 8392193, 268440577});
+        SK sk3{sk.s, sk.r};
+        KSQuadCircHint hint3 = ksQuadCircHint(ring3, sk3, rng);
+        CT up = modSwitchAdd0(prod, ring3);
+        CT ks3 = keySwitchQuadCirc(hint3, up);
+        CT result3 = modSwitchDrop0(modSwitchDrop0(ks3, ring2), ring1);
+        std::vector<CT> full = mulFullBatch(ring2, ring3, ring1, hint3, {s}, {arg2});
+        bool same3 = full[0].l == result3.l && full[0].k == result3.k;
+        for (int c = 0; c < 2; ++c) same3 = same3 && full[0].c[c].advisePow().data() == result3.c[c].advisePow().data();
+        printf("fused full mul_ (2 -> 3 -> 1 limbs) == per-op path: %s\n", same3 ? "yes" : "NO");
+
         SK sk1{sk.s, sk.r};
         std::vector<uint64_t> dec = decrypt(sk1, result, npt), dec2 = decrypt(sk1, result2, npt);
         printf("Decrypted evaluation result: [%llu, %llu]\n", (unsigned long long)dec[0], (unsigned long long)dec[1]);
-        const bool ok = same && dec == ptresult && dec2 == ptresult;
+        std::vector<uint64_t> dec3 = decrypt(sk1, full[0], npt);
+        const bool ok = same && same3 && dec == ptresult && dec2 == ptresult && dec3 == ptresult;
         printf("%s\n", ok ? "PASS" : "FAIL");
         return ok ? 0 : 1;
     } catch (const std::exception& e) {

@@ -25,4 +25,5 @@ def test_arithmetic_example_prints_pass(replay_binary, index):
     out = subprocess.run([replay_binary, index], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "fused path == per-op path: yes" in out.stdout
+    assert "fused full mul_ (2 -> 3 -> 1 limbs) == per-op path: yes" in out.stdout
     assert out.stdout.strip().endswith("PASS")
