@@ -2,7 +2,7 @@
 
 The path has no cross-ciphertext dataflow (every reference op is a pure function of single values,
 Crypto/Alchemy/Interpreter/Eval.hs:41-53), so ranks own contiguous chunks of the batch, the hint is
-replicated, and no collective runs inside the timed region.  torch.distributed is used for the
+replicated (broadcast once, before timing), and no collective runs inside the timed region.  torch.distributed is used for the
 rendezvous, the barrier and the max-over-ranks of the step time; RCCL moves data only when a caller
 explicitly gathers results (outside the timed region).
 """
@@ -50,6 +50,21 @@ def init_distributed(backend: str | None = None):
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world, dist
+
+
+def broadcast_array(arr, dist, src: int = 0, device=None):
+    """Broadcast a numpy array from rank `src` to every rank, in place (the key-switch hint, once per circuit,
+    outside any timed region).  With the nccl (= RCCL) backend the bytes travel device to device over xGMI."""
+    if dist is None:
+        return arr
+    import numpy as np
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    if device is not None:
+        t = t.to(device)
+    dist.broadcast(t, src=src)
+    arr[...] = t.cpu().numpy()
+    return arr
 
 
 def barrier(dist):

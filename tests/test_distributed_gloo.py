@@ -23,6 +23,10 @@ WORKER = textwrap.dedent("""
     t_max = shard.max_over_ranks(fake_step_seconds, dist)
     n_sum = shard.sum_over_ranks(sh.count, dist)
     first_sum = shard.sum_over_ranks(sh.first, dist)
+    import numpy as np
+    hint = np.arange(24, dtype=np.int64).reshape(2, 3, 4) * (7 if rank == 0 else -1)     # only rank 0 holds the hint
+    shard.broadcast_array(hint, dist, src=0)
+    assert int(hint.sum()) == 7 * sum(range(24)), hint
     shard.barrier(dist)
     print(json.dumps({"rank": rank, "count": sh.count, "first": sh.first, "t_max": t_max, "n_sum": n_sum,
                       "first_sum": first_sum, "value": n_sum / t_max}), flush=True)
