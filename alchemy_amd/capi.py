@@ -245,10 +245,18 @@ class Ring:
 
     def hint_load(self, host_crt, gadget: int = ALCH_GAD_TRIV) -> "Hint":
         host = np.ascontiguousarray(host_crt, dtype=np.int64)
-        assert host.shape == (2 * self.L, self.n, self.L)
+        assert host.shape == (2 * self.gadget_digits(gadget), self.n, self.L)
         h = C.c_void_p()
         _check(self._l.alch_hint_load(self._h, gadget, _p64(host), C.byref(h)))
         return Hint(self, h)
+
+    def gadget_digits(self, gadget: int = ALCH_GAD_TRIV) -> int:
+        """Digits (= hint rows) of a gadget on this ring: L for TrivGad, sum_i ceil(log2 q_i) for BaseBGad 2."""
+        if gadget == ALCH_GAD_TRIV:
+            return self.L
+        nd = C.c_int()
+        _check(self._l.alch_decompose_base2(self._h, None, None, C.byref(nd)))
+        return nd.value
 
     def hint_from_buf(self, buf: "Buf", gadget: int = ALCH_GAD_TRIV) -> "Hint":
         h = C.c_void_p()

@@ -166,10 +166,12 @@ __global__ void k_decompose_triv(DevRing<W> R, const W* c, W* digits) {
 // the ceil(log2 q_i) digits (balanced remainder in {0,-1}, top digit absorbs the rest) and writes each one
 // reduced into every limb.  first_digit[i] = index of limb i's first digit, kd[i] = its digit count.
 template <typename W>
-__global__ void k_decompose_base2(DevRing<W> R, const W* c, W* digits, Scal<u32> first_digit, Scal<u32> kd) {
+__global__ void k_decompose_base2(DevRing<W> R, const W* c, W* digits, Scal<u32> first_digit, Scal<u32> kd, u32 D) {
     typedef typename Signed<W>::type SW;
     const size_t n = (size_t)1 << R.logn;
     const size_t L = (size_t)R.L;
+    c += (size_t)blockIdx.y * L * n;                       // blockIdx.y: which ring element
+    digits += (size_t)blockIdx.y * D * L * n;
     for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < L * n; w += (size_t)gridDim.x * blockDim.x) {
         const size_t k = w % n, i = w / n;
         const W qi = R.mod[i].q;
@@ -190,6 +192,45 @@ __global__ void k_decompose_base2(DevRing<W> R, const W* c, W* digits, Scal<u32>
                 out[j * n + k] = (W)r;
             }
         }
+    }
+}
+
+// SymmSHE (*) on linear ciphertexts, element-wise on the CRT basis: c0 = a0 b0 s, c1 = (a0 b1 + a1 b0) s -> out,
+// c2 = a1 b1 s -> c2buf (one element per ciphertext).  sr2 = s R^2 (Montgomery).  Used by the BaseBGad key switch.
+template <typename W>
+__global__ void k_tensor_ew(DevRing<W> R, const W* a, const W* b, W* out, W* c2buf, size_t nct, Scal<W> sr2) {
+    const size_t n = (size_t)1 << R.logn;
+    const size_t Ln = (size_t)R.L * n;
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < nct * Ln; w += (size_t)gridDim.x * blockDim.x) {
+        const size_t ct = w / Ln, rem = w % Ln;
+        const ModP<W> m = R.mod[rem / n];
+        const W a0 = a[2 * ct * Ln + rem], a1 = a[(2 * ct + 1) * Ln + rem];
+        const W b0 = b[2 * ct * Ln + rem], b1 = b[(2 * ct + 1) * Ln + rem];
+        const W x0 = mont_mul(a0, sr2.v[rem / n], m), x1 = mont_mul(a1, sr2.v[rem / n], m);      // a s R
+        out[2 * ct * Ln + rem] = mont_mul(b0, x0, m);
+        out[(2 * ct + 1) * Ln + rem] = add_mod(mont_mul(b1, x0, m), mont_mul(b0, x1, m), m.q);
+        c2buf[ct * Ln + rem] = mont_mul(b1, x1, m);
+    }
+}
+
+// keySwitchQuadCirc's inner product for a many-digit gadget: out_c += sum_d digit_d * hint_{d,c} (CRT basis).
+// digits: [ct][D][L][n]; hint: [D][2][L][n] in Montgomery form.
+template <typename W>
+__global__ void k_hint_mac(DevRing<W> R, W* out, const W* digits, const W* hint, size_t nct, u32 D) {
+    const size_t n = (size_t)1 << R.logn;
+    const size_t Ln = (size_t)R.L * n;
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < nct * Ln; w += (size_t)gridDim.x * blockDim.x) {
+        const size_t ct = w / Ln, rem = w % Ln;
+        const ModP<W> m = R.mod[rem / n];
+        W acc0 = out[2 * ct * Ln + rem], acc1 = out[(2 * ct + 1) * Ln + rem];
+        const W* dg = digits + ct * (size_t)D * Ln + rem;
+        for (u32 d = 0; d < D; ++d) {
+            const W x = dg[(size_t)d * Ln];
+            acc0 = add_mod(acc0, mont_mul(x, hint[(size_t)(2 * d) * Ln + rem], m), m.q);
+            acc1 = add_mod(acc1, mont_mul(x, hint[(size_t)(2 * d + 1) * Ln + rem], m), m.q);
+        }
+        out[2 * ct * Ln + rem] = acc0;
+        out[(2 * ct + 1) * Ln + rem] = acc1;
     }
 }
 
@@ -715,9 +756,8 @@ extern "C" int alch_decompose_triv(alch_ring* r, const int64_t* c_pow, int64_t* 
     return alch_buf_download(s.b, 1, (size_t)r->L, digits);
 }
 
-extern "C" int alch_decompose_base2(alch_ring* r, const int64_t* c_pow, int64_t* digits, int* n_digits) {
-    if (!r) return fail(ALCH_E_INVALID, "null ring");
-    Scal<u32> first, kd;
+// BaseBGad 2 layout: limb i owns ceil(log2 q_i) digits starting at first[i]; returns their total.
+static int base2_layout(const alch_ring* r, Scal<u32>& first, Scal<u32>& kd) {
     int D = 0;
     for (int j = 0; j < MAXL; ++j) { first.v[j] = 0; kd.v[j] = 0; }
     for (int i = 0; i < r->L; ++i) {
@@ -727,6 +767,19 @@ extern "C" int alch_decompose_base2(alch_ring* r, const int64_t* c_pow, int64_t*
         kd.v[i] = (u32)k;
         D += k;
     }
+    return D;
+}
+
+static int gadget_digits(const alch_ring* r, int gadget) {
+    if (gadget == ALCH_GAD_TRIV) return r->L;
+    Scal<u32> f, k;
+    return base2_layout(r, f, k);
+}
+
+extern "C" int alch_decompose_base2(alch_ring* r, const int64_t* c_pow, int64_t* digits, int* n_digits) {
+    if (!r) return fail(ALCH_E_INVALID, "null ring");
+    Scal<u32> first, kd;
+    const int D = base2_layout(r, first, kd);
     if (n_digits) *n_digits = D;
     if (!digits) return ALCH_OK;
     if (!c_pow) return fail(ALCH_E_INVALID, "null argument");
@@ -736,8 +789,8 @@ extern "C" int alch_decompose_base2(alch_ring* r, const int64_t* c_pow, int64_t*
     if ((rc = alch_buf_upload(s.b, 0, 1, c_pow)) != ALCH_OK) return rc;
     char* dig = reinterpret_cast<char*>(s.b->dptr) + elem_bytes(r);
     const size_t total = elem_words(r);
-    if (r->word == 4) hipLaunchKernelGGL((k_decompose_base2<u32>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d32, (const u32*)s.b->dptr, (u32*)dig, first, kd);
-    else hipLaunchKernelGGL((k_decompose_base2<u64>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d64, (const u64*)s.b->dptr, (u64*)dig, first, kd);
+    if (r->word == 4) hipLaunchKernelGGL((k_decompose_base2<u32>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d32, (const u32*)s.b->dptr, (u32*)dig, first, kd, (u32)D);
+    else hipLaunchKernelGGL((k_decompose_base2<u64>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d64, (const u64*)s.b->dptr, (u64*)dig, first, kd, (u32)D);
     HIP_TRY(hipGetLastError());
     return alch_buf_download(s.b, 1, (size_t)D, digits);
 }
@@ -746,8 +799,8 @@ extern "C" int alch_decompose_base2(alch_ring* r, const int64_t* c_pow, int64_t*
 // hint
 // ------------------------------------------------------------------------------------------------------
 static int hint_from_device(alch_ring* r, int gadget, const void* src_crt, alch_hint** out) {
-    if (gadget != ALCH_GAD_TRIV) return fail(ALCH_E_UNSUPPORTED, "device key switch supports TrivGad in this round");
-    const int digits = r->L;
+    if (gadget != ALCH_GAD_TRIV && gadget != ALCH_GAD_BASE2) return fail(ALCH_E_INVALID, "unknown gadget");
+    const int digits = gadget_digits(r, gadget);
     const size_t elems = 2 * (size_t)digits;
     void* p = nullptr;
     if (hipMalloc(&p, elems * elem_bytes(r)) != hipSuccess) return fail(ALCH_E_NOMEM, "hipMalloc(hint) failed");
@@ -793,10 +846,12 @@ extern "C" int alch_buf_decompose_triv(const alch_buf* src, size_t src_index, al
 
 extern "C" int alch_hint_load(alch_ring* r, int gadget, const int64_t* host_crt, alch_hint** out) {
     if (!r || !host_crt || !out) return fail(ALCH_E_INVALID, "null argument");
+    if (gadget != ALCH_GAD_TRIV && gadget != ALCH_GAD_BASE2) return fail(ALCH_E_INVALID, "unknown gadget");
+    const size_t elems = 2 * (size_t)gadget_digits(r, gadget);
     ScratchBuf s;
-    int rc = alch_buf_alloc(r, 2 * (size_t)r->L, &s.b);
+    int rc = alch_buf_alloc(r, elems, &s.b);
     if (rc != ALCH_OK) return rc;
-    if ((rc = alch_buf_upload(s.b, 0, 2 * (size_t)r->L, host_crt)) != ALCH_OK) return rc;
+    if ((rc = alch_buf_upload(s.b, 0, elems, host_crt)) != ALCH_OK) return rc;
     rc = hint_from_device(r, gadget, s.b->dptr, out);
     if (rc == ALCH_OK) HIP_TRY(hipStreamSynchronize(r->stream));
     return rc;
@@ -804,7 +859,9 @@ extern "C" int alch_hint_load(alch_ring* r, int gadget, const int64_t* host_crt,
 
 extern "C" int alch_hint_from_buf(alch_ring* r, int gadget, const alch_buf* src, alch_hint** out) {
     if (!r || !src || !out) return fail(ALCH_E_INVALID, "null argument");
-    if (src->ring != r || src->n_elems < 2 * (size_t)r->L) return fail(ALCH_E_INVALID, "hint source needs 2*L elements of this ring");
+    if (gadget != ALCH_GAD_TRIV && gadget != ALCH_GAD_BASE2) return fail(ALCH_E_INVALID, "unknown gadget");
+    if (src->ring != r || src->n_elems < 2 * (size_t)gadget_digits(r, gadget))
+        return fail(ALCH_E_INVALID, "hint source needs 2 ring elements per gadget digit");
     return hint_from_device(r, gadget, src->dptr, out);
 }
 
@@ -819,6 +876,47 @@ extern "C" int alch_hint_free(alch_hint* h) {
 // ------------------------------------------------------------------------------------------------------
 // the hot path
 // ------------------------------------------------------------------------------------------------------
+// keySwitchQuadCirc hint (a * b) for a BaseBGad 2 hint (PT2CT.hs:140; Tunnel.hs:24 / HomomRLWR.hs:46 pick it):
+// D = sum_i ceil(log2 q_i) digits, each reduced into every limb and transformed -- D*L crt per ciphertext against
+// L*(L-1) for TrivGad, so the op is two orders of magnitude heavier by construction and is run unfused:
+// element-wise tensor product, batched crtInv of c2, decompose, batched crt of the digits, hint inner product.
+template <typename W>
+static int do_mul_relin_base2(alch_ring* r, const alch_hint* hint, const void* a, const void* b, void* out, size_t batch,
+                              const uint64_t* s_pre) {
+    Scal<u32> first, kd;
+    const u32 D = (u32)base2_layout(r, first, kd);
+    const size_t eb = elem_bytes(r);
+    // scratch: c2 (1 element) + digits (D elements) per ciphertext of a chunk, at most ~1 GiB
+    size_t chunk = std::max<size_t>(1, ((size_t)1 << 30) / ((D + 1) * eb));
+    chunk = std::min(chunk, batch);
+    int rc = ensure_ws(&r->ws_digits, &r->ws_digits_bytes, chunk * (D + 1) * eb);
+    if (rc != ALCH_OK) return rc;
+    char* c2 = reinterpret_cast<char*>(r->ws_digits);
+    char* dig = c2 + chunk * eb;
+    Scal<W> sr2;
+    scal_to_mont<W>(r, s_pre, 2, sr2);
+    const size_t ct_bytes = 2 * eb;
+    for (size_t done = 0; done < batch; done += chunk) {
+        const size_t now = std::min(chunk, batch - done);
+        const W* pa = reinterpret_cast<const W*>(reinterpret_cast<const char*>(a) + done * ct_bytes);
+        const W* pb = reinterpret_cast<const W*>(reinterpret_cast<const char*>(b) + done * ct_bytes);
+        W* po = reinterpret_cast<W*>(reinterpret_cast<char*>(out) + done * ct_bytes);
+        const size_t words = now * elem_words(r);
+        hipLaunchKernelGGL((k_tensor_ew<W>), dim3(ew_grid(words)), dim3(256), 0, r->stream, dev_ring<W>(r), pa, pb, po,
+                           (W*)c2, now, sr2);
+        HIP_TRY(hipGetLastError());
+        if ((rc = do_crt<W>(r, c2, 0, now, true)) != ALCH_OK) return rc;
+        hipLaunchKernelGGL((k_decompose_base2<W>), dim3(ew_grid(elem_words(r)), (unsigned)now), dim3(256), 0, r->stream,
+                           dev_ring<W>(r), (const W*)c2, (W*)dig, first, kd, D);
+        HIP_TRY(hipGetLastError());
+        if ((rc = do_crt<W>(r, dig, 0, now * D, false)) != ALCH_OK) return rc;
+        hipLaunchKernelGGL((k_hint_mac<W>), dim3(ew_grid(words)), dim3(256), 0, r->stream, dev_ring<W>(r), po, (const W*)dig,
+                           (const W*)hint->dptr, now, D);
+        HIP_TRY(hipGetLastError());
+    }
+    return ALCH_OK;
+}
+
 template <typename W>
 static int do_mul_relin(alch_ring* r, const alch_hint* hint, const void* a, const void* b, void* out, size_t batch,
                         const uint64_t* s_pre) {
@@ -891,8 +989,12 @@ extern "C" int alch_ct_mul_relin(alch_ring* r, const alch_hint* hint, const alch
         pa = wa;
         pb = wb;
     }
-    rc = r->word == 4 ? do_mul_relin<u32>(r, hint, pa, pb, out->dptr, batch, s_pre)
-                      : do_mul_relin<u64>(r, hint, pa, pb, out->dptr, batch, s_pre);
+    if (hint->gadget == ALCH_GAD_BASE2)
+        rc = r->word == 4 ? do_mul_relin_base2<u32>(r, hint, pa, pb, out->dptr, batch, s_pre)
+                          : do_mul_relin_base2<u64>(r, hint, pa, pb, out->dptr, batch, s_pre);
+    else
+        rc = r->word == 4 ? do_mul_relin<u32>(r, hint, pa, pb, out->dptr, batch, s_pre)
+                          : do_mul_relin<u64>(r, hint, pa, pb, out->dptr, batch, s_pre);
     if (rc != ALCH_OK) return rc;
     if (flags & ALCH_POW_OUT) return buf_crt(out, 0, 2 * batch, true);
     return ALCH_OK;

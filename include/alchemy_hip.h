@@ -58,7 +58,7 @@ typedef struct alch_hint alch_hint;
 
 /* gadgets (Crypto/Alchemy/Interpreter/PT2CT.hs:139-140) */
 #define ALCH_GAD_TRIV 0            /* TrivGad: one digit per limb, centred lift                 */
-#define ALCH_GAD_BASE2 1           /* BaseBGad 2 (alch_decompose_base2; no fused key switch yet) */
+#define ALCH_GAD_BASE2 1           /* BaseBGad 2: sum_i ceil(log2 q_i) digits; unfused device path */
 
 const char *alch_last_error(void);
 /* Library/ABI version: (major<<16)|minor. */
@@ -140,7 +140,9 @@ int alch_buf_checksum(const alch_buf *buf, size_t first, size_t count, uint64_t 
 /* ---- key-switch hint ----------------------------------------------------------------------------
  * KSQuadCircHint gad (Cyc t m' zq) as produced by ksQuadCircHint
  * (Crypto/Alchemy/Interpreter/KeysHints.hs:101-113): one degree-1 polynomial (h0_i, h1_i) per gadget
- * digit.  host: 2*L consecutive ring elements in the CRT basis, order h0_0, h1_0, h0_1, h1_1, ... .
+ * digit.  host: 2*D consecutive ring elements in the CRT basis, order h0_0, h1_0, h0_1, h1_1, ... ;
+ * D = L for TrivGad, sum_i ceil(log2 q_i) for BaseBGad 2 (digits of limb 0 first, least significant first;
+ * alch_decompose_base2 reports D).
  * Kept device-resident (Montgomery form) for every later call. */
 int alch_hint_load(alch_ring *ring, int gadget, const int64_t *host_crt, alch_hint **out);
 /* Same, taking 2*L CRT-basis elements already on the device (e.g. synthetic). */

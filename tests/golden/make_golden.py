@@ -107,6 +107,26 @@ def gen_mul_relin():
     dump("mul_relin_small.json", {"cases": cases})
 
 
+def gen_mul_relin_base2():
+    """The same end-to-end check with the BaseBGad 2 gadget (PT2CT.hs:140): one hint row per signed binary digit."""
+    cases = []
+    for seed, (n, npt, p, qs) in enumerate([(16, 2, 7, ARITH_QS[:2]), (32, 4, 2, SMALL_QS[:3])]):
+        rng = random.Random(7000 + seed)
+        sk = M.gen_sk(n, 3.0, rng)
+        pa = [rng.randrange(p) for _ in range(npt)]
+        pb = [rng.randrange(p) for _ in range(npt)]
+        cta = M.encrypt(sk, pa, p, qs, 3.0, rng)
+        ctb = M.encrypt(sk, pb, p, qs, 3.0, rng)
+        hint = M.ks_quad_circ_hint(sk, qs, 3.0, rng, "baseb")
+        out = M.key_switch_quad_circ(hint, M.ct_mul(cta, ctb))
+        want_pt = M.negacyclic_mul(pa, pb, p)
+        assert M.decrypt(sk, out, npt) == want_pt
+        cases.append({"n": n, "npt": npt, "p": p, "qs": qs, "sk": sk, "want_pt": want_pt,
+                      "cta": ct_to_json(cta), "ctb": ct_to_json(ctb), "hint": [[h0, h1] for h0, h1 in hint.h],
+                      "s_pre": [pow(p, -1, q) for q in qs], "out": ct_to_json(out)})
+    dump("mul_relin_base2_small.json", {"cases": cases})
+
+
 def gen_arithmetic():
     """examples/Arithmetic.hs: (x + y) * y on R_7 (index 4), ciphertext index 32 (n=16, BASELINE wording) --
     limb counts as PT2CT selects them: the product runs on 2 limbs, hint on 2, result on 1."""
@@ -195,6 +215,7 @@ if __name__ == "__main__":
     gen_ntt()
     gen_decompose()
     gen_mul_relin()
+    gen_mul_relin_base2()
     gen_arithmetic()
     gen_full_mul()
     gen_digests()

@@ -75,3 +75,20 @@ def oracle_full_mul(oracle_lib, n, qs_h, l_in, l_out, hint_crt, a0, a1, b0, b1, 
             cur = oracle_lib.Ring(n, qs_h[L - k:]).rescale_drop0(cur)
         out.append(cur if pow_out else oracle_lib.Ring(n, qs_h[L - l_out:]).crt(cur))
     return out[0], out[1]
+
+
+def oracle_mul_relin_base2(oracle_lib, n, qs, hint_crt, a0, a1, b0, b1, s_pre=None, pow_out=False):
+    """keySwitchQuadCirc hint (a * b) with a BaseBGad 2 hint, composed from the C restatement's primitives
+    (CRT-basis operands and hint).  Pinned to the exact model by tests/golden/mul_relin_base2_small.json."""
+    o = oracle_lib.Ring(n, qs)
+    s = list(s_pre) if s_pre is not None else [1] * len(qs)
+    c0 = o.scale(o.mul(a0, b0), s)
+    c1 = o.scale(o.add(o.mul(a0, b1), o.mul(a1, b0)), s)
+    c2 = o.scale(o.mul(a1, b1), s)
+    digs = o.decompose_base2(o.crtinv(c2))
+    assert 2 * len(digs) == len(hint_crt)
+    for i, d in enumerate(digs):
+        dc = o.crt(d)
+        c0 = o.add(c0, o.mul(dc, hint_crt[2 * i]))
+        c1 = o.add(c1, o.mul(dc, hint_crt[2 * i + 1]))
+    return (o.crtinv(c0), o.crtinv(c1)) if pow_out else (c0, c1)

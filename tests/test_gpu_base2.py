@@ -1,0 +1,50 @@
+"""GPU parity of keySwitchQuadCirc hint (a * b) with a BaseBGad 2 hint (PT2CT.hs:140; the gadget Tunnel.hs:24 and
+HomomRLWR.hs:46 select): alch_ct_mul_relin with an ALCH_GAD_BASE2 hint against the exact model's fixture and the C
+restatement's composition.  Bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import ARITH_QS, CFG3_QS
+from helpers import from_aos, hint_to_crt_aos, load_golden, oracle_mul_relin_base2, to_aos
+
+pytestmark = pytest.mark.gpu
+
+
+def test_base2_key_switch_golden(oracle_lib):
+    import alchemy_amd as A
+    for case in load_golden("mul_relin_base2_small.json")["cases"]:
+        n, qs = case["n"], case["qs"]
+        g, o = A.Ring(2 * n, qs), oracle_lib.Ring(n, qs)
+        hint = g.hint_load(np.stack(hint_to_crt_aos(o, case["hint"])), gadget=A.capi.ALCH_GAD_BASE2)
+        a = g.upload(np.stack([to_aos(c) for c in case["cta"]["c"]]))
+        b = g.upload(np.stack([to_aos(c) for c in case["ctb"]["c"]]))
+        out = g.alloc(2)
+        g.ct_mul_relin(hint, a, b, out, 1, s_pre=case["s_pre"], flags=A.capi.ALCH_POW_IN | A.capi.ALCH_POW_OUT)
+        assert [from_aos(e) for e in out.download()] == case["out"]["c"]
+
+
+@pytest.mark.parametrize("logn,qs,batch", [
+    (4, ARITH_QS[:2], 3), (8, ARITH_QS, 2), (11, CFG3_QS[:2], 3), (11, [65537, 786433, 2147352577], 2),
+    (13, CFG3_QS, 1), (15, CFG3_QS, 1), (10, [1152921504606748673, 1152921504606683137], 2),
+])
+def test_base2_key_switch_matches_oracle(oracle_lib, logn, qs, batch):
+    import alchemy_amd as A
+    n, L = 1 << logn, len(qs)
+    rng = np.random.default_rng(8000 + logn)
+    g = A.Ring(2 * n, qs)
+    D = g.gadget_digits(A.capi.ALCH_GAD_BASE2)
+    assert D == sum((q - 1).bit_length() for q in qs)
+
+    def rand(count):
+        return np.stack([np.stack([rng.integers(0, q, size=n, dtype=np.int64) for q in qs], axis=1) for _ in range(count)])
+
+    hint, a, b = rand(2 * D), rand(2 * batch), rand(2 * batch)
+    gh = g.hint_load(hint, gadget=A.capi.ALCH_GAD_BASE2)
+    ga, gb, gout = g.upload(a), g.upload(b), g.alloc(2 * batch)
+    s_pre = [pow(7, -1, q) for q in qs]
+    g.ct_mul_relin(gh, ga, gb, gout, batch, s_pre=s_pre)
+    got = gout.download()
+    for ct in range(batch):
+        w0, w1 = oracle_mul_relin_base2(oracle_lib, n, qs, list(hint), a[2 * ct], a[2 * ct + 1], b[2 * ct], b[2 * ct + 1],
+                                        s_pre=s_pre)
+        assert np.array_equal(got[2 * ct], w0) and np.array_equal(got[2 * ct + 1], w1), f"mismatch ct {ct}"

@@ -162,3 +162,16 @@ def test_full_mul_composition_matches_model(oracle_lib):
         s = [pow(p, -1, q) for q in qs_h[L - l_in:]]          # fresh encryptions are LSD; modSwitch's toMSD
         r0, r1 = oracle_full_mul(oracle_lib, n, qs_h, l_in, l_out, hint, x[0], x[1], y[0], y[1], s_pre=s, pow_out=True)
         assert [from_aos(r0), from_aos(r1)] == case["result"]["c"]
+
+
+def test_base2_key_switch_composition_matches_model(oracle_lib):
+    """helpers.oracle_mul_relin_base2 (the checker of the BaseBGad device path) against the exact model's fixture."""
+    from helpers import oracle_mul_relin_base2
+    for case in load_golden("mul_relin_base2_small.json")["cases"]:
+        n, qs = case["n"], case["qs"]
+        o = oracle_lib.Ring(n, qs)
+        a = [o.crt(to_aos(c)) for c in case["cta"]["c"]]
+        b = [o.crt(to_aos(c)) for c in case["ctb"]["c"]]
+        hint = hint_to_crt_aos(o, case["hint"])
+        r0, r1 = oracle_mul_relin_base2(oracle_lib, n, qs, hint, a[0], a[1], b[0], b[1], s_pre=case["s_pre"], pow_out=True)
+        assert [from_aos(r0), from_aos(r1)] == case["out"]["c"]
