@@ -1009,7 +1009,8 @@ static int do_mul_full(alch_ring* rh, alch_ring* rin, alch_ring* rout, const alc
     const size_t n = rh->n;
     // per pipeline: digits [chunk][L_in][n] signed | key-switched chunk [chunk][2][Lh][n] | stash [slots][ddn][n] signed
     const size_t chunk = std::min(rh->chunk, (batch + 7) / 8 * 8);
-    const unsigned slots = 512;
+    // resident workgroups of k_rescale_out (each owns a stash slot); ALCH_RS_SLOTS: test knob
+    static const unsigned slots = getenv("ALCH_RS_SLOTS") ? (unsigned)std::max(1, atoi(getenv("ALCH_RS_SLOTS"))) : 512u;
     const size_t dig_bytes = chunk * (size_t)rin->L * n * sizeof(SW);
     const size_t ks_bytes = chunk * 2 * (size_t)rh->L * n * sizeof(W);
     const size_t stash_bytes = (size_t)slots * (size_t)ddn * n * sizeof(SW);

@@ -49,3 +49,40 @@ def test_launch_structure_does_not_change_results(env, logn, batch):
                          text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.strip().endswith("OK")
+
+
+WORKER_FULL = textwrap.dedent("""
+    import os, sys, numpy as np
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+    import alchemy_amd as A
+    from oracle import cref
+    from helpers import oracle_full_mul
+    qs_h = [2144468993, 2147352577, 2146959361, 2146041857, 2145976321]      # all = 1 mod 2^16
+    logn, batch = int(sys.argv[1]), int(sys.argv[2])
+    n = 1 << logn
+    rin, rh, rout = A.Ring(2 * n, qs_h[1:]), A.Ring(2 * n, qs_h), A.Ring(2 * n, qs_h[2:])
+    rng = np.random.default_rng(6)
+    rnd = lambda c, qs: np.stack([np.stack([rng.integers(0, q, size=n, dtype=np.int64) for q in qs], axis=1) for _ in range(c)])
+    hint, a, b = rnd(10, qs_h), rnd(2 * batch, qs_h[1:]), rnd(2 * batch, qs_h[1:])
+    gh, ga, gb, gout = rh.hint_load(hint), rin.upload(a), rin.upload(b), rout.alloc(2 * batch)
+    A.capi.ct_mul_full(gh, ga, gb, gout, batch)
+    got = gout.download()
+    for ct in range(batch):
+        w0, w1 = oracle_full_mul(cref, n, qs_h, 4, 3, list(hint), a[2*ct], a[2*ct+1], b[2*ct], b[2*ct+1])
+        assert np.array_equal(got[2*ct], w0) and np.array_equal(got[2*ct+1], w1), ct
+    print("OK")
+""" % (ROOT, ROOT))
+
+
+@pytest.mark.parametrize("env,logn,batch", [
+    ({"ALCH_CHUNK": "8"}, 11, 37),                              # 5 chunks on two streams, ragged last chunk
+    ({"ALCH_CHUNK": "8", "ALCH_ONE_STREAM": "1"}, 11, 21),
+    ({"ALCH_CHUNK": "16", "ALCH_KS_GRID": "24", "ALCH_RS_SLOTS": "5"}, 11, 40),   # persistent grids smaller than the item counts
+    ({"ALCH_CHUNK": "8", "ALCH_RS_SLOTS": "3", "ALCH_TI_GRID": "8"}, 15, 9),
+])
+def test_full_mul_launch_structure_does_not_change_results(env, logn, batch):
+    e = dict(os.environ, **env)
+    out = subprocess.run([sys.executable, "-c", WORKER_FULL, str(logn), str(batch)], env=e, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.strip().endswith("OK")
