@@ -151,6 +151,8 @@ __global__ void k_decompose_triv(DevRing<W> R, const W* c, W* digits) {
     const size_t n = (size_t)1 << R.logn;
     const size_t L = (size_t)R.L;
     const size_t total = L * L * n;
+    c += (size_t)blockIdx.y * L * n;                       // blockIdx.y: which ring element
+    digits += (size_t)blockIdx.y * total;
     for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < total; w += (size_t)gridDim.x * blockDim.x) {
         const size_t k = w % n, j = (w / n) % L, i = w / (n * L);
         const W qi = R.mod[i].q, qj = R.mod[j].q;
@@ -348,8 +350,8 @@ static int validate_ring_args(uint32_t m, int L, const uint64_t* q, int* logn_ou
             if (q[i] == q[j]) return fail(ALCH_E_INVALID, "RNS moduli must be distinct");
     }
     const int word = all32 ? 4 : 8;
-    const int maxlog = all32 ? 15 : 14;
-    if (logn > maxlog) return fail(ALCH_E_UNSUPPORTED, "ring dimension exceeds one LDS-resident transform (n <= 2^15 for 32-bit, 2^14 for 64-bit residues)");
+    const int maxlog = all32 ? 16 : 15;        // the top size of each word runs as two LDS-resident halves
+    if (logn > maxlog) return fail(ALCH_E_UNSUPPORTED, "ring dimension too large (n <= 2^16 for 32-bit, 2^15 for 64-bit residues)");
     *logn_out = logn;
     *word_out = word;
     return ALCH_OK;
@@ -487,11 +489,13 @@ static hipError_t dispatch(int logn, const NttCall<u32>& c) {
     if (logn <= 9) return dispatch32_small(logn, c);
     if (logn <= 13) return dispatch32_mid(logn, c);
     if (logn == 14) return dispatch32_14(logn, c);
-    return dispatch32_15(logn, c);
+    if (logn == 15) return dispatch32_15(logn, c);
+    return dispatch32_16(logn, c);
 }
 static hipError_t dispatch(int logn, const NttCall<u64>& c) {
     if (logn <= 11) return dispatch64_small(logn, c);
-    return dispatch64_big(logn, c);
+    if (logn <= 14) return dispatch64_big(logn, c);
+    return dispatch64_15(logn, c);
 }
 
 template <typename W>
@@ -876,15 +880,19 @@ extern "C" int alch_hint_free(alch_hint* h) {
 // ------------------------------------------------------------------------------------------------------
 // the hot path
 // ------------------------------------------------------------------------------------------------------
-// keySwitchQuadCirc hint (a * b) for a BaseBGad 2 hint (PT2CT.hs:140; Tunnel.hs:24 / HomomRLWR.hs:46 pick it):
-// D = sum_i ceil(log2 q_i) digits, each reduced into every limb and transformed -- D*L crt per ciphertext against
-// L*(L-1) for TrivGad, so the op is two orders of magnitude heavier by construction and is run unfused:
-// element-wise tensor product, batched crtInv of c2, decompose, batched crt of the digits, hint inner product.
+// keySwitchQuadCirc hint (a * b), unfused: element-wise tensor product, batched crtInv of c2, decompose, batched crt
+// of the digits, hint inner product.  Serves
+//   * BaseBGad 2 hints (PT2CT.hs:140; Tunnel.hs:24 / HomomRLWR.hs:46 pick that gadget): D = sum_i ceil(log2 q_i)
+//     digits, each reduced into every limb and transformed -- D*L crt per ciphertext against L*(L-1) for TrivGad,
+//     two orders of magnitude heavier by construction;
+//   * TrivGad on rings too large for one LDS-resident transform (n = 2^16 / 2^15), where the fused kernels do
+//     not exist and crt runs as k_crt_split.
 template <typename W>
-static int do_mul_relin_base2(alch_ring* r, const alch_hint* hint, const void* a, const void* b, void* out, size_t batch,
-                              const uint64_t* s_pre) {
+static int do_mul_relin_unfused(alch_ring* r, const alch_hint* hint, const void* a, const void* b, void* out, size_t batch,
+                                const uint64_t* s_pre) {
     Scal<u32> first, kd;
-    const u32 D = (u32)base2_layout(r, first, kd);
+    const bool base2 = hint->gadget == ALCH_GAD_BASE2;
+    const u32 D = base2 ? (u32)base2_layout(r, first, kd) : (u32)r->L;
     const size_t eb = elem_bytes(r);
     // scratch: c2 (1 element) + digits (D elements) per ciphertext of a chunk, at most ~1 GiB
     size_t chunk = std::max<size_t>(1, ((size_t)1 << 30) / ((D + 1) * eb));
@@ -906,9 +914,18 @@ static int do_mul_relin_base2(alch_ring* r, const alch_hint* hint, const void* a
                            (W*)c2, now, sr2);
         HIP_TRY(hipGetLastError());
         if ((rc = do_crt<W>(r, c2, 0, now, true)) != ALCH_OK) return rc;
-        hipLaunchKernelGGL((k_decompose_base2<W>), dim3(ew_grid(elem_words(r)), (unsigned)now), dim3(256), 0, r->stream,
-                           dev_ring<W>(r), (const W*)c2, (W*)dig, first, kd, D);
-        HIP_TRY(hipGetLastError());
+        for (size_t y0 = 0; y0 < now; y0 += 32768) {             // grid.y is 16-bit
+            const unsigned ny = (unsigned)std::min<size_t>(32768, now - y0);
+            const W* src = reinterpret_cast<const W*>(c2 + y0 * eb);
+            W* dst = reinterpret_cast<W*>(dig + y0 * D * eb);
+            if (base2)
+                hipLaunchKernelGGL((k_decompose_base2<W>), dim3(ew_grid(elem_words(r)), ny), dim3(256), 0, r->stream,
+                                   dev_ring<W>(r), src, dst, first, kd, D);
+            else
+                hipLaunchKernelGGL((k_decompose_triv<W>), dim3(ew_grid((size_t)r->L * elem_words(r)), ny), dim3(256), 0,
+                                   r->stream, dev_ring<W>(r), src, dst);
+            HIP_TRY(hipGetLastError());
+        }
         if ((rc = do_crt<W>(r, dig, 0, now * D, false)) != ALCH_OK) return rc;
         hipLaunchKernelGGL((k_hint_mac<W>), dim3(ew_grid(words)), dim3(256), 0, r->stream, dev_ring<W>(r), po, (const W*)dig,
                            (const W*)hint->dptr, now, D);
@@ -916,6 +933,9 @@ static int do_mul_relin_base2(alch_ring* r, const alch_hint* hint, const void* a
     }
     return ALCH_OK;
 }
+
+// rings whose limb-polynomial does not fit one LDS-resident transform (k_crt_split)
+static bool split_ring(const alch_ring* r) { return r->logn > (r->word == 4 ? 15 : 14); }
 
 template <typename W>
 static int do_mul_relin(alch_ring* r, const alch_hint* hint, const void* a, const void* b, void* out, size_t batch,
@@ -989,9 +1009,9 @@ extern "C" int alch_ct_mul_relin(alch_ring* r, const alch_hint* hint, const alch
         pa = wa;
         pb = wb;
     }
-    if (hint->gadget == ALCH_GAD_BASE2)
-        rc = r->word == 4 ? do_mul_relin_base2<u32>(r, hint, pa, pb, out->dptr, batch, s_pre)
-                          : do_mul_relin_base2<u64>(r, hint, pa, pb, out->dptr, batch, s_pre);
+    if (hint->gadget == ALCH_GAD_BASE2 || split_ring(r))
+        rc = r->word == 4 ? do_mul_relin_unfused<u32>(r, hint, pa, pb, out->dptr, batch, s_pre)
+                          : do_mul_relin_unfused<u64>(r, hint, pa, pb, out->dptr, batch, s_pre);
     else
         rc = r->word == 4 ? do_mul_relin<u32>(r, hint, pa, pb, out->dptr, batch, s_pre)
                           : do_mul_relin<u64>(r, hint, pa, pb, out->dptr, batch, s_pre);
@@ -1106,6 +1126,7 @@ extern "C" int alch_ct_mul_full(const alch_hint* hint, const alch_buf* a, const 
     if (!is_suffix_ring(rin, rh)) return fail(ALCH_E_INVALID, "operand moduli must be the last limbs of the hint's ring (same word size)");
     if (!is_suffix_ring(rout, rh)) return fail(ALCH_E_INVALID, "output moduli must be the last limbs of the hint's ring (same word size)");
     if (rh->L - rout->L > MAXDROP) return fail(ALCH_E_UNSUPPORTED, "at most 3 limbs dropped per call");
+    if (split_ring(rh)) return fail(ALCH_E_UNSUPPORTED, "fused mul_ needs n <= 2^15 (32-bit) / 2^14 (64-bit); compose it from alch_ct_mul_relin and alch_buf_rescale_*");
     if (flags & ~(unsigned)ALCH_POW_OUT) return fail(ALCH_E_UNSUPPORTED, "only ALCH_POW_OUT is accepted");
     if (batch == 0) return ALCH_OK;
     if (a->n_elems < 2 * batch || b->n_elems < 2 * batch || out->n_elems < 2 * batch)

@@ -1,0 +1,132 @@
+// k_crt_split: Tensor crt / crtInv for a ring twice as large as one LDS-resident transform
+// (n = 2^16 with 32-bit residues, n = 2^15 with 64-bit residues: a limb-polynomial is 256 KiB).
+//
+// After stage 0 of the merged-twist Cooley-Tukey transform the two halves of the data are independent
+// sub-transforms of size n/2 that use the big ring's twiddles tw[(2 + half) << s + h]  (ntt_pass `prefix`);
+// the inverse runs the same thing backwards.  One workgroup owns one limb-polynomial and works IN PLACE:
+//   crt    : stage 0 from HBM (x, y) -> (x + w y) into LDS, (x - w y) back to HBM in place;
+//            half 0: LDS sub-transform -> store;  half 1: reload, LDS sub-transform -> store.
+//   crtInv : half 0: load, LDS inverse sub-transform (no n^-1), store in place;  half 1: load, inverse
+//            sub-transform, result stays in LDS;  stage 0 + n^-1: a from HBM, b from LDS -> both halves.
+// Every HBM word a lane re-reads was written by that same lane (same index pattern), so no cross-lane
+// ordering is needed.  Traffic: 1.5 reads + 1.5 writes of the polynomial instead of 1 + 1.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ntt_engine.hpp"
+
+namespace alch {
+
+template <int LOGN, typename W, bool INVERSE>
+__global__ void __launch_bounds__(Geo<LOGN - 1>::T) k_crt_split(DevRing<W> R, W* __restrict__ data, size_t first_poly) {
+    constexpr int LOGM = LOGN - 1;
+    typedef Geo<LOGM> G;
+    typedef typename Vec4<W>::type V;
+    constexpr int VL = Vec4<W>::LANES;
+    constexpr int M = G::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W* lds = reinterpret_cast<W*>(smem);
+    const size_t p = first_poly + blockIdx.x;
+    const int j = (int)(p % (size_t)R.L);
+    W* lo = data + p * (size_t)(2 * M);
+    W* hi = lo + M;
+    const ModP<W> m = R.mod[j];
+    const W q = m.q, qni = m.qni;
+    const int tid = threadIdx.x;
+
+    if constexpr (!INVERSE) {
+        const W w1 = R.twf[j][1];
+#pragma unroll
+        for (int r = 0; r < G::E / VL; ++r) {
+            const int idx = (tid + G::T * r) * VL;
+            const V x = *reinterpret_cast<const V*>(lo + idx), y = *reinterpret_cast<const V*>(hi + idx);
+            V u0, u1;
+#pragma unroll
+            for (int e = 0; e < VL; ++e) {
+                const W t = csub(mont_mul_lazy(y[e], w1, q, qni), q);
+                u0[e] = x[e] + t;                                   // inputs are reduced: [0, 2q)
+                u1[e] = csub((W)(x[e] + (q - t)), q);               // stored reduced
+            }
+            *reinterpret_cast<V*>(&lds[swz<LOGM>(idx)]) = u0;
+            *reinterpret_cast<V*>(hi + idx) = u1;
+        }
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            W* dst = half ? hi : lo;
+            if (half) {
+                stage_in<LOGM, W>(lds, [&](int idx) { return *reinterpret_cast<const V*>(hi + idx); });
+            }
+            lds_barrier();
+            int t2 = tid;
+            asm volatile("" : "+v"(t2));
+            ntt_forward<LOGM, W, false>(lds, fwd_tw(R, j), R.twf[j], q, qni, t2, NoEpilogue(), 2 + half);
+#pragma unroll
+            for (int r = 0; r < G::E / VL; ++r) {
+                const int idx = (t2 + G::T * r) * VL;
+                V v = *reinterpret_cast<const V*>(&lds[swz<LOGM>(idx)]);
+#pragma unroll
+                for (int e = 0; e < VL; ++e) v[e] = csub(v[e], q);
+                *reinterpret_cast<V*>(dst + idx) = v;
+            }
+            lds_barrier();                      // LDS is refilled by other lanes' loads next
+        }
+    } else {
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const W* src = half ? hi : lo;
+            stage_in<LOGM, W>(lds, [&](int idx) { return *reinterpret_cast<const V*>(src + idx); });
+            lds_barrier();
+            int t2 = tid;
+            asm volatile("" : "+v"(t2));
+            ntt_inverse<LOGM, W, false, false, false>(lds, R.twi[j], q, qni, (W)0, (W)0, t2, NoEpilogue(), NoHook(), 2 + half);
+            if (half == 0) {
+#pragma unroll
+                for (int r = 0; r < G::E / VL; ++r) {
+                    const int idx = (t2 + G::T * r) * VL;
+                    V v = *reinterpret_cast<const V*>(&lds[swz<LOGM>(idx)]);
+#pragma unroll
+                    for (int e = 0; e < VL; ++e) v[e] = csub(v[e], q);
+                    *reinterpret_cast<V*>(lo + idx) = v;
+                }
+                lds_barrier();
+            }
+        }
+        // stage 0 with n^-1 folded in: c[k] = (a + b) n^-1,  c[k + n/2] = (a - b) tw_inv[1] n^-1
+        const W ninv = R.ninv_m[j], w1ninv = R.w1ninv_m[j];
+#pragma unroll
+        for (int r = 0; r < G::E / VL; ++r) {
+            const int idx = (tid + G::T * r) * VL;
+            const V a = *reinterpret_cast<const V*>(lo + idx);
+            const V bb = *reinterpret_cast<const V*>(&lds[swz<LOGM>(idx)]);
+            V c0, c1;
+#pragma unroll
+            for (int e = 0; e < VL; ++e) {
+                const W b = csub(bb[e], q);
+                c0[e] = csub(mont_mul_lazy((W)(a[e] + b), ninv, q, qni), q);
+                c1[e] = csub(mont_mul_lazy((W)(a[e] - b + q), w1ninv, q, qni), q);
+            }
+            *reinterpret_cast<V*>(lo + idx) = c0;
+            *reinterpret_cast<V*>(hi + idx) = c1;
+        }
+    }
+}
+
+template <typename W, int LOGN>
+inline hipError_t run_call_split(const NttCall<W>& c) {
+    typedef Geo<LOGN - 1> G;
+    const size_t lds_bytes = (size_t)G::N * sizeof(W);
+    hipError_t e;
+    if (c.op == OP_CRT) {
+        auto k = k_crt_split<LOGN, W, false>;
+        if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(G::T), lds_bytes, c.stream, *c.ring, c.data, c.first_poly);
+    } else if (c.op == OP_CRTINV) {
+        auto k = k_crt_split<LOGN, W, true>;
+        if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(G::T), lds_bytes, c.stream, *c.ring, c.data, c.first_poly);
+    } else {
+        return hipErrorInvalidValue;        // the fused kernels exist for LDS-resident sizes only
+    }
+    return hipGetLastError();
+}
+
+}  // namespace alch

@@ -508,5 +508,7 @@ hipError_t dispatch32_14(int logn, const NttCall<u32>& c);
 hipError_t dispatch32_15(int logn, const NttCall<u32>& c);
 hipError_t dispatch64_small(int logn, const NttCall<u64>& c);   // 4..11
 hipError_t dispatch64_big(int logn, const NttCall<u64>& c);     // 12..14
+hipError_t dispatch32_16(int logn, const NttCall<u32>& c);      // split transform: crt / crtInv only
+hipError_t dispatch64_15(int logn, const NttCall<u64>& c);
 
 }  // namespace alch

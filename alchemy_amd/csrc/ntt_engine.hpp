@@ -219,7 +219,10 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const TW* __restri
 // and stop the compiler from hoisting every pass's LDS addresses out of its loop).
 // Callers must __syncthreads() after filling LDS; the function syncs between passes.
 template <int LOGN, typename W, bool KEEP_LAST, bool SERIAL = false, typename TW, typename Epi>
-__device__ __forceinline__ void ntt_forward(W* lds, const TW* tw, const W* twm, W q, W qni, int tid, Epi&& epi) {
+__device__ __forceinline__ void ntt_forward(W* lds, const TW* tw, const W* twm, W q, W qni, int tid, Epi&& epi,
+                                            int prefix = 1) {
+    // prefix != 1: the transform is one half of a transform twice its size whose stage 0 ran elsewhere
+    // (k_crt_split); tw / twm are then the tables of the big ring.
     // tw : twiddle table for the passes whose twiddles are shared by many lanes (Plantard constants on 32-bit
     //      rings: one instruction less per butterfly, fetched by scalar or broadcast loads);
     // twm: Montgomery table for the last pass, where every lane needs its own 15 twiddles and two-word
@@ -228,21 +231,21 @@ __device__ __forceinline__ void ntt_forward(W* lds, const TW* tw, const W* twm, 
     constexpr int P = G::NPASS, F = G::NS0, LT = G::LOGT;
     NoEpilogue none;
     if constexpr (P == 1) {
-        ntt_pass<LOGN, LT, W, 0, F, false, KEEP_LAST, SERIAL>(lds, twm, q, qni, (W)0, (W)0, tid, 1, epi);
+        ntt_pass<LOGN, LT, W, 0, F, false, KEEP_LAST, SERIAL>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, epi);
     } else {
-        ntt_pass<LOGN, LT, W, 0, F, false, false, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, 1, none);
+        ntt_pass<LOGN, LT, W, 0, F, false, false, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, prefix, none);
         lds_barrier();
         if constexpr (P == 2) {
-            ntt_pass<LOGN, LT, W, F, 4, false, KEEP_LAST, SERIAL>(lds, twm, q, qni, (W)0, (W)0, tid, 1, epi);
+            ntt_pass<LOGN, LT, W, F, 4, false, KEEP_LAST, SERIAL>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, epi);
         } else {
-            ntt_pass<LOGN, LT, W, F, 4, false, false, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, 1, none);
+            ntt_pass<LOGN, LT, W, F, 4, false, false, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, prefix, none);
             lds_barrier();
             if constexpr (P == 3) {
-                ntt_pass<LOGN, LT, W, F + 4, 4, false, KEEP_LAST, SERIAL>(lds, twm, q, qni, (W)0, (W)0, tid, 1, epi);
+                ntt_pass<LOGN, LT, W, F + 4, 4, false, KEEP_LAST, SERIAL>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, epi);
             } else {
-                ntt_pass<LOGN, LT, W, F + 4, 4, false, false, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, 1, none);
+                ntt_pass<LOGN, LT, W, F + 4, 4, false, false, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, prefix, none);
                 lds_barrier();
-                ntt_pass<LOGN, LT, W, F + 8, 4, false, KEEP_LAST, SERIAL>(lds, twm, q, qni, (W)0, (W)0, tid, 1, epi);
+                ntt_pass<LOGN, LT, W, F + 8, 4, false, KEEP_LAST, SERIAL>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, epi);
             }
         }
     }
@@ -258,9 +261,11 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // the transform issues no vector-memory loads, so global loads started in the hook (a prefetch for the next
 // work item) are never waited for by this transform -- vmcnt retires in order, and a later twiddle load would
 // otherwise drag the whole prefetch's HBM latency into the pass.
-template <int LOGN, typename W, bool KEEP_LAST, bool SERIAL = false, typename Epi, typename Hook = NoHook>
+template <int LOGN, typename W, bool KEEP_LAST, bool SERIAL = false, bool FOLD = true, typename Epi, typename Hook = NoHook>
 __device__ __forceinline__ void ntt_inverse(W* lds, const W* twi, W q, W qni, W ninv_m, W w1ninv_m, int tid,
-                                            Epi&& epi, Hook&& hook = NoHook()) {
+                                            Epi&& epi, Hook&& hook = NoHook(), int prefix = 1) {
+    // FOLD = false, prefix = 2 + half: the stages 1.. of a transform twice this size on one half of its slots
+    // (k_crt_split); the caller runs stage 0 and the n^-1 scaling itself.
     typedef Geo<LOGN> G;
     constexpr int P = G::NPASS, F = G::NS0, LT = G::LOGT;
     NoEpilogue none;
@@ -268,13 +273,13 @@ __device__ __forceinline__ void ntt_inverse(W* lds, const W* twi, W q, W qni, W 
     constexpr bool U3 = (LOGN - (F + 8) - 4 >= 6), U2 = (LOGN - (F + 4) - 4 >= 6), U1 = (LOGN - F - 4 >= 6);
     bool hooked = false;
     if constexpr (P >= 4) { if (U3 && !hooked) { hook(); hooked = true; }
-        ntt_pass<LOGN, LT, W, F + 8, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, none); lds_barrier(); }
+        ntt_pass<LOGN, LT, W, F + 8, 4, true, false, SERIAL, W, NoEpilogue&, FOLD>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, prefix, none); lds_barrier(); }
     if constexpr (P >= 3) { if (U2 && !hooked) { hook(); hooked = true; }
-        ntt_pass<LOGN, LT, W, F + 4, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, none); lds_barrier(); }
+        ntt_pass<LOGN, LT, W, F + 4, 4, true, false, SERIAL, W, NoEpilogue&, FOLD>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, prefix, none); lds_barrier(); }
     if constexpr (P >= 2) { if (U1 && !hooked) { hook(); hooked = true; }
-        ntt_pass<LOGN, LT, W, F, 4, true, false, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, none); lds_barrier(); }
+        ntt_pass<LOGN, LT, W, F, 4, true, false, SERIAL, W, NoEpilogue&, FOLD>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, prefix, none); lds_barrier(); }
     if (!hooked) hook();
-    ntt_pass<LOGN, LT, W, 0, F, true, KEEP_LAST, SERIAL>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, 1, epi);
+    ntt_pass<LOGN, LT, W, 0, F, true, KEEP_LAST, SERIAL, W, Epi&, FOLD>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, prefix, epi);
     if constexpr (!KEEP_LAST) lds_barrier();
 }
 

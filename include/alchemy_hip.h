@@ -68,7 +68,10 @@ uint32_t alch_version(void);
  * Replaces the per-call twiddle/modulus arguments lol-cpp receives from Haskell; built once per
  * (index, modulus-list) type, i.e. once per `Cyc t m' zq` instance (PT2CT.hs:251-254).
  * m = cyclotomic index (2n).  Validates q prime and q == 1 mod m (else ALCH_E_NO_CRT, the CRTrans
- * failure of Lol's crtFuncs), builds device-resident twiddle tables with the root rule above. */
+ * failure of Lol's crtFuncs), builds device-resident twiddle tables with the root rule above.
+ * Sizes: 32 <= m <= 2^17 (n <= 2^16) when every q < 2^31, m <= 2^16 (n <= 2^15) otherwise.  The largest size
+ * of each word runs its transforms as two LDS-resident halves and the key switch unfused; the fused
+ * kernels of alch_ct_mul_relin / alch_ct_mul_full cover n <= 2^15 (32-bit) / 2^14 (64-bit). */
 int alch_ring_create(uint32_t m, int L, const uint64_t *q, alch_ring **out);
 int alch_ring_destroy(alch_ring *ring);
 /* Host-only (no GPU needed): the root-rule constants of one modulus, for cross-checking against the

@@ -23,10 +23,14 @@ def _ring_pair(oracle_lib, n, qs):
     return A.Ring(2 * n, qs), oracle_lib.Ring(n, qs)
 
 
-@pytest.mark.parametrize("logn", [4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
+# = 1 mod 2^17: the synthetic two-power stand-ins for BASELINE configs 4 / 5
+SIX_QS_17 = [2147352577, 2146959361, 2146041857, 2144468993, 2142502913, 2135818241]
+
+
+@pytest.mark.parametrize("logn", [4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
 def test_crt_crtinv_match_oracle(oracle_lib, logn):
     n = 1 << logn
-    qs = CFG3_QS[:3] if logn > 8 else ARITH_QS
+    qs = SIX_QS_17[:3] if logn == 16 else CFG3_QS[:3] if logn > 8 else ARITH_QS
     g, o = _ring_pair(oracle_lib, n, qs)
     rng = np.random.default_rng(100 + logn)
     x = _rand_elems(rng, 3, n, qs)
@@ -46,10 +50,10 @@ def test_crt_crtinv_match_oracle(oracle_lib, logn):
         assert np.array_equal(got[e], o.crtinv(y[e]))
 
 
-@pytest.mark.parametrize("logn", [4, 8, 14])
+@pytest.mark.parametrize("logn", [4, 8, 14, 15])
 def test_crt_60bit(oracle_lib, logn):
     n = 1 << logn
-    qs = [CFG2_Q60]
+    qs = [1152921504606584833 if logn == 15 else CFG2_Q60]          # = 1 mod 2^16 for n = 2^15 (split transform)
     g, o = _ring_pair(oracle_lib, n, qs)
     assert g.word_bytes == 8
     rng = np.random.default_rng(7)
@@ -99,12 +103,16 @@ def _mul_relin_case(oracle_lib, n, qs, batch, seed, s_pre=None, pow_basis=False)
     (11, UNBAL_QS, 3), (15, UNBAL_QS, 2), (8, [1073750017, 8392193], 2),
     # limb-count extremes on the two-workgroup kernel: one limb (no digit transform at all) and the maximum of 8
     (15, CFG3_QS[:1], 3), (11, CFG3_QS[:1], 9), (11, EIGHT_QS, 2), (11, EIGHT_SMALL_QS, 3),
+    # n = 2^16: split transforms + unfused key switch (configs 4 / 5 stand-in: six primes = 1 mod 2^17)
+    (16, SIX_QS_17, 2), (16, SIX_QS_17[:2], 3),
+    (15, [1152921504606584833, 1152921504598720513], 2),      # 60-bit residues, n = 2^15: the same on 8-byte words
 ])
 def test_ct_mul_relin_crt_basis(oracle_lib, logn, qs, batch):
     _mul_relin_case(oracle_lib, 1 << logn, qs, batch, seed=1000 + logn)
 
 
-@pytest.mark.parametrize("logn,qs,batch", [(4, ARITH_QS, 2), (8, ARITH_QS, 3), (12, CFG3_QS, 1), (15, CFG3_QS, 1)])
+@pytest.mark.parametrize("logn,qs,batch", [(4, ARITH_QS, 2), (8, ARITH_QS, 3), (12, CFG3_QS, 1), (15, CFG3_QS, 1),
+                                           (16, SIX_QS_17[:3], 1)])
 def test_ct_mul_relin_pow_basis(oracle_lib, logn, qs, batch):
     _mul_relin_case(oracle_lib, 1 << logn, qs, batch, seed=2000 + logn, pow_basis=True)
 
