@@ -85,7 +85,8 @@ def test_ring_argument_validation_precedes_device_probe():
                        ((48, [ARITH_QS[0]]), capi.ALCH_E_UNSUPPORTED),        # index not a power of two
                        ((16, [ARITH_QS[0]]), capi.ALCH_E_UNSUPPORTED),        # n < 16
                        ((1 << 17, [CFG3_QS[3]]), capi.ALCH_E_NO_CRT),         # 2145976321 is 1 mod 2^16 only
-                       ((1 << 17, [CFG3_QS[0]]), capi.ALCH_E_UNSUPPORTED),    # n = 2^16 exceeds one LDS-resident transform
+                       ((1 << 18, [2146959361]), capi.ALCH_E_UNSUPPORTED),    # n = 2^17: beyond the split transform (32-bit words)
+                       ((1 << 17, [1152921504606584833]), capi.ALCH_E_UNSUPPORTED),   # n = 2^16 with 64-bit words
                        ((512, [ARITH_QS[0], ARITH_QS[0]]), capi.ALCH_E_INVALID),
                        ((512, []), capi.ALCH_E_INVALID)]:
         with pytest.raises(A.AlchemyError) as e:
