@@ -24,7 +24,7 @@ SYMBOLS = [
     "alch_buf_elems", "alch_buf_upload", "alch_buf_download", "alch_buf_fill_uniform", "alch_buf_crt",
     "alch_buf_crtinv", "alch_buf_mul", "alch_buf_add", "alch_buf_checksum", "alch_hint_load", "alch_hint_from_buf",
     "alch_hint_free", "alch_ct_mul_relin", "alch_buf_rescale_drop0", "alch_buf_sub", "alch_buf_scale",
-    "alch_buf_decompose_triv", "alch_buf_rescale_add0", "alch_decompose_base2", "alch_ct_mul_full",
+    "alch_buf_decompose_triv", "alch_buf_rescale_add0", "alch_decompose_base2", "alch_ct_mul_full", "alch_buf_device_ptr",
 ]
 
 
@@ -111,6 +111,7 @@ def load_library():
         "alch_hint_free": [VP],
         "alch_ct_mul_relin": [VP, VP, VP, VP, VP, C.c_size_t, PU64, C.c_uint],
         "alch_ct_mul_full": [VP, VP, VP, VP, C.c_size_t, PU64, C.c_uint],
+        "alch_buf_device_ptr": [VP, C.POINTER(VP), C.POINTER(C.c_size_t)],
         "alch_buf_rescale_drop0": [VP, VP, C.c_size_t],
         "alch_buf_rescale_add0": [VP, VP, C.c_size_t],
         "alch_buf_sub": [VP, VP, VP, C.c_size_t],
@@ -306,6 +307,30 @@ class Buf:
 
     def fill_uniform(self, seed: int):
         _check(self.ring._l.alch_buf_fill_uniform(self._h, C.c_uint64(seed)))
+
+    def device_ptr(self):
+        """(address, bytes) of the device allocation."""
+        p, nb = C.c_void_p(), C.c_size_t()
+        _check(self.ring._l.alch_buf_device_ptr(self._h, C.byref(p), C.byref(nb)))
+        return int(p.value), int(nb.value)
+
+    def as_torch(self, first: int = 0, count: int | None = None):
+        """Zero-copy torch view (1-D, int32 or int64 words, limb-major) of elements [first, first+count) -- for
+        torch.distributed collectives on result batches.  The caller orders streams (Ring.sync())."""
+        import torch
+        count = self.n_elems - first if count is None else count
+        addr, _ = self.device_ptr()
+        wb = self.ring.word_bytes
+        words = count * self.ring.n * self.ring.L
+
+        class _View:                     # minimal __cuda_array_interface__ carrier
+            pass
+
+        v = _View()
+        v.__cuda_array_interface__ = {"shape": (words,), "typestr": "<i4" if wb == 4 else "<i8",
+                                      "data": (addr + first * self.ring.n * self.ring.L * wb, False), "version": 2}
+        v._keepalive = self
+        return torch.as_tensor(v, device="cuda")
 
     def crt(self, first: int = 0, count: int | None = None):
         _check(self.ring._l.alch_buf_crt(self._h, first, self.n_elems - first if count is None else count))

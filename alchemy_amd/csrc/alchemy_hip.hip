@@ -553,6 +553,13 @@ extern "C" int alch_buf_elems(const alch_buf* b, size_t* n) {
     return ALCH_OK;
 }
 
+extern "C" int alch_buf_device_ptr(const alch_buf* b, void** ptr, size_t* bytes) {
+    if (!b || !ptr) return fail(ALCH_E_INVALID, "null argument");
+    *ptr = b->dptr;
+    if (bytes) *bytes = b->n_elems * elem_bytes(b->ring);
+    return ALCH_OK;
+}
+
 template <typename W>
 static int do_transfer(alch_ring* r, void* dev, size_t count, int64_t* host, bool to_device) {
     const size_t bytes = count * elem_words(r) * sizeof(int64_t);

@@ -140,6 +140,45 @@ def main():
     ev_ms_max = shard.max_over_ranks(ev_ms, dist, red_dev)
     checksum = out.checksum(0, 2)
 
+    # The batch gather (north star: "RCCL over xGMI for the batch gather only"): after timing, every rank
+    # contributes a slice of its result batch to an all-gather, zero-copy from the library's buffer.  Reported next
+    # to the throughput, never inside it: gathering every result would be bound by xGMI ingress (7 x ~153 GB/s per
+    # GPU), far below what the ranks produce.
+    gather = None
+    if dist is not None:
+        try:
+            G_CTS = min(B, 256)                               # 256 ciphertexts = 256 MiB of device words per rank
+            mine = out.as_torch(0, 2 * G_CTS)
+            everyone = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
+            ring.sync()
+
+            def all_gather():
+                if red_dev is not None:
+                    dist.all_gather_into_tensor(everyone, mine)                  # RCCL
+                else:
+                    dist.all_gather(list(everyone.chunk(world)), mine)           # gloo rehearsal
+
+            all_gather()
+            torch.cuda.synchronize()
+            ok = bool(torch.equal(everyone[rank * mine.numel():(rank + 1) * mine.numel()], mine))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            shard.barrier(dist)
+            e0.record()
+            for _ in range(5):
+                all_gather()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = shard.max_over_ranks(e0.elapsed_time(e1) / 5, dist, red_dev)
+            nbytes = mine.numel() * mine.element_size()
+            gather = {"ciphertexts_per_rank": G_CTS, "bytes_per_rank": nbytes, "ms": ms,
+                      "ingress_GBs_per_gpu": (world - 1) * nbytes / (ms * 1e-3) / 1e9,
+                      "xgmi_ingress_bound_GBs": 7 * 153.0, "own_slice_intact": ok,
+                      "backend": "rccl" if red_dev is not None else "gloo"}
+            del everyone
+        except Exception as e:                      # noqa: BLE001 -- report, do not lose the throughput line
+            print(f"[bench] result all-gather failed: {e!r}", file=sys.stderr, flush=True)
+            gather = {"error": repr(e)}
+
     pow_ops = None
     if args.pow:
         from alchemy_amd.capi import ALCH_POW_IN, ALCH_POW_OUT
@@ -217,6 +256,7 @@ def main():
             line["pow_basis_in_out_ops_per_s"] = pow_ops
         if full is not None:
             line["full_mul"] = full
+        line["result_gather"] = gather
         if world == 1 and args.cpu_ops > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_ops)
             line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(max(8, args.cpu_ops // 4))

@@ -60,6 +60,7 @@ foreign import ccall safe   "alch_decompose_base2"     c_decomposeBase2  :: Ptr 
 foreign import ccall safe   "alch_buf_alloc"           c_bufAlloc        :: Ptr AlchRing -> CSize -> Ptr (Ptr AlchBuf) -> IO CInt
 foreign import ccall safe   "alch_buf_free"            c_bufFree         :: Ptr AlchBuf -> IO CInt
 foreign import ccall unsafe "alch_buf_elems"           c_bufElems        :: Ptr AlchBuf -> Ptr CSize -> IO CInt
+foreign import ccall unsafe "alch_buf_device_ptr"      c_bufDevicePtr    :: Ptr AlchBuf -> Ptr (Ptr ()) -> Ptr CSize -> IO CInt
 foreign import ccall safe   "alch_buf_upload"          c_bufUpload       :: Ptr AlchBuf -> CSize -> CSize -> Ptr Int64 -> IO CInt
 foreign import ccall safe   "alch_buf_download"        c_bufDownload     :: Ptr AlchBuf -> CSize -> CSize -> Ptr Int64 -> IO CInt
 foreign import ccall safe   "alch_buf_fill_uniform"    c_bufFillUniform  :: Ptr AlchBuf -> Word64 -> IO CInt

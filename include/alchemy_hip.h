@@ -120,6 +120,10 @@ int alch_decompose_base2(alch_ring *ring, const int64_t *c_pow, int64_t *digits,
 int alch_buf_alloc(alch_ring *ring, size_t n_elems, alch_buf **out);
 int alch_buf_free(alch_buf *buf);
 int alch_buf_elems(const alch_buf *buf, size_t *n_elems);
+/* Device address and size of the buffer (limb-major words, see above) for zero-copy hand-off to other device
+ * code on the same GPU -- RCCL collectives that gather result batches, a caller's own kernels.
+ * Work queued on the ring's stream must be ordered against the consumer by the caller (alch_sync or events). */
+int alch_buf_device_ptr(const alch_buf *buf, void **ptr, size_t *bytes);
 int alch_buf_upload(alch_buf *buf, size_t first, size_t count, const int64_t *host);
 int alch_buf_download(const alch_buf *buf, size_t first, size_t count, int64_t *host);
 /* Synthetic residues: word (e,j,k) = splitmix64(seed + ((e*L + j)*n + k)) mod q_j  (oracle:

@@ -122,3 +122,24 @@ def test_ct_mul_relin_with_encoding_scalar(oracle_lib):
     qs = ARITH_QS
     s = [pow(7, -1, q) for q in qs]
     _mul_relin_case(oracle_lib, 256, qs, 2, seed=77, s_pre=s)
+
+
+def test_device_pointer_view_is_the_limb_major_buffer():
+    """alch_buf_device_ptr / Buf.as_torch: the zero-copy view RCCL gathers of result batches use (bench.py)."""
+    import torch
+    import alchemy_amd as A
+    n, qs = 64, ARITH_QS
+    g = A.Ring(2 * n, qs)
+    rng = np.random.default_rng(3)
+    x = _rand_elems(rng, 3, n, qs)
+    buf = g.upload(x)
+    g.sync()
+    addr, nbytes = buf.device_ptr()
+    assert addr != 0 and nbytes == 3 * n * len(qs) * g.word_bytes
+    view = buf.as_torch(1, 2)                                  # elements 1, 2
+    want = np.ascontiguousarray(np.transpose(x[1:], (0, 2, 1))).reshape(-1)      # [elem][limb][coefficient]
+    assert np.array_equal(view.cpu().numpy().astype(np.int64), want)
+    view.zero_()                                               # writes through to the library's buffer
+    torch.cuda.synchronize()
+    got = buf.download()
+    assert np.array_equal(got[0], x[0]) and not got[1:].any()
