@@ -221,9 +221,10 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
                 const W c2 = csub(mont_mul_lazy(v[3][e], x1, q, qni), q);           // a1 b1 s
                 // sums of two products (< 2 q^2 < 2^32 q) share one Montgomery reduction
                 acc0[s * 4 + e] = csub(mont_red_lazy((u64)x0 * v[2][e] + (u64)c2 * v[4][e], q, qni), q);
-                const W t1 = csub(mont_red_lazy((u64)x0 * v[3][e] + (u64)x1 * v[2][e], q, qni), q);
-                const W t2 = csub(mont_mul_lazy(c2, v[5][e], q, qni), q);
-                acc1[s * 4 + e] = csub(t1 + t2, q);
+                // three products (< 3 q^2 < 2^64): bring the high word below q first, then one reduction
+                const u64 p1 = (u64)x0 * v[3][e] + (u64)x1 * v[2][e] + (u64)c2 * v[5][e];
+                const u64 p1r = ((u64)csub((W)(p1 >> 32), q) << 32) | (u32)p1;        // high word < 1.5 q -> < q
+                acc1[s * 4 + e] = csub(mont_red_lazy(p1r, q, qni), q);
             }
             if (s + ID < EPT / 4) issue(s + ID, in[s % ID]);  // refill the buffer just consumed
             __builtin_amdgcn_sched_barrier(0);   // at most two slices of loads live

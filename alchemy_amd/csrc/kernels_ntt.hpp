@@ -202,7 +202,9 @@ k_tensor_intt(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
         const int i = (int)(item % (unsigned)L);
         const ModP<W> m = R.mod[i];
         const W q = m.q, qni = m.qni;
-        const W sr2 = spre.v[i];
+        // The scalar s (and the R that turns the Montgomery product a1 b1 R^-1 back) rides on the n^-1 constants the
+        // last inverse stage multiplies by anyway: the transform is linear.
+        const W ninv_s = mont_mul(R.ninv_m[i], spre.v[i], m), w1ninv_s = mont_mul(R.w1ninv_m[i], spre.v[i], m);
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));          // keep LDS address arithmetic inside the item loop (VGPR pressure)
 #pragma unroll
@@ -210,10 +212,7 @@ k_tensor_intt(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
             const int idx = (tid + G::T * ((r + (int)(item ^ (item >> 3))) & (NV - 1))) * VL;
             V v;
 #pragma unroll
-            for (int e = 0; e < VL; ++e) {
-                W xs = csub(mont_mul_lazy(pa[r][e], sr2, q, qni), q);     // a1 * s * R
-                v[e] = mont_mul_lazy(pb[r][e], xs, q, qni);                // a1 * b1 * s   in [0,2q)
-            }
+            for (int e = 0; e < VL; ++e) v[e] = mont_mul_lazy(pa[r][e], pb[r][e], q, qni);   // a1 b1 R^-1 in [0,2q)
             *reinterpret_cast<V*>(&lds[swz<LOGN>(idx)]) = v;
         }
         TI_STAMP(0);                            // loads + c2 + LDS write
@@ -244,12 +243,12 @@ k_tensor_intt(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
             if (item + gridDim.x < nitems) issue(item + gridDim.x);
             ntt_pass<LOGN, G::LOGT, W, 3, 4, true, false, false>(lds, twi, q, qni, R.ninv_m[i], R.w1ninv_m[i], tid, 1, none);
             TI_STAMP(2); lds_barrier(); TI_STAMP(3);
-            ntt_pass<LOGN, G::LOGT, W, 0, 3, true, true, false>(lds, twi, q, qni, R.ninv_m[i], R.w1ninv_m[i], tid, 1, epi);
+            ntt_pass<LOGN, G::LOGT, W, 0, 3, true, true, false>(lds, twi, q, qni, ninv_s, w1ninv_s, tid, 1, epi);
             TI_STAMP(4);
         } else
 #endif
         if (!(dbg & 2u))
-        ntt_inverse<LOGN, W, true>(lds, R.twi[i], q, qni, R.ninv_m[i], R.w1ninv_m[i], tid, epi,
+        ntt_inverse<LOGN, W, true>(lds, R.twi[i], q, qni, ninv_s, w1ninv_s, tid, epi,
                                    [&]() { if (item + gridDim.x < nitems) issue(item + gridDim.x); });
         lds_barrier();                       // every lane has read its last-pass inputs before LDS is refilled
         TI_STAMP(5);
