@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(Geo<LOGN - 1>::T) k_crt_split(DevRing<W> R, W*
 template <typename W, int LOGN>
 inline hipError_t run_call_split(const NttCall<W>& c) {
     typedef Geo<LOGN - 1> G;
-    const size_t lds_bytes = (size_t)G::N * sizeof(W);
+    const size_t lds_bytes = (size_t)lds_words<LOGN - 1>() * sizeof(W);
     hipError_t e;
     if (c.op == OP_CRT) {
         auto k = k_crt_split<LOGN, W, false>;

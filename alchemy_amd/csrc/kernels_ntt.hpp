@@ -398,7 +398,7 @@ template <typename W, int LOGN>
 inline hipError_t run_call(const NttCall<W>& c) {
     typedef Geo<LOGN> G;
     typedef typename Signed<W>::type SW;
-    const size_t lds_bytes = (size_t)G::N * sizeof(W);
+    const size_t lds_bytes = (size_t)lds_words<LOGN>() * sizeof(W);
     const DevRing<W>& R = *c.ring;
     hipError_t e;
     switch (c.op) {
@@ -445,7 +445,7 @@ inline hipError_t run_call(const NttCall<W>& c) {
             static const unsigned persist = getenv("ALCH_KS_GRID") ? (unsigned)atoi(getenv("ALCH_KS_GRID")) : 2048u;  // measured: 512 -> 438k, 1024 -> 447k, 2048..4096 -> 458k, one item per workgroup -> 453k op/s
             const unsigned grid = nitems < persist ? nitems : persist;
             constexpr int TH = 1 << (LOGN - 6);
-            const size_t half_lds = lds_bytes / 2;
+            const size_t half_lds = (size_t)lds_words<LOGN - 1>() * sizeof(W);
             if (c.dup > 0) {
                 if (c.balanced) {
                     auto k = k_ks_accum_half<LOGN, true, 32, true>;

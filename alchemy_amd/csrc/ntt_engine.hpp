@@ -33,13 +33,43 @@ struct Geo {
     static constexpr bool SWZ = LOGN >= 10;
 };
 
-// Logical coefficient index -> LDS word index.  Only bits >= 2 move, so aligned groups of four words
-// stay contiguous (128-bit accesses remain legal).
-// swz is linear over XOR: swz(a ^ b) = swz(a) ^ swz(b).  A pass therefore swizzles its group base once
-// and reaches element k with one XOR against the compile-time constant swz(k << LB).
+// Logical coefficient index -> LDS word index.
+// ALCH_LDS_PAD = 0: XOR swizzle, no extra LDS.  Only bits >= 2 move, so aligned groups of four words stay
+//   contiguous; linear over XOR (swz(a ^ b) = swz(a) ^ swz(b)), so a pass swizzles its group base once and
+//   reaches element k with one v_xor against the compile-time constant swz(k << LB).
+// ALCH_LDS_PAD = 1: four padding words after every 64 (LDS grows by 1/16).  Additive over operands with
+//   disjoint bits (pad(a | b) = pad(a) + pad(b)), so element k is the group base plus a compile-time constant,
+//   which the LDS instructions take as an immediate offset: no address arithmetic per access.
+// Both are bank-conflict free for the four access shapes the passes use (LB = 0: 16 contiguous words per lane,
+// 128-bit accesses; LB = 4: runs of 16 lanes 256 words apart; LB >= 6: 64 consecutive words; lane-contiguous
+// 16-byte pieces): see DESIGN.md.
+#ifndef ALCH_LDS_PAD
+#define ALCH_LDS_PAD 1
+#endif
 template <int LOGN>
 __host__ __device__ constexpr int swz(int idx) {
+#if ALCH_LDS_PAD
+    return (LOGN >= 10) ? idx + ((idx >> 6) << 2) : idx;
+#else
     return (LOGN >= 10) ? (idx ^ (((idx >> 6) & 3) << 2) ^ (((idx >> 8) & 3) << 4)) : idx;
+#endif
+}
+// address of element (base | k << LB) from the mapped base and the mapped constant
+__host__ __device__ constexpr int lds_join(int mapped_base, int mapped_k) {
+#if ALCH_LDS_PAD
+    return mapped_base + mapped_k;
+#else
+    return mapped_base ^ mapped_k;
+#endif
+}
+// words of LDS a 2^LOGN-point transform needs
+template <int LOGN>
+__host__ __device__ constexpr int lds_words() {
+#if ALCH_LDS_PAD
+    return (LOGN >= 10) ? (1 << LOGN) + (1 << (LOGN - 4)) : (1 << LOGN);
+#else
+    return 1 << LOGN;
+#endif
 }
 
 template <typename W> struct Vec4;
@@ -130,13 +160,13 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const TW* __restri
         if constexpr (LB == 0 && R >= VL) {
 #pragma unroll
             for (int k = 0; k < R; k += VL) {
-                V v = *reinterpret_cast<const V*>(&lds[sb ^ swz<LOGN>(k)]);
+                V v = *reinterpret_cast<const V*>(&lds[lds_join(sb, swz<LOGN>(k))]);
 #pragma unroll
                 for (int e = 0; e < VL; ++e) x[k + e] = v[e];
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < R; ++k) x[k] = lds[sb ^ swz<LOGN>(k << LB)];
+            for (int k = 0; k < R; ++k) x[k] = lds[lds_join(sb, swz<LOGN>(k << LB))];
         }
         // ---- butterflies
         const int gm = (prefix << S0) + h;
@@ -197,11 +227,11 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const TW* __restri
                     V v;
 #pragma unroll
                     for (int e = 0; e < VL; ++e) v[e] = x[k + e];
-                    *reinterpret_cast<V*>(&lds[sb ^ swz<LOGN>(k)]) = v;
+                    *reinterpret_cast<V*>(&lds[lds_join(sb, swz<LOGN>(k))]) = v;
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < R; ++k) lds[sb ^ swz<LOGN>(k << LB)] = x[k];
+                for (int k = 0; k < R; ++k) lds[lds_join(sb, swz<LOGN>(k << LB))] = x[k];
             }
             // One group at a time: callers (k_ks_accum*) hold 2*E accumulators across the transform, and
             // interleaving groups would push them over the 128-VGPR budget.
