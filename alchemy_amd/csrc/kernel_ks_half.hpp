@@ -25,7 +25,7 @@
 #define ALCH_KS_INIT_DEPTH 2
 #endif
 #ifndef ALCH_KS_HINT_DEPTH
-#define ALCH_KS_HINT_DEPTH 6
+#define ALCH_KS_HINT_DEPTH 5
 #endif
 // timing experiment only (wrong results): drop every workgroup barrier of the kernel
 #ifdef ALCH_EXP_NOBARRIER
@@ -324,7 +324,9 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         // fully coalesced 1 KiB wave accesses instead of 16-byte pieces at a 64-byte lane stride.
         // The hint rows of the first HD slices are requested before the barrier (LDS-only barriers let global loads
         // stay in flight), the rest HD slices ahead of their use: the rows come from L2 / Infinity Cache, whose
-        // latency a shallower pipeline does not cover (measured: depth 2 -> 448k, 4 -> 463k, 6 -> 468k op/s).
+        // latency a shallower pipeline does not cover (measured with the XOR-swizzled LDS layout: depth 2 -> 448k, 4 -> 463k,
+        // 6 -> 468k op/s; with the padded layout depth 6 makes the register allocator rotate the accumulators and
+        // spill, and 4..5 are best: 500k -> 511k op/s).
         // (Running the digit loads of pass G one group ahead the same way spilled ~150 VGPRs: -20 %.)
         constexpr int HD = ALCH_KS_HINT_DEPTH;          // slices of hint rows in flight (2 x 16 B per lane each)
         V ph0[HD], ph1[HD];
