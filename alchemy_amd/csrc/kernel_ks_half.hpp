@@ -27,6 +27,13 @@
 #ifndef ALCH_KS_HINT_DEPTH
 #define ALCH_KS_HINT_DEPTH 5
 #endif
+// Ablation switches (ALCH_EXP_FLAGS; wrong results, timing only) exist in -DALCH_ABLATE builds alone: in the product
+// kernel they cost real instructions (the compiler hoists e.g. the "skip the tensor part" zero-fill in front of the branch).
+#ifdef ALCH_ABLATE
+#define KS_DBG(bit) (dbg_mask & (bit))
+#else
+#define KS_DBG(bit) false
+#endif
 // timing experiment only (wrong results): drop every workgroup barrier of the kernel
 #ifdef ALCH_EXP_NOBARRIER
 #define KS_SYNC() ((void)0)
@@ -177,7 +184,7 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     const W sr2 = js < 0 ? (W)0 : spre.v[js];
     const size_t n = (size_t)N;
     const size_t slot0 = (size_t)hf * M;
-    const size_t cti = (dbg_mask & 1u) ? (ct & 7) : ct;                // traffic experiment: alias the inputs
+    const size_t cti = KS_DBG(1u) ? (ct & 7) : ct;                // traffic experiment: alias the inputs
     const size_t jsz = (size_t)(js < 0 ? 0 : js);
     const W* a0 = a + ((2 * cti) * (size_t)Ls + jsz) * n + slot0;
     const W* a1 = a + ((2 * cti + 1) * (size_t)Ls + jsz) * n + slot0;
@@ -207,7 +214,7 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
 #pragma unroll
         for (int s = 2; s < ID; ++s) issue(s, in[s]);
         (void)0;
-        if (dbg_mask & 1024u) {
+        if (KS_DBG(1024u)) {
 #pragma unroll
             for (int s = 0; s < EPT; ++s) { acc0[s] = 0; acc1[s] = 0; }
         } else {
@@ -233,8 +240,8 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     }
     KS_STAMP(0);                                  // tensor part (c0, c1, diagonal digit)
     for (int i = 0; i < Ls; ++i) {
-        if (i == js || (dbg_mask & 512u)) continue;
-        const int32_t* d = digits + (((dbg_mask & 2u) ? (ct & 7) : ct) * (size_t)Ls + i) * n;   // dbg_mask: traffic experiments only
+        if (i == js || KS_DBG(512u)) continue;
+        const int32_t* d = digits + ((KS_DBG(2u) ? (ct & 7) : ct) * (size_t)Ls + i) * n;   // dbg_mask: traffic experiments only
         // Nothing below depends on i except d and the hint rows; keep addresses and twiddles from being
         // hoisted out of the digit loop (that costs ~250 spilled VGPRs).
         auto twf = fwd_tw(R, j);                        // Plantard constants (shared-twiddle passes)
@@ -245,7 +252,7 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         KS_STAMP(1);                              // barrier before pass G
 
         // ---- global stages 0..2, HBM/L2 -> registers -> LDS
-        if (!(dbg_mask & 256u)) {
+        if (!KS_DBG(256u)) {
             const auto w1 = twf[1], w2 = twf[2 + hf], w3a = twf[4 + 2 * hf], w3b = twf[5 + 2 * hf];
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -295,7 +302,7 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         KS_STAMP(3);                              // barrier after pass G
 
         // ---- remaining stages: sub-transform of size n/2, local stages 2 .. LOGM-1
-        const int ih = (dbg_mask & 8u) ? j : i + dup;                         // traffic experiment: alias the hint rows
+        const int ih = KS_DBG(8u) ? j : i + dup;                         // traffic experiment: alias the hint rows
         const W* h0 = hj + (size_t)(2 * ih) * hstride;
         const W* h1 = hj + (size_t)(2 * ih + 1) * hstride;
         const int prefix = 2 + hf;
@@ -309,15 +316,15 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
             ntt_pass<LOGM, LT, W, 6, 4, false, false, true>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, none);
         } else {
             static_assert(NP <= 3, "at most 3 LDS passes");
-            if (!(dbg_mask & 16u)) ntt_pass<LOGM, LT, W, 2, 4, false, false, ALCH_KS_SERIAL>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
+            if (!KS_DBG(16u)) ntt_pass<LOGM, LT, W, 2, 4, false, false, ALCH_KS_SERIAL>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
             KS_STAMP(4);                          // LDS pass 1
             KS_SYNC();
             KS_STAMP(5);
-            if (!(dbg_mask & 32u)) ntt_pass<LOGM, LT, W, 6, 4, false, false, ALCH_KS_SERIAL>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
+            if (!KS_DBG(32u)) ntt_pass<LOGM, LT, W, 6, 4, false, false, ALCH_KS_SERIAL>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
             KS_STAMP(6);                          // LDS pass 2
             KS_SYNC();
             KS_STAMP(7);
-            if (!(dbg_mask & 64u)) ntt_pass<LOGM, LT, W, 10, 4, false, false, true>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, none);
+            if (!KS_DBG(64u)) ntt_pass<LOGM, LT, W, 10, 4, false, false, true>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, none);
         }
         // hint multiply-accumulate, in the lane-contiguous slot layout: the transform result goes through LDS
         // once more so that hint loads (and the tensor inputs / result stores, which share the layout) are
@@ -338,7 +345,7 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
 #pragma unroll
         for (int r = 0; r < HD; ++r) hint_issue(r, ph0[r], ph1[r]);
         KS_SYNC();
-        if (!(dbg_mask & 128u))
+        if (!KS_DBG(128u))
 #pragma unroll
         for (int r = 0; r < EPT / 4; ++r) {
             const int idx = (tid + T * ((r + rot) & (EPT / 4 - 1))) * 4;
@@ -355,10 +362,10 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     }
 
     KS_STAMP(9);
-    const size_t cto = (dbg_mask & 4u) ? (ct & 7) : ct;                // traffic experiment: alias the outputs
+    const size_t cto = KS_DBG(4u) ? (ct & 7) : ct;                // traffic experiment: alias the outputs
     W* o0 = out + ((2 * cto) * (size_t)L + j) * n + slot0;
     W* o1 = out + ((2 * cto + 1) * (size_t)L + j) * n + slot0;
-    if (!(dbg_mask & 2048u)) { po0 = o0; po1 = o1; prot = rot; }
+    if (!KS_DBG(2048u)) { po0 = o0; po1 = o1; prot = rot; }
     KS_STAMP(10);                                 // result stores issued
     KS_STAMP_FLUSH();
     }  // item loop: the next item touches LDS only after the barrier that opens its first pass G

@@ -160,6 +160,13 @@ namespace alch {
 #define TI_STAMP(ph) do {} while (0)
 #endif
 
+// ablation switches of kernel A (ALCH_EXP_A): -DALCH_ABLATE builds only, see kernel_ks_half.hpp
+#ifdef ALCH_ABLATE
+#define TI_DBG(bit) (dbg & (bit))
+#else
+#define TI_DBG(bit) false
+#endif
+
 // ---- fused kernel A: tensor c2 + crtInv + centred lift ---------------------------------------------
 template <int LOGN, typename W>
 __global__ void __launch_bounds__(Geo<LOGN>::T)
@@ -178,7 +185,7 @@ k_tensor_intt(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
     // hides the HBM latency that a one-workgroup CU cannot hide by switching workgroups.
     V pa[NV], pb[NV];
     auto issue = [&](unsigned item) {
-        const size_t ct = (dbg & 1u) ? ((item / (unsigned)L) & 7) : item / (unsigned)L;   // dbg: timing experiments
+        const size_t ct = TI_DBG(1u) ? ((item / (unsigned)L) & 7) : item / (unsigned)L;   // dbg: timing experiments
         const int i = (int)(item % (unsigned)L);
         const W* a1 = a + ((2 * ct + 1) * (size_t)L + i) * (size_t)G::N;
         const W* b1 = b + ((2 * ct + 1) * (size_t)L + i) * (size_t)G::N;
@@ -229,7 +236,7 @@ k_tensor_intt(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
             for (int k = 0; k < RR; ++k) {
                 W v = csub(x[k], q);
                 SW z = v > half ? (SW)v - (SW)q : (SW)v;
-                if (!(dbg & 4u)) d[base + k * STRIDE] = z;
+                if (!TI_DBG(4u)) d[base + k * STRIDE] = z;
             }
         };
 #ifdef ALCH_STAMPS
@@ -247,7 +254,7 @@ k_tensor_intt(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
             TI_STAMP(4);
         } else
 #endif
-        if (!(dbg & 2u))
+        if (!TI_DBG(2u))
         ntt_inverse<LOGN, W, true>(lds, R.twi[i], q, qni, ninv_s, w1ninv_s, tid, epi,
                                    [&]() { if (item + gridDim.x < nitems) issue(item + gridDim.x); });
         lds_barrier();                       // every lane has read its last-pass inputs before LDS is refilled
