@@ -12,8 +12,8 @@
 // the dropped limbs are a per-lane private stash: written and read back by the same lane (global scratch,
 // `ddn * n` signed words per resident workgroup, L2-resident), no cross-lane ordering needed.
 // Cost per component: L crtInv + (L - ddn) crt, one read of L and one write of L - ddn limb-polynomials.
-// (Loading the next limb into registers during the current transforms, as k_tensor_intt does, was measured 7 %
-// slower here: with the forward transform in the same kernel the 32 extra registers spill ~100 VGPRs.)
+// (Loading the next limb into registers during the current transforms, as k_tensor_intt does, was measured 5-7 %
+// slower here, twice: with the forward transform in the same kernel the 32 extra registers spill.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ntt_engine.hpp"

@@ -449,7 +449,7 @@ inline hipError_t run_call(const NttCall<W>& c) {
             static const unsigned dbg_mask = getenv("ALCH_EXP_FLAGS") ? (unsigned)strtoul(getenv("ALCH_EXP_FLAGS"), nullptr, 0) : 0u;   // 1 inputs, 2 digits, 4 outputs, 8 hints aliased (wrong results, timing only)
             const size_t groups = (c.nct + 7) / 8;
             const unsigned nitems = (unsigned)(groups * 16 * (size_t)R.L);
-            static const unsigned persist = getenv("ALCH_KS_GRID") ? (unsigned)atoi(getenv("ALCH_KS_GRID")) : 2048u;  // measured: 512 -> 438k, 1024 -> 447k, 2048..4096 -> 458k, one item per workgroup -> 453k op/s
+            static const unsigned persist = getenv("ALCH_KS_GRID") ? (unsigned)atoi(getenv("ALCH_KS_GRID")) : 4096u;  // measured (1024-ciphertext chunks = 8192 items): 2048 -> 511k, 3072 -> 510k, 4096 (two items per workgroup) -> 517k, 8192 (one each) -> 513k op/s
             const unsigned grid = nitems < persist ? nitems : persist;
             constexpr int TH = 1 << (LOGN - 6);
             const size_t half_lds = (size_t)lds_words<LOGN - 1>() * sizeof(W);
