@@ -253,7 +253,14 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
 
         // ---- global stages 0..2, HBM/L2 -> registers -> LDS
         if (!KS_DBG(256u)) {
-            const auto w1 = twf[1], w2 = twf[2 + hf], w3a = twf[4 + 2 * hf], w3b = twf[5 + 2 * hf];
+            // stage 0 gives this half x + w1 y (lower) or x - w1 y (upper): the upper half multiplies by -w1 instead,
+            // so both run the same instructions (no select per coefficient)
+#if ALCH_USE_PLANTARD
+            const auto w1 = twf[1];
+#else
+            const W w1 = hf ? q - twf[1] : twf[1];
+#endif
+            const auto w2 = twf[2 + hf], w3a = twf[4 + 2 * hf], w3b = twf[5 + 2 * hf];
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const int lo4 = (tid + T * g) * 4;                    // coefficients lo4..lo4+3 of each eighth
@@ -269,15 +276,22 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
                     const SV zx = zxs[k], zy = zys[k];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        W xr, yr;
-                        if constexpr (BALANCED) { xr = (W)zx[e] + q; yr = (W)zy[e] + q; }           // (0, 2q)
-                        else {
-                            xr = mont_mul_lazy((W)((W)zx[e] + R.dig_off[j]), m.r1, q, qni);
+                        W xx, yr;
+                        if constexpr (BALANCED) {
+                            // |z| < q: z mod q = min(z, z + q) as unsigned words (a negative z is a huge word)
+                            const W zq = (W)zx[e] + q;
+                            xx = zq < (W)zx[e] ? zq : (W)zx[e];
+                            yr = (W)zy[e] + q;                                                      // (0, 2q)
+                        } else {
+                            xx = csub(mont_mul_lazy((W)((W)zx[e] + R.dig_off[j]), m.r1, q, qni), q);
                             yr = mont_mul_lazy((W)((W)zy[e] + R.dig_off[j]), m.r1, q, qni);
                         }
-                        const W xx = csub(xr, q);
                         const W t = tw_mul(yr, w1, q, qni);
+#if ALCH_USE_PLANTARD
                         u[k][e] = hf ? xx + (q - t) : xx + t;
+#else
+                        u[k][e] = xx + t;
+#endif
                     }
                 }
 #pragma unroll
