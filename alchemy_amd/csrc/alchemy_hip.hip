@@ -953,7 +953,9 @@ static int do_mul_relin(alch_ring* r, const alch_hint* hint, const void* a, cons
     // small enough for them to stay in the 256 MiB Infinity Cache; to keep the GPU full across the kernel
     // boundaries of such small launches, even and odd chunks run as two independent pipelines on two streams
     // (each with its own digit scratch), so one pipeline's tail overlaps the other's head.
-    const size_t chunk = std::min(r->chunk, (batch + 7) / 8 * 8);
+    // the key-switch kernel addresses each array with 32-bit byte offsets: a chunk's ciphertexts stay below 4 GiB
+    const size_t cap = std::max<size_t>(8, (((size_t)1 << 32) - 1) / (2 * elem_bytes(r)) / 8 * 8);
+    const size_t chunk = std::min(std::min(r->chunk, cap), (batch + 7) / 8 * 8);
     const size_t dig_bytes = chunk * elem_words(r) * sizeof(SW);
     int rc = ensure_ws(&r->ws_digits, &r->ws_digits_bytes, 2 * dig_bytes);
     if (rc != ALCH_OK) return rc;
@@ -1035,7 +1037,8 @@ static int do_mul_full(alch_ring* rh, alch_ring* rin, alch_ring* rout, const alc
     const int dup = rh->L - rin->L, ddn = rh->L - rout->L;
     const size_t n = rh->n;
     // per pipeline: digits [chunk][L_in][n] signed | key-switched chunk [chunk][2][Lh][n] | stash [slots][ddn][n] signed
-    const size_t chunk = std::min(rh->chunk, (batch + 7) / 8 * 8);
+    const size_t cap = std::max<size_t>(8, (((size_t)1 << 32) - 1) / (2 * elem_bytes(rh)) / 8 * 8);   // 32-bit byte offsets per array
+    const size_t chunk = std::min(std::min(rh->chunk, cap), (batch + 7) / 8 * 8);
     // resident workgroups of k_rescale_out (each owns a stash slot); ALCH_RS_SLOTS: test knob
     static const unsigned slots = getenv("ALCH_RS_SLOTS") ? (unsigned)std::max(1, atoi(getenv("ALCH_RS_SLOTS"))) : 512u;
     const size_t dig_bytes = chunk * (size_t)rin->L * n * sizeof(SW);

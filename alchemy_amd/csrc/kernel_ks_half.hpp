@@ -102,6 +102,21 @@ __device__ __forceinline__ u32 mont_red_lazy(u64 p, u32 q, u32 qni) {       // p
     return (u32)((p + (u64)m * q) >> 32);
 }
 
+// Global memory goes through buffer instructions: one descriptor per array (wave-uniform, from the kernel arguments),
+// the per-lane part of every address is the single VGPR `lane16` = threadIdx.x * 16 bytes, everything else (work
+// item, limb, slice rotation) is scalar and travels in the instruction's SGPR offset.  With flat loads the same
+// addresses cost ~150 VALU instructions of 64-bit pointer arithmetic per digit transform.  All byte offsets are
+// below 2^32 (the host caps the chunk size accordingly).
+template <typename Rsrc>
+__device__ __forceinline__ u32 __attribute__((ext_vector_type(4))) buf_ld16(Rsrc r, u32 voff, u32 soff) {
+    typedef u32 V4 __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+template <typename Rsrc>
+__device__ __forceinline__ void buf_st16(Rsrc r, u32 voff, u32 soff, u32 __attribute__((ext_vector_type(4))) v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)), v), r, voff, soff, 0);
+}
+
 // EPT = coefficients (and accumulator pairs) per thread: 32 -> n/64 threads, <= 128 VGPRs, 4 waves per SIMD.
 // EPT = 16 (n/32 threads, <= 64 VGPRs, 8 waves per SIMD) builds and is bit-exact, but spills 61 VGPRs and ran
 // 30 % SLOWER on MI355X (294 k vs 418 k op/s), so it is not dispatched.
@@ -129,6 +144,13 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     const int L = R.L;
     const int dup = UP ? dup_ : 0;
     const int Ls = L - dup;                         // limbs of the operands and number of digits
+    const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(a), 0, (u32)((size_t)nct * 2 * Ls * N * 4), 0x00020000);
+    const auto rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(b), 0, (u32)((size_t)nct * 2 * Ls * N * 4), 0x00020000);
+    const auto rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(digits), 0, (u32)((size_t)nct * Ls * N * 4), 0x00020000);
+    const auto rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32*>(hint), 0, (u32)((size_t)2 * L * L * N * 4), 0x00020000);
+    const auto ro = __builtin_amdgcn_make_buffer_rsrc(out, 0, (u32)((size_t)nct * 2 * L * N * 4), 0x00020000);
+    const u32 lane16 = threadIdx.x * 16u;
+    constexpr u32 SLICE = (u32)T * 16u;             // bytes between two lane-contiguous slices
     // Persistent workgroups: the grid is two workgroups per CU and each loops over work items
     // (ciphertext, limb j, half): no partial last wave of workgroups, and the result stores of one item can be
     // issued behind the first loads of the next.  (An LDS-DMA prefetch of the next item's inputs towards L2 was
@@ -148,22 +170,22 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     // to HBM before the next item's loads could be consumed.  (Spreading the stores over all eight slices was
     // measured 15 % slower.)
     W acc0[EPT], acc1[EPT];
-    W* po0 = nullptr;
-    W* po1 = nullptr;
+    u32 po0 = 0, po1 = 0;                          // byte offsets of the previous item's two result rows
+    bool pending = false;
     int prot = 0;
     auto store_slice = [&](int r) {               // slice r of the previous item's results
-        if (po0 == nullptr) return;
-        const int idx = ((int)threadIdx.x + T * ((r + prot) & (EPT / 4 - 1))) * 4;
+        if (!pending) return;
+        const u32 so = SLICE * (u32)((r + prot) & (EPT / 4 - 1));
         V v0, v1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v0[e] = acc0[r * 4 + e]; v1[e] = acc1[r * 4 + e]; }
-        *reinterpret_cast<V*>(po0 + idx) = v0;
-        *reinterpret_cast<V*>(po1 + idx) = v1;
+        buf_st16(ro, lane16, po0 + so, v0);
+        buf_st16(ro, lane16, po1 + so, v1);
     };
     auto flush_stores = [&]() {
 #pragma unroll
         for (int r = 0; r < EPT / 4; ++r) store_slice(r);
-        po0 = nullptr;
+        pending = false;
     };
     for (unsigned item = blockIdx.x; item < nitems; item += gridDim.x) {
     int j, hf;
@@ -182,31 +204,27 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     // an added limb runs the same tensor code on limb 0's operands with scalar 0 (c0 = c1 = c2 = 0): a fifth of
     // the items waste ~10 % of their time, and the kernel keeps one copy of the load/store pipeline
     const W sr2 = js < 0 ? (W)0 : spre.v[js];
-    const size_t n = (size_t)N;
-    const size_t slot0 = (size_t)hf * M;
-    const size_t cti = KS_DBG(1u) ? (ct & 7) : ct;                // traffic experiment: alias the inputs
-    const size_t jsz = (size_t)(js < 0 ? 0 : js);
-    const W* a0 = a + ((2 * cti) * (size_t)Ls + jsz) * n + slot0;
-    const W* a1 = a + ((2 * cti + 1) * (size_t)Ls + jsz) * n + slot0;
-    const W* b0 = b + ((2 * cti) * (size_t)Ls + jsz) * n + slot0;
-    const W* b1 = b + ((2 * cti + 1) * (size_t)Ls + jsz) * n + slot0;
-    const W* hj = hint + (size_t)j * n + slot0;                // + ((i*2 + c)*L)*n
-    const size_t hstride = (size_t)L * n;
+    const u32 slot0 = (u32)hf * (u32)M * 4u;                                   // byte offsets from here on
+    const u32 cti = KS_DBG(1u) ? (u32)(ct & 7) : (u32)ct;                      // traffic experiment: alias the inputs
+    const u32 jsz = (u32)(js < 0 ? 0 : js);
+    constexpr u32 ROW = (u32)N * 4u;                                           // one limb-polynomial
+    const u32 a0 = ((2 * cti) * (u32)Ls + jsz) * ROW + slot0, a1 = ((2 * cti + 1) * (u32)Ls + jsz) * ROW + slot0;
+    const u32 hj = (u32)j * ROW + slot0;                                       // + ((i*2 + c)*L) rows
+    const u32 hstride = (u32)L * ROW;
 
     KS_STAMP_INIT();
     {   // c0, c1 and the diagonal digit (i == j): d_j = c2_j (mod q_j), no transform needed.
         // Eight 4-coefficient slices, software-pipelined: the six 16-byte loads of slice s+1 are in flight
         // while slice s is multiplied out (issuing them one slice at a time exposed the HBM latency eight
         // times per workgroup: 20 % of the kernel in the phase stamps).
-        const W* h0 = hj + (size_t)(2 * j) * hstride;
-        const W* h1 = hj + (size_t)(2 * j + 1) * hstride;
+        const u32 h0 = hj + (u32)(2 * j) * hstride, h1 = hj + (u32)(2 * j + 1) * hstride;
         constexpr int ID = ALCH_KS_INIT_DEPTH;         // slices of tensor inputs in flight (6 x 16 B per lane each)
         V in[ID][6];
         auto issue = [&](int s, V (&v)[6]) {
-            const int idx = ((int)threadIdx.x + T * ((s + rot) & (EPT / 4 - 1))) * 4;   // lane-contiguous 16-byte pieces
-            v[0] = *reinterpret_cast<const V*>(a0 + idx); v[1] = *reinterpret_cast<const V*>(a1 + idx);
-            v[2] = *reinterpret_cast<const V*>(b0 + idx); v[3] = *reinterpret_cast<const V*>(b1 + idx);
-            v[4] = *reinterpret_cast<const V*>(h0 + idx); v[5] = *reinterpret_cast<const V*>(h1 + idx);
+            const u32 so = SLICE * (u32)((s + rot) & (EPT / 4 - 1));               // lane-contiguous 16-byte pieces
+            v[0] = buf_ld16(ra, lane16, a0 + so); v[1] = buf_ld16(ra, lane16, a1 + so);
+            v[2] = buf_ld16(rb, lane16, a0 + so); v[3] = buf_ld16(rb, lane16, a1 + so);
+            v[4] = buf_ld16(rh, lane16, h0 + so); v[5] = buf_ld16(rh, lane16, h1 + so);
         };
         issue(0, in[0]);
         issue(1, in[1]);
@@ -241,7 +259,7 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     KS_STAMP(0);                                  // tensor part (c0, c1, diagonal digit)
     for (int i = 0; i < Ls; ++i) {
         if (i == js || KS_DBG(512u)) continue;
-        const int32_t* d = digits + ((KS_DBG(2u) ? (ct & 7) : ct) * (size_t)Ls + i) * n;   // dbg_mask: traffic experiments only
+        const u32 d = ((KS_DBG(2u) ? (u32)(ct & 7) : (u32)ct) * (u32)Ls + (u32)i) * ROW;   // byte offset of digit i
         // Nothing below depends on i except d and the hint rows; keep addresses and twiddles from being
         // hoisted out of the digit loop (that costs ~250 spilled VGPRs).
         auto twf = fwd_tw(R, j);                        // Plantard constants (shared-twiddle passes)
@@ -268,8 +286,8 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
                 SV zxs[4], zys[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    zxs[k] = *reinterpret_cast<const SV*>(d + k * (N / 8) + lo4);
-                    zys[k] = *reinterpret_cast<const SV*>(d + (k + 4) * (N / 8) + lo4);
+                    zxs[k] = __builtin_bit_cast(SV, buf_ld16(rd, lane16, d + (u32)(k * (N / 8) + T * g * 4) * 4u));
+                    zys[k] = __builtin_bit_cast(SV, buf_ld16(rd, lane16, d + (u32)((k + 4) * (N / 8) + T * g * 4) * 4u));
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -317,8 +335,7 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
 
         // ---- remaining stages: sub-transform of size n/2, local stages 2 .. LOGM-1
         const int ih = KS_DBG(8u) ? j : i + dup;                         // traffic experiment: alias the hint rows
-        const W* h0 = hj + (size_t)(2 * ih) * hstride;
-        const W* h1 = hj + (size_t)(2 * ih + 1) * hstride;
+        const u32 h0 = hj + (u32)(2 * ih) * hstride, h1 = hj + (u32)(2 * ih + 1) * hstride;
         const int prefix = 2 + hf;
         NoEpilogue none;
         constexpr int NP = (LOGM - 2) / 4;
@@ -352,9 +369,9 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         constexpr int HD = ALCH_KS_HINT_DEPTH;          // slices of hint rows in flight (2 x 16 B per lane each)
         V ph0[HD], ph1[HD];
         auto hint_issue = [&](int r, V& a0v, V& a1v) {
-            const int idx = (tid + T * ((r + rot) & (EPT / 4 - 1))) * 4;
-            a0v = *reinterpret_cast<const V*>(h0 + idx);
-            a1v = *reinterpret_cast<const V*>(h1 + idx);
+            const u32 so = SLICE * (u32)((r + rot) & (EPT / 4 - 1));
+            a0v = buf_ld16(rh, lane16, h0 + so);
+            a1v = buf_ld16(rh, lane16, h1 + so);
         };
 #pragma unroll
         for (int r = 0; r < HD; ++r) hint_issue(r, ph0[r], ph1[r]);
@@ -376,10 +393,13 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     }
 
     KS_STAMP(9);
-    const size_t cto = KS_DBG(4u) ? (ct & 7) : ct;                // traffic experiment: alias the outputs
-    W* o0 = out + ((2 * cto) * (size_t)L + j) * n + slot0;
-    W* o1 = out + ((2 * cto + 1) * (size_t)L + j) * n + slot0;
-    if (!KS_DBG(2048u)) { po0 = o0; po1 = o1; prot = rot; }
+    const u32 cto = KS_DBG(4u) ? (u32)(ct & 7) : (u32)ct;                // traffic experiment: alias the outputs
+    if (!KS_DBG(2048u)) {
+        po0 = ((2 * cto) * (u32)L + (u32)j) * ROW + slot0;
+        po1 = ((2 * cto + 1) * (u32)L + (u32)j) * ROW + slot0;
+        pending = true;
+        prot = rot;
+    }
     KS_STAMP(10);                                 // result stores issued
     KS_STAMP_FLUSH();
     }  // item loop: the next item touches LDS only after the barrier that opens its first pass G

@@ -447,6 +447,7 @@ inline hipError_t run_call(const NttCall<W>& c) {
         if constexpr (std::is_same<W, u32>::value && (LOGN == 15 || LOGN == 11)) {
             // two workgroups per (ciphertext, limb): see kernel_ks_half.hpp
             static const unsigned dbg_mask = getenv("ALCH_EXP_FLAGS") ? (unsigned)strtoul(getenv("ALCH_EXP_FLAGS"), nullptr, 0) : 0u;   // 1 inputs, 2 digits, 4 outputs, 8 hints aliased (wrong results, timing only)
+            if ((size_t)c.nct * 2 * (size_t)R.L * G::N * sizeof(W) >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // 32-bit byte offsets
             const size_t groups = (c.nct + 7) / 8;
             const unsigned nitems = (unsigned)(groups * 16 * (size_t)R.L);
             static const unsigned persist = getenv("ALCH_KS_GRID") ? (unsigned)atoi(getenv("ALCH_KS_GRID")) : 4096u;  // measured (1024-ciphertext chunks = 8192 items): 2048 -> 511k, 3072 -> 510k, 4096 (two items per workgroup) -> 517k, 8192 (one each) -> 513k op/s
