@@ -183,19 +183,26 @@ k_tensor_intt(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
     // Persistent workgroups (one polynomial fills the CU's LDS, so one workgroup per CU is resident): the
     // a1/b1 coefficients of the NEXT item are loaded into registers while the current transform runs, which
     // hides the HBM latency that a one-workgroup CU cannot hide by switching workgroups.
+    // Global memory through buffer instructions (see kernel_ks_half.hpp): per-lane part of every address is one
+    // VGPR, the rest is scalar.  Byte offsets stay below 2^32 (the host caps the chunk).
+    const u32 nct = nitems / (unsigned)L;
+    const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<W*>(a), 0, (u32)((size_t)nct * 2 * L * G::N * sizeof(W)), 0x00020000);
+    const auto rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<W*>(b), 0, (u32)((size_t)nct * 2 * L * G::N * sizeof(W)), 0x00020000);
+    const auto rd = __builtin_amdgcn_make_buffer_rsrc(digits, 0, (u32)((size_t)nct * L * G::N * sizeof(W)), 0x00020000);
+    const u32 lane16 = threadIdx.x * 16u;
+    constexpr u32 ROW = (u32)G::N * (u32)sizeof(W);
     V pa[NV], pb[NV];
     auto issue = [&](unsigned item) {
-        const size_t ct = TI_DBG(1u) ? ((item / (unsigned)L) & 7) : item / (unsigned)L;   // dbg: timing experiments
-        const int i = (int)(item % (unsigned)L);
-        const W* a1 = a + ((2 * ct + 1) * (size_t)L + i) * (size_t)G::N;
-        const W* b1 = b + ((2 * ct + 1) * (size_t)L + i) * (size_t)G::N;
+        const u32 ct = TI_DBG(1u) ? ((item / (unsigned)L) & 7) : item / (unsigned)L;   // dbg: timing experiments
+        const u32 i = item % (unsigned)L;
+        const u32 row = ((2 * ct + 1) * (u32)L + i) * ROW;
 #pragma unroll
         for (int r = 0; r < NV; ++r) {
             // rotated start per item: lockstep workgroups must not all read the same offset of their
             // 128 KiB-aligned rows at the same time (HBM channel conflicts)
-            const int idx = ((int)threadIdx.x + G::T * ((r + (int)(item ^ (item >> 3))) & (NV - 1))) * VL;
-            pa[r] = *reinterpret_cast<const V*>(a1 + idx);
-            pb[r] = *reinterpret_cast<const V*>(b1 + idx);
+            const u32 so = row + (u32)G::T * 16u * ((r + (item ^ (item >> 3))) & (NV - 1));
+            pa[r] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(ra, lane16, so, 0));
+            pb[r] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rb, lane16, so, 0));
         }
     };
 #ifdef ALCH_STAMPS
@@ -225,7 +232,7 @@ k_tensor_intt(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
         TI_STAMP(0);                            // loads + c2 + LDS write
         lds_barrier();
         TI_STAMP(1);
-        SW* d = digits + (ct * (size_t)L + i) * (size_t)G::N;
+        const u32 drow = ((u32)ct * (u32)L + (u32)i) * ROW;
         const W half = (q - 1) >> 1;
         // The digit is stored straight from the last (strided) pass: 32 dword stores per lane, each wave store
         // 256 contiguous bytes.  Routing the result through LDS for 16-byte stores was measured 4 % slower.
@@ -236,7 +243,13 @@ k_tensor_intt(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
             for (int k = 0; k < RR; ++k) {
                 W v = csub(x[k], q);
                 SW z = v > half ? (SW)v - (SW)q : (SW)v;
-                if (!TI_DBG(4u)) d[base + k * STRIDE] = z;
+                if (!TI_DBG(4u)) {
+                    if constexpr (sizeof(W) == 4)
+                        __builtin_amdgcn_raw_buffer_store_b32((u32)z, rd, (u32)base * 4u, drow + (u32)(k * STRIDE) * 4u, 0);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(rd, 0, 0, 0)), z),
+                                                              rd, (u32)base * 8u, drow + (u32)(k * STRIDE) * 8u, 0);
+                }
             }
         };
 #ifdef ALCH_STAMPS
