@@ -343,7 +343,7 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
             ntt_pass<LOGM, LT, W, 2, 4, false, false, true>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, none);
         } else if constexpr (NP == 2) {
             ntt_pass<LOGM, LT, W, 2, 4, false, false, ALCH_KS_SERIAL>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
-            KS_SYNC();
+            pair_sync<LOGM>();                    // LB = 4 -> LB = 0: the hand-off stays inside each wave
             ntt_pass<LOGM, LT, W, 6, 4, false, false, true>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, none);
         } else {
             static_assert(NP <= 3, "at most 3 LDS passes");
@@ -353,7 +353,7 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
             KS_STAMP(5);
             if (!KS_DBG(32u)) ntt_pass<LOGM, LT, W, 6, 4, false, false, ALCH_KS_SERIAL>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
             KS_STAMP(6);                          // LDS pass 2
-            KS_SYNC();
+            pair_sync<LOGM>();                    // LB = 4 -> LB = 0: the hand-off stays inside each wave
             KS_STAMP(7);
             if (!KS_DBG(64u)) ntt_pass<LOGM, LT, W, 10, 4, false, false, true>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, none);
         }

@@ -248,6 +248,18 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const TW* __restri
 // tid = threadIdx.x (passed in so that a caller looping over transforms can make it opaque per iteration
 // and stop the compiler from hoisting every pass's LDS addresses out of its loop).
 // Callers must __syncthreads() after filling LDS; the function syncs between passes.
+// The passes with LB = 4 and LB = 0 (the last two of crt, the first two of crtInv) give every wave the same 1024
+// contiguous coefficients (64 lanes x 16: [1024 w, 1024 w + 1024) per group index), so the hand-off between them
+// stays inside a wave: LDS executes one wave's instructions in order, no workgroup barrier is needed.
+#ifndef ALCH_WAVE_LOCAL_PAIR
+#define ALCH_WAVE_LOCAL_PAIR 1
+#endif
+template <int LOGN>
+__device__ __forceinline__ void pair_sync() {
+    if constexpr (ALCH_WAVE_LOCAL_PAIR && LOGN >= 10) asm volatile("" ::: "memory");
+    else lds_barrier();
+}
+
 template <int LOGN, typename W, bool KEEP_LAST, bool SERIAL = false, typename TW, typename Epi>
 __device__ __forceinline__ void ntt_forward(W* lds, const TW* tw, const W* twm, W q, W qni, int tid, Epi&& epi,
                                             int prefix = 1) {
@@ -269,12 +281,12 @@ __device__ __forceinline__ void ntt_forward(W* lds, const TW* tw, const W* twm, 
             ntt_pass<LOGN, LT, W, F, 4, false, KEEP_LAST, SERIAL>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, epi);
         } else {
             ntt_pass<LOGN, LT, W, F, 4, false, false, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, prefix, none);
-            lds_barrier();
+            if constexpr (P == 3) pair_sync<LOGN>(); else lds_barrier();
             if constexpr (P == 3) {
                 ntt_pass<LOGN, LT, W, F + 4, 4, false, KEEP_LAST, SERIAL>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, epi);
             } else {
                 ntt_pass<LOGN, LT, W, F + 4, 4, false, false, SERIAL>(lds, tw, q, qni, (W)0, (W)0, tid, prefix, none);
-                lds_barrier();
+                pair_sync<LOGN>();
                 ntt_pass<LOGN, LT, W, F + 8, 4, false, KEEP_LAST, SERIAL>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, epi);
             }
         }
@@ -303,9 +315,10 @@ __device__ __forceinline__ void ntt_inverse(W* lds, const W* twi, W q, W qni, W 
     constexpr bool U3 = (LOGN - (F + 8) - 4 >= 6), U2 = (LOGN - (F + 4) - 4 >= 6), U1 = (LOGN - F - 4 >= 6);
     bool hooked = false;
     if constexpr (P >= 4) { if (U3 && !hooked) { hook(); hooked = true; }
-        ntt_pass<LOGN, LT, W, F + 8, 4, true, false, SERIAL, W, NoEpilogue&, FOLD>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, prefix, none); lds_barrier(); }
+        ntt_pass<LOGN, LT, W, F + 8, 4, true, false, SERIAL, W, NoEpilogue&, FOLD>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, prefix, none); pair_sync<LOGN>(); }
     if constexpr (P >= 3) { if (U2 && !hooked) { hook(); hooked = true; }
-        ntt_pass<LOGN, LT, W, F + 4, 4, true, false, SERIAL, W, NoEpilogue&, FOLD>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, prefix, none); lds_barrier(); }
+        ntt_pass<LOGN, LT, W, F + 4, 4, true, false, SERIAL, W, NoEpilogue&, FOLD>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, prefix, none);
+        if constexpr (P == 3) pair_sync<LOGN>(); else lds_barrier(); }
     if constexpr (P >= 2) { if (U1 && !hooked) { hook(); hooked = true; }
         ntt_pass<LOGN, LT, W, F, 4, true, false, SERIAL, W, NoEpilogue&, FOLD>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, prefix, none); lds_barrier(); }
     if (!hooked) hook();
