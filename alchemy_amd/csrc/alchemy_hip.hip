@@ -499,9 +499,11 @@ static hipError_t dispatch(int logn, const NttCall<u64>& c) {
 }
 
 template <typename W>
-static int do_crt(alch_ring* r, void* data, size_t first_elem, size_t count, bool inverse) {
+static int do_crt(alch_ring* r, void* data, size_t first_elem, size_t count, bool inverse, const void* src = nullptr) {
+    // src != null: transform src[first_elem ..) into data[first_elem ..) (LDS-resident sizes only)
     if (count == 0) return ALCH_OK;
     NttCall<W> c{};
+    c.src = reinterpret_cast<const W*>(src);
     c.op = inverse ? OP_CRTINV : OP_CRT;
     c.ring = &dev_ring<W>(r);
     c.stream = r->stream;
@@ -1011,9 +1013,15 @@ extern "C" int alch_ct_mul_relin(alch_ring* r, const alch_hint* hint, const alch
         if ((rc = ensure_ws(&r->ws_in, &r->ws_in_bytes, 2 * bytes)) != ALCH_OK) return rc;
         char* wa = reinterpret_cast<char*>(r->ws_in);
         char* wb = wa + bytes;
-        HIP_TRY(hipMemcpyAsync(wa, a->dptr, bytes, hipMemcpyDeviceToDevice, r->stream));
-        HIP_TRY(hipMemcpyAsync(wb, b->dptr, bytes, hipMemcpyDeviceToDevice, r->stream));
-        rc = r->word == 4 ? do_crt<u32>(r, wa, 0, 4 * batch, false) : do_crt<u64>(r, wa, 0, 4 * batch, false);
+        if (split_ring(r)) {                 // the split transform works in place: copy first
+            HIP_TRY(hipMemcpyAsync(wa, a->dptr, bytes, hipMemcpyDeviceToDevice, r->stream));
+            HIP_TRY(hipMemcpyAsync(wb, b->dptr, bytes, hipMemcpyDeviceToDevice, r->stream));
+            rc = r->word == 4 ? do_crt<u32>(r, wa, 0, 4 * batch, false) : do_crt<u64>(r, wa, 0, 4 * batch, false);
+        } else {                             // out of place, straight from the operands
+            rc = r->word == 4 ? do_crt<u32>(r, wa, 0, 2 * batch, false, a->dptr) : do_crt<u64>(r, wa, 0, 2 * batch, false, a->dptr);
+            if (rc == ALCH_OK)
+                rc = r->word == 4 ? do_crt<u32>(r, wb, 0, 2 * batch, false, b->dptr) : do_crt<u64>(r, wb, 0, 2 * batch, false, b->dptr);
+        }
         if (rc != ALCH_OK) return rc;
         pa = wa;
         pb = wb;

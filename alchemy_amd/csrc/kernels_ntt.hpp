@@ -72,6 +72,7 @@ struct NttCall {
     hipStream_t stream;
     // OP_CRT / OP_CRTINV
     W* data;
+    const W* src;          // null: in place
     size_t first_poly, npoly;
     // fused kernels
     const W* a;
@@ -106,7 +107,7 @@ __device__ __forceinline__ void stage_in(W* lds, F&& load4) {
 
 // ---- batched crt / crtInv --------------------------------------------------------------------------
 template <int LOGN, typename W, bool INVERSE>
-__global__ void __launch_bounds__(Geo<LOGN>::T) k_crt(DevRing<W> R, W* __restrict__ data, size_t first_poly) {
+__global__ void __launch_bounds__(Geo<LOGN>::T) k_crt(DevRing<W> R, W* data, const W* src, size_t first_poly) {
     typedef Geo<LOGN> G;
     typedef typename Vec4<W>::type V;
     constexpr int VL = Vec4<W>::LANES;
@@ -115,9 +116,10 @@ __global__ void __launch_bounds__(Geo<LOGN>::T) k_crt(DevRing<W> R, W* __restric
     const size_t p = first_poly + blockIdx.x;
     const int j = (int)(p % (size_t)R.L);
     W* poly = data + p * (size_t)G::N;
+    const W* in = src ? src + p * (size_t)G::N : poly;      // src != null: out of place (same element layout)
     const W q = R.mod[j].q, qni = R.mod[j].qni;
 
-    stage_in<LOGN, W>(lds, [&](int idx) { return *reinterpret_cast<const V*>(poly + idx); });
+    stage_in<LOGN, W>(lds, [&](int idx) { return *reinterpret_cast<const V*>(in + idx); });
     lds_barrier();
     if constexpr (!INVERSE) ntt_forward<LOGN, W, false>(lds, fwd_tw(R, j), R.twf[j], q, qni, (int)threadIdx.x, NoEpilogue());
     else ntt_inverse<LOGN, W, false>(lds, R.twi[j], q, qni, R.ninv_m[j], R.w1ninv_m[j], (int)threadIdx.x, NoEpilogue());
@@ -425,13 +427,13 @@ inline hipError_t run_call(const NttCall<W>& c) {
     case OP_CRT: {
         auto k = k_crt<LOGN, W, false>;
         if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(G::T), lds_bytes, c.stream, R, c.data, c.first_poly);
+        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(G::T), lds_bytes, c.stream, R, c.data, c.src, c.first_poly);
         break;
     }
     case OP_CRTINV: {
         auto k = k_crt<LOGN, W, true>;
         if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(G::T), lds_bytes, c.stream, R, c.data, c.first_poly);
+        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(G::T), lds_bytes, c.stream, R, c.data, c.src, c.first_poly);
         break;
     }
     case OP_TENSOR_INTT: {
