@@ -32,13 +32,24 @@ HINT_BYTES = 2 * 4 * 4 * (1 << LOGN) * 8              # 8 MiB, counted once per 
 HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline(sample_ops: int):
     from oracle import cref
     ring = cref.Ring(1 << LOGN, CFG3_QS)
     secs = ring.bench_mul_relin(sample_ops, 2026)
     return {"value": sample_ops / secs, "unit": "ctxt-mul+relin/s", "cores": 1, "kind": "port",
             "sample": f"{sample_ops} ops of keySwitchQuadCirc(a*b), n=2^15, L=4, CRT basis in/out, "
-                      f"single thread C restatement of Lol's CT algorithm ({secs:.1f} s)"}
+                      f"single thread C restatement of Lol's CT algorithm ({secs:.1f} s) on {_cpu_model()}, "
+                      f"{os.cpu_count()} logical CPUs visible"}
 
 
 def cpu_baseline_all_cores(ops_per_thread: int):
