@@ -20,6 +20,17 @@
 
 namespace alch {
 
+template <typename W, typename Rsrc>
+__device__ __forceinline__ typename Signed<W>::type ld_word(Rsrc r, u32 voff, u32 soff) {
+    if constexpr (sizeof(W) == 4) return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+    else return __builtin_bit_cast(int64_t, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+template <typename W, typename Rsrc>
+__device__ __forceinline__ void st_word(Rsrc r, u32 voff, u32 soff, W v) {
+    if constexpr (sizeof(W) == 4) __builtin_amdgcn_raw_buffer_store_b32((u32)v, r, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b64(r, 0, 0, 0)), v), r, voff, soff, 0);
+}
+
 template <int LOGN, typename W>
 __global__ void __launch_bounds__(Geo<LOGN>::T)
 k_rescale_out(DevRing<W> R, const W* __restrict__ src, W* __restrict__ out, typename Signed<W>::type* stash,
@@ -33,23 +44,32 @@ k_rescale_out(DevRing<W> R, const W* __restrict__ src, W* __restrict__ out, type
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W* lds = reinterpret_cast<W*>(smem);
     const int L = R.L, ddn = D.ddn, Lo = L - ddn;
-    SW* st = stash + (size_t)blockIdx.x * (size_t)ddn * G::N;
+    // buffer instructions (see kernel_ks_half.hpp): one VGPR of per-lane address, the rest scalar; offsets < 2^32
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<W*>(src), 0, (u32)((size_t)nitems * L * G::N * sizeof(W)), 0x00020000);
+    const auto rout = __builtin_amdgcn_make_buffer_rsrc(out, 0, (u32)((size_t)nitems * Lo * G::N * sizeof(W)), 0x00020000);
+    const auto rst = __builtin_amdgcn_make_buffer_rsrc(stash, 0, (u32)((size_t)gridDim.x * ddn * G::N * sizeof(W)), 0x00020000);
+    constexpr u32 ROW = (u32)G::N * (u32)sizeof(W), WB = (u32)sizeof(W);
+    const u32 st0 = blockIdx.x * (u32)ddn * ROW;
+    const u32 lane16 = threadIdx.x * 16u;
 
     for (unsigned item = blockIdx.x; item < nitems; item += gridDim.x) {
-        const W* x = src + (size_t)item * (size_t)L * G::N;          // item = 2*ct + component
-        W* o = out + (size_t)item * (size_t)Lo * G::N;
+        const u32 x = item * (u32)L * ROW;                           // item = 2*ct + component; byte offsets
+        const u32 o = item * (u32)Lo * ROW;
         for (int t = 0; t < L; ++t) {
             const ModP<W> m = R.mod[t];
             const W q = m.q, qni = m.qni;
             const W half = (q - 1) >> 1;
-            const W* poly = x + (size_t)t * G::N;
+            const u32 poly = x + (u32)t * ROW;
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));       // keep each limb's address arithmetic inside the loop (VGPR pressure)
             lds_barrier();                      // the previous limb's last pass / stores have finished with LDS
-            stage_in<LOGN, W>(lds, [&](int idx) { return *reinterpret_cast<const V*>(poly + idx); });
+#pragma unroll
+            for (int r = 0; r < G::E / VL; ++r)
+                *reinterpret_cast<V*>(&lds[swz<LOGN>((tid + G::T * r) * VL)]) =
+                    __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, poly + (u32)(G::T * r) * 16u, 0));
             lds_barrier();
             const int nd = t < ddn ? t : ddn;   // drops that apply to this limb
-            W* ot = o + (size_t)(t - ddn) * G::N;
+            const u32 ot = o + (u32)(t - ddn) * ROW;
             auto epi = [&](int, int base, W* v) {
 #pragma unroll
                 for (int k = 0; k < RR; ++k) v[k] = csub(v[k], q);
@@ -57,7 +77,7 @@ k_rescale_out(DevRing<W> R, const W* __restrict__ src, W* __restrict__ out, type
                     const W qim = D.qinv_m[u][t];
                     SW z[RR];
 #pragma unroll
-                    for (int k = 0; k < RR; ++k) z[k] = st[(size_t)u * G::N + base + k * STRIDE];
+                    for (int k = 0; k < RR; ++k) z[k] = ld_word<W>(rst, (u32)base * WB, st0 + (u32)u * ROW + (u32)(k * STRIDE) * WB);
 #pragma unroll
                     for (int k = 0; k < RR; ++k) {
                         W r;
@@ -69,10 +89,11 @@ k_rescale_out(DevRing<W> R, const W* __restrict__ src, W* __restrict__ out, type
                 if (t < ddn) {
 #pragma unroll
                     for (int k = 0; k < RR; ++k)
-                        st[(size_t)t * G::N + base + k * STRIDE] = v[k] > half ? (SW)v[k] - (SW)q : (SW)v[k];
+                        st_word(rst, (u32)base * WB, st0 + (u32)t * ROW + (u32)(k * STRIDE) * WB,
+                                (W)(v[k] > half ? (SW)v[k] - (SW)q : (SW)v[k]));
                 } else if (pow_out) {
 #pragma unroll
-                    for (int k = 0; k < RR; ++k) ot[base + k * STRIDE] = v[k];
+                    for (int k = 0; k < RR; ++k) st_word(rout, (u32)base * WB, ot + (u32)(k * STRIDE) * WB, v[k]);
                 } else {
 #pragma unroll
                     for (int k = 0; k < RR; ++k) lds[swz<LOGN>(base + k * STRIDE)] = v[k];   // the words this lane just read
@@ -88,7 +109,9 @@ k_rescale_out(DevRing<W> R, const W* __restrict__ src, W* __restrict__ out, type
                     V v = *reinterpret_cast<const V*>(&lds[swz<LOGN>(idx)]);
 #pragma unroll
                     for (int e = 0; e < VL; ++e) v[e] = csub(v[e], q);
-                    *reinterpret_cast<V*>(ot + idx) = v;
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        __builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(rout, 0, 0, 0)), v), rout, lane16,
+                        ot + (u32)(G::T * r) * 16u, 0);
                 }
             }
         }
