@@ -259,9 +259,9 @@ k_tensor_intt(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
             NoEpilogue none;
             const W* twi = R.twi[i];
             ntt_pass<LOGN, G::LOGT, W, 11, 4, true, false, false>(lds, twi, q, qni, R.ninv_m[i], R.w1ninv_m[i], tid, 1, none);
-            TI_STAMP(2); lds_barrier(); TI_STAMP(3);
+            TI_STAMP(6); pair_sync<LOGN>(); TI_STAMP(3);
             ntt_pass<LOGN, G::LOGT, W, 7, 4, true, false, false>(lds, twi, q, qni, R.ninv_m[i], R.w1ninv_m[i], tid, 1, none);
-            TI_STAMP(2); lds_barrier(); TI_STAMP(3);
+            TI_STAMP(7); lds_barrier(); TI_STAMP(3);
             if (item + gridDim.x < nitems) issue(item + gridDim.x);
             ntt_pass<LOGN, G::LOGT, W, 3, 4, true, false, false>(lds, twi, q, qni, R.ninv_m[i], R.w1ninv_m[i], tid, 1, none);
             TI_STAMP(2); lds_barrier(); TI_STAMP(3);

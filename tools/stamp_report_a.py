@@ -14,9 +14,9 @@ lib = load_library()
 buf = (C.c_ulonglong * 16)()
 ring.ct_mul_relin(hint, a, b, out, B); ring.sync(); lib.alch_debug_stamps_a(buf)
 ring.ct_mul_relin(hint, a, b, out, B); ring.sync(); lib.alch_debug_stamps_a(buf)
-names = ["loads + c2 + LDS write", "barrier", "passes 1-3 (compute)", "barriers between passes", "last pass + centred lift + stores", "final barrier"]
+names = ["loads + c2 + LDS write", "barrier", "pass 3 (stages 3-6, scalar twiddles)", "barriers between passes", "last pass + centred lift + stores", "final barrier", "pass 1 (stages 11-14, per-lane twiddles)", "pass 2 (stages 7-10)"]
 wgs = B * 4
-tot = sum(buf[i] for i in range(6))
+tot = sum(buf[i] for i in range(8))
 print(f"k_tensor_intt: mean cycles per workgroup (stamped wave) = {tot/wgs:.0f}")
 for i, nm in enumerate(names):
     print(f"  {nm:36s} {buf[i]/wgs:9.0f} cyc  {100.0*buf[i]/tot:5.1f} %")
