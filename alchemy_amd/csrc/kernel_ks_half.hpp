@@ -5,16 +5,17 @@
 //   * runs global stages 0..2 straight from HBM/L2 into registers (it reads the whole digit, computes only
 //     its own half of the stage-0 outputs -- one extra modular product per coefficient, +6.7 % of a
 //     transform's multiplies -- and writes n/2 words to LDS), then
-//   * finishes the remaining log n - 3 stages as a sub-transform of size n/2 in 64 KiB of LDS
-//     (prefix = 2 + half, see ntt_pass), the last pass feeding the hint multiply-accumulate from registers.
-// With 64 KiB LDS, 512 threads and <= 128 VGPRs per workgroup a CU holds two workgroups whose HBM phases
+//   * finishes the remaining log n - 3 stages as a sub-transform of size n/2 in 64 (+4 padding) KiB of LDS
+//     (prefix = 2 + half, see ntt_pass); the result takes one more trip through LDS into the lane-contiguous
+//     layout in which the hint rows, tensor inputs and results are read and written (1 KiB per wave access).
+// With 68 KiB LDS, 512 threads and <= 128 VGPRs per workgroup a CU holds two workgroups whose HBM phases
 // (tensor inputs, digits, hint, result stores) and barrier stalls hide under each other's butterflies;
 // the one-workgroup-per-CU form (k_ks_accum) idles the VALU during those phases.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ntt_engine.hpp"
 
-// experiment switches (tools/build_variants.sh)
+// experiment switches (tools/build_variant.sh)
 #ifndef ALCH_KS_SERIAL
 #define ALCH_KS_SERIAL true
 #endif
