@@ -76,7 +76,7 @@ static int fail(int code, const std::string& msg) {
     } while (0)
 
 extern "C" const char* alch_last_error(void) { return g_err.c_str(); }
-extern "C" uint32_t alch_version(void) { return (1u << 16) | 0u; }
+extern "C" uint32_t alch_version(void) { return (1u << 16) | 3u; }   // 1.3: + alch_decompose_base2, BaseBGad hints, alch_ct_mul_full, alch_buf_device_ptr, n = 2^16
 
 // ------------------------------------------------------------------------------------------------------
 // element-wise kernels (HBM-bound; 16 B per lane, grid-stride, ~2048 workgroups)
