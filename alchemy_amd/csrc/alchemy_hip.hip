@@ -200,15 +200,22 @@ __global__ void k_decompose_base2(DevRing<W> R, const W* c, W* digits, Scal<u32>
 // SymmSHE (*) on linear ciphertexts, element-wise on the CRT basis: c0 = a0 b0 s, c1 = (a0 b1 + a1 b0) s -> out,
 // c2 = a1 b1 s -> c2buf (one element per ciphertext).  sr2 = s R^2 (Montgomery).  Used by the BaseBGad key switch.
 template <typename W>
-__global__ void k_tensor_ew(DevRing<W> R, const W* a, const W* b, W* out, W* c2buf, size_t nct, Scal<W> sr2) {
+__global__ void k_tensor_ew(DevRing<W> R, const W* a, const W* b, W* out, W* c2buf, size_t nct, Scal<W> sr2, int dup) {
+    // R: the ring of out / c2buf (L limbs); a, b live on its last L - dup limbs; the dup leading limbs of the
+    // results are zero (modSwitch up: Rescale b -> (a,b), its q_a factor folded into sr2 by the host)
     const size_t n = (size_t)1 << R.logn;
-    const size_t Ln = (size_t)R.L * n;
+    const size_t Ln = (size_t)R.L * n, Lsn = (size_t)(R.L - dup) * n, off = (size_t)dup * n;
     for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < nct * Ln; w += (size_t)gridDim.x * blockDim.x) {
         const size_t ct = w / Ln, rem = w % Ln;
+        if (rem < off) {
+            out[2 * ct * Ln + rem] = 0; out[(2 * ct + 1) * Ln + rem] = 0; c2buf[ct * Ln + rem] = 0;
+            continue;
+        }
+        const size_t rs = rem - off, js = rs / n;
         const ModP<W> m = R.mod[rem / n];
-        const W a0 = a[2 * ct * Ln + rem], a1 = a[(2 * ct + 1) * Ln + rem];
-        const W b0 = b[2 * ct * Ln + rem], b1 = b[(2 * ct + 1) * Ln + rem];
-        const W x0 = mont_mul(a0, sr2.v[rem / n], m), x1 = mont_mul(a1, sr2.v[rem / n], m);      // a s R
+        const W a0 = a[2 * ct * Lsn + rs], a1 = a[(2 * ct + 1) * Lsn + rs];
+        const W b0 = b[2 * ct * Lsn + rs], b1 = b[(2 * ct + 1) * Lsn + rs];
+        const W x0 = mont_mul(a0, sr2.v[js], m), x1 = mont_mul(a1, sr2.v[js], m);      // a s R
         out[2 * ct * Ln + rem] = mont_mul(b0, x0, m);
         out[(2 * ct + 1) * Ln + rem] = add_mod(mont_mul(b1, x0, m), mont_mul(b0, x1, m), m.q);
         c2buf[ct * Ln + rem] = mont_mul(b1, x1, m);
@@ -920,7 +927,7 @@ static int do_mul_relin_unfused(alch_ring* r, const alch_hint* hint, const void*
         W* po = reinterpret_cast<W*>(reinterpret_cast<char*>(out) + done * ct_bytes);
         const size_t words = now * elem_words(r);
         hipLaunchKernelGGL((k_tensor_ew<W>), dim3(ew_grid(words)), dim3(256), 0, r->stream, dev_ring<W>(r), pa, pb, po,
-                           (W*)c2, now, sr2);
+                           (W*)c2, now, sr2, 0);
         HIP_TRY(hipGetLastError());
         if ((rc = do_crt<W>(r, c2, 0, now, true)) != ALCH_OK) return rc;
         for (size_t y0 = 0; y0 < now; y0 += 32768) {             // grid.y is 16-bit
@@ -1126,6 +1133,97 @@ static int do_mul_full(alch_ring* rh, alch_ring* rin, alch_ring* rout, const alc
     return ALCH_OK;
 }
 
+// The same mul_ for rings whose polynomial does not fit one LDS-resident transform (split crt, n = 2^16 / 2^15):
+// composed from the element-wise kernels and batched transforms, one ciphertext chunk at a time.
+template <typename W>
+static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, const alch_hint* hint, const void* a,
+                               const void* b, void* out, size_t batch, const uint64_t* s_pre, bool pow_out) {
+    const int L = rh->L, dup = L - rin->L, ddn = L - rout->L;
+    const size_t eb = elem_bytes(rh);
+    // scratch per ciphertext: key-switched pair (2) + c2 (1) + digits (L) + rescale ping-pong (2 + 2), in ring_h elements
+    const size_t per_ct = (size_t)(2 + 1 + L + 4) * eb;
+    size_t chunk = std::max<size_t>(1, ((size_t)1 << 30) / per_ct);
+    chunk = std::min(chunk, batch);
+    int rc = ensure_ws(&rh->ws_full, &rh->ws_full_bytes, chunk * per_ct);
+    if (rc != ALCH_OK) return rc;
+    char* ks = reinterpret_cast<char*>(rh->ws_full);
+    char* c2 = ks + chunk * 2 * eb;
+    char* dig = c2 + chunk * eb;
+    char* ping = dig + chunk * (size_t)L * eb;
+    char* pong = ping + chunk * 2 * eb;
+    uint64_t s_eff[MAXL];
+    for (int j = 0; j < rin->L; ++j) {
+        u64 v = s_pre ? s_pre[j] % rin->q[j] : 1;
+        for (int u = 0; u < dup; ++u) v = h_mulmod(v, rh->q[u] % rin->q[j], rin->q[j]);
+        s_eff[j] = v;
+    }
+    Scal<W> sr2;
+    scal_to_mont<W>(rin, s_eff, 2, sr2);
+    // DevRing of the suffix ring that starts at limb u of ring_h
+    auto suffix = [&](int u) {
+        DevRing<W> d = dev_ring<W>(rh);
+        d.L = L - u;
+        for (int j = 0; j + u < L; ++j) {
+            d.mod[j] = d.mod[j + u]; d.ninv_m[j] = d.ninv_m[j + u]; d.w1ninv_m[j] = d.w1ninv_m[j + u];
+            d.twf[j] = d.twf[j + u]; d.twi[j] = d.twi[j + u]; d.twp[j] = d.twp[j + u];
+        }
+        return d;
+    };
+    const size_t in_bytes = 2 * elem_bytes(rin), out_bytes = 2 * elem_bytes(rout);
+    for (size_t done = 0; done < batch; done += chunk) {
+        const size_t now = std::min(chunk, batch - done);
+        const W* pa = reinterpret_cast<const W*>(reinterpret_cast<const char*>(a) + done * in_bytes);
+        const W* pb = reinterpret_cast<const W*>(reinterpret_cast<const char*>(b) + done * in_bytes);
+        const size_t words = now * elem_words(rh);
+        // (*) and modSwitch up
+        hipLaunchKernelGGL((k_tensor_ew<W>), dim3(ew_grid(words)), dim3(256), 0, rh->stream, dev_ring<W>(rh), pa, pb, (W*)ks,
+                           (W*)c2, now, sr2, dup);
+        HIP_TRY(hipGetLastError());
+        // keySwitchQuadCirc on ring_h
+        if ((rc = do_crt<W>(rh, c2, 0, now, true)) != ALCH_OK) return rc;
+        for (size_t y0 = 0; y0 < now; y0 += 32768) {
+            const unsigned ny = (unsigned)std::min<size_t>(32768, now - y0);
+            hipLaunchKernelGGL((k_decompose_triv<W>), dim3(ew_grid((size_t)L * elem_words(rh)), ny), dim3(256), 0, rh->stream,
+                               dev_ring<W>(rh), reinterpret_cast<const W*>(c2 + y0 * eb), reinterpret_cast<W*>(dig + y0 * L * eb));
+            HIP_TRY(hipGetLastError());
+        }
+        if ((rc = do_crt<W>(rh, dig, 0, now * L, false)) != ALCH_OK) return rc;
+        hipLaunchKernelGGL((k_hint_mac<W>), dim3(ew_grid(words)), dim3(256), 0, rh->stream, dev_ring<W>(rh), (W*)ks, (const W*)dig,
+                           (const W*)hint->dptr, now, (u32)L);
+        HIP_TRY(hipGetLastError());
+        // modSwitch down: Pow basis, one limb at a time, then back to the CRT basis on ring_out
+        if ((rc = do_crt<W>(rh, ks, 0, 2 * now, true)) != ALCH_OK) return rc;
+        char* cur = ks;
+        for (int u = 0; u < ddn; ++u) {
+            char* nxt = (u + 1 == ddn) ? reinterpret_cast<char*>(out) + done * out_bytes : ((u & 1) ? pong : ping);
+            const DevRing<W> rs = suffix(u);
+            uint64_t inv[MAXL] = {0};
+            Scal<W> sm;
+            for (int j = 0; j < MAXL; ++j) sm.v[j] = 0;
+            const int bits = 8 * (int)sizeof(W);
+            for (int j = 1; j < rs.L; ++j) {
+                const u64 qj = rh->q[u + j];
+                inv[j] = h_powmod(rh->q[u] % qj, qj - 2, qj);
+                sm.v[j] = (W)h_mulmod(inv[j], h_powmod(2, (u64)bits, qj), qj);
+            }
+            const size_t total = 2 * now * (size_t)(rs.L - 1) * rh->n;
+            hipLaunchKernelGGL((k_rescale_drop0<W>), dim3(ew_grid(total)), dim3(256), 0, rh->stream, rs, (const W*)cur, (W*)nxt,
+                               2 * now, sm);
+            HIP_TRY(hipGetLastError());
+            cur = nxt;
+        }
+        if (!pow_out) {
+            // crt on ring_out, queued on ring_h's stream (same device tables: ring_out is a suffix of ring_h)
+            hipStream_t keep = rout->stream;
+            rout->stream = rh->stream;
+            rc = do_crt<W>(rout, out, 2 * done, 2 * now, false);
+            rout->stream = keep;
+            if (rc != ALCH_OK) return rc;
+        }
+    }
+    return ALCH_OK;
+}
+
 static bool is_suffix_ring(const alch_ring* small, const alch_ring* big) {
     if (small->m != big->m || small->word != big->word || small->L >= big->L) return false;
     for (int j = 0; j < small->L; ++j)
@@ -1144,7 +1242,6 @@ extern "C" int alch_ct_mul_full(const alch_hint* hint, const alch_buf* a, const 
     if (!is_suffix_ring(rin, rh)) return fail(ALCH_E_INVALID, "operand moduli must be the last limbs of the hint's ring (same word size)");
     if (!is_suffix_ring(rout, rh)) return fail(ALCH_E_INVALID, "output moduli must be the last limbs of the hint's ring (same word size)");
     if (rh->L - rout->L > MAXDROP) return fail(ALCH_E_UNSUPPORTED, "at most 3 limbs dropped per call");
-    if (split_ring(rh)) return fail(ALCH_E_UNSUPPORTED, "fused mul_ needs n <= 2^15 (32-bit) / 2^14 (64-bit); compose it from alch_ct_mul_relin and alch_buf_rescale_*");
     if (flags & ~(unsigned)ALCH_POW_OUT) return fail(ALCH_E_UNSUPPORTED, "only ALCH_POW_OUT is accepted");
     if (batch == 0) return ALCH_OK;
     if (a->n_elems < 2 * batch || b->n_elems < 2 * batch || out->n_elems < 2 * batch)
@@ -1159,7 +1256,12 @@ extern "C" int alch_ct_mul_full(const alch_hint* hint, const alch_buf* a, const 
         HIP_TRY(hipStreamWaitEvent(rh->stream, rh->ev_x, 0));
     }
     const bool pow_out = (flags & ALCH_POW_OUT) != 0;
-    int rc = rh->word == 4 ? do_mul_full<u32>(rh, rin, rout, hint, a->dptr, b->dptr, out->dptr, batch, s_pre, pow_out)
+    int rc;
+    if (split_ring(rh))
+        rc = rh->word == 4 ? do_mul_full_unfused<u32>(rh, rin, rout, hint, a->dptr, b->dptr, out->dptr, batch, s_pre, pow_out)
+                           : do_mul_full_unfused<u64>(rh, rin, rout, hint, a->dptr, b->dptr, out->dptr, batch, s_pre, pow_out);
+    else
+        rc = rh->word == 4 ? do_mul_full<u32>(rh, rin, rout, hint, a->dptr, b->dptr, out->dptr, batch, s_pre, pow_out)
                            : do_mul_full<u64>(rh, rin, rout, hint, a->dptr, b->dptr, out->dptr, batch, s_pre, pow_out);
     if (rc != ALCH_OK) return rc;
     HIP_TRY(hipEventRecord(rh->ev_x, rh->stream));

@@ -71,7 +71,8 @@ uint32_t alch_version(void);
  * failure of Lol's crtFuncs), builds device-resident twiddle tables with the root rule above.
  * Sizes: 32 <= m <= 2^17 (n <= 2^16) when every q < 2^31, m <= 2^16 (n <= 2^15) otherwise.  The largest size
  * of each word runs its transforms as two LDS-resident halves and the key switch unfused; the fused
- * kernels of alch_ct_mul_relin / alch_ct_mul_full cover n <= 2^15 (32-bit) / 2^14 (64-bit). */
+ * kernels of alch_ct_mul_relin / alch_ct_mul_full cover n <= 2^15 (32-bit) / 2^14 (64-bit); at the largest size both
+ * entry points run the same operations composed from element-wise kernels and batched transforms. */
 int alch_ring_create(uint32_t m, int L, const uint64_t *q, alch_ring **out);
 int alch_ring_destroy(alch_ring *ring);
 /* Host-only (no GPU needed): the root-rule constants of one modulus, for cross-checking against the

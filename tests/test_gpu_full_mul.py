@@ -67,20 +67,23 @@ def _case(oracle_lib, logn, qs_h, l_in, l_out, batch, seed, s_pre=None, pow_out=
     (13, SIX_QS[:5], 4, 3, 2),
     (15, CFG3_QS[:1] + SIX_QS[1:5], 4, 3, 2),
     (15, SIX_QS[:5], 4, 3, 9),
+    # n = 2^16 (split transforms): the same entry point composes the op from element-wise kernels and batched transforms
+    (16, SIX_QS, 5, 4, 2), (16, SIX_QS[:4], 2, 1, 3),
 ])
 def test_full_mul_matches_oracle(oracle_lib, logn, qs_h, l_in, l_out, batch):
     _case(oracle_lib, logn, qs_h, l_in, l_out, batch, seed=5000 + logn)
 
 
-@pytest.mark.parametrize("logn", [6, 11, 15])
+@pytest.mark.parametrize("logn", [6, 11, 15, 16])
 def test_full_mul_pow_out_with_scalar(oracle_lib, logn):
     qs = SIX_QS[:5]
     _case(oracle_lib, logn, qs, 4, 3, 2, seed=6000 + logn, s_pre=[pow(2, -1, q) for q in qs[1:]], pow_out=True)
 
 
-@pytest.mark.parametrize("logn", [5, 10, 14])
+@pytest.mark.parametrize("logn", [5, 10, 14, 15])
 def test_full_mul_60bit(oracle_lib, logn):
-    _case(oracle_lib, logn, Q60S, 2, 1, 2, seed=7000 + logn)
+    qs = [1152921504606584833, 1152921504598720513, 1152921504597016577] if logn == 15 else Q60S    # = 1 mod 2^16
+    _case(oracle_lib, logn, qs, 2, 1, 2, seed=7000 + logn)
 
 
 def test_full_mul_rejects_bad_rings():
