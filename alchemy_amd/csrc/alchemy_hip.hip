@@ -506,14 +506,15 @@ static hipError_t dispatch(int logn, const NttCall<u64>& c) {
 }
 
 template <typename W>
-static int do_crt(alch_ring* r, void* data, size_t first_elem, size_t count, bool inverse, const void* src = nullptr) {
+static int do_crt(alch_ring* r, void* data, size_t first_elem, size_t count, bool inverse, const void* src = nullptr,
+                  hipStream_t stream = nullptr) {
     // src != null: transform src[first_elem ..) into data[first_elem ..) (LDS-resident sizes only)
     if (count == 0) return ALCH_OK;
     NttCall<W> c{};
     c.src = reinterpret_cast<const W*>(src);
     c.op = inverse ? OP_CRTINV : OP_CRT;
     c.ring = &dev_ring<W>(r);
-    c.stream = r->stream;
+    c.stream = stream ? stream : r->stream;     // another ring's stream when the call is part of that ring's pipeline
     c.data = reinterpret_cast<W*>(data);
     const size_t polys = count * (size_t)r->L;
     // grids are 32-bit: split very large batches
@@ -1214,11 +1215,7 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
         }
         if (!pow_out) {
             // crt on ring_out, queued on ring_h's stream (same device tables: ring_out is a suffix of ring_h)
-            hipStream_t keep = rout->stream;
-            rout->stream = rh->stream;
-            rc = do_crt<W>(rout, out, 2 * done, 2 * now, false);
-            rout->stream = keep;
-            if (rc != ALCH_OK) return rc;
+            if ((rc = do_crt<W>(rout, out, 2 * done, 2 * now, false, nullptr, rh->stream)) != ALCH_OK) return rc;
         }
     }
     return ALCH_OK;
