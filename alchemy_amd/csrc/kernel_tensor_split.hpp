@@ -1,0 +1,102 @@
+// k_tensor_intt_split: kernel A (c2 = a1 b1 s, crtInv, centred lift -> TrivGad digit) with the inverse transform run
+// as TWO sequential half-size sub-transforms in 64 (+4) KiB of LDS, so that two independent 8-wave workgroups share
+// a CU (k_tensor_intt holds the whole polynomial in LDS: one 16-wave workgroup per CU whose waves move through the
+// load / transform / store phases in lock step).
+//
+// Gentleman-Sande order: the stages 14..1 of the n-point inverse act inside each half of the slots (sub-transform of
+// size n/2 with the big ring's twiddles, prefix = 2 + half, no n^-1); stage 0 pairs coefficient k of the two
+// halves.  Half 0's result waits in 32 registers per lane while half 1 is transformed; both are read from LDS in the
+// same lane-contiguous pattern, so stage 0, the n^-1 s scaling, the centred lift and the 16-byte digit stores are
+// lane-local.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ntt_engine.hpp"
+
+namespace alch {
+
+template <int LOGN>
+__global__ void __launch_bounds__(1 << (LOGN - 6), 4)
+k_tensor_intt_split(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict__ b, int32_t* __restrict__ digits,
+                    unsigned nitems, Scal<u32> spre) {
+    typedef u32 W;
+    constexpr int LOGM = LOGN - 1, M = 1 << LOGM, LT = LOGN - 6, T = 1 << LT;
+    typedef Geo<LOGM, LT> G;
+    static_assert(G::E == 32 && (LOGM - 2) % 4 == 0, "32 coefficients per lane, stages 4+4+4+2");
+    typedef u32 V __attribute__((ext_vector_type(4)));
+    typedef int32_t SV __attribute__((ext_vector_type(4)));
+    constexpr int NV = G::E / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W* lds = reinterpret_cast<W*>(smem);
+    const int L = R.L;
+    const u32 nct = nitems / (unsigned)L;
+    const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<W*>(a), 0, (u32)((size_t)nct * 2 * L * (2 * M) * 4), 0x00020000);
+    const auto rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<W*>(b), 0, (u32)((size_t)nct * 2 * L * (2 * M) * 4), 0x00020000);
+    const auto rd = __builtin_amdgcn_make_buffer_rsrc(digits, 0, (u32)((size_t)nct * L * (2 * M) * 4), 0x00020000);
+    const u32 lane16 = threadIdx.x * 16u;
+    constexpr u32 ROW = (u32)(2 * M) * 4u, SLICE = (u32)T * 16u, HALF = (u32)M * 4u;
+
+    for (unsigned item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const u32 ct = item / (unsigned)L, i = item % (unsigned)L;
+        const ModP<W> m = R.mod[i];
+        const W q = m.q, qni = m.qni;
+        const W ninv_s = mont_mul(R.ninv_m[i], spre.v[i], m), w1ninv_s = mont_mul(R.w1ninv_m[i], spre.v[i], m);
+        const u32 row = ((2 * ct + 1) * (u32)L + i) * ROW;           // a1 / b1 of this ciphertext and limb
+        const u32 drow = (ct * (u32)L + i) * ROW;
+        const int rot = (int)((item ^ (item >> 3)) & (NV - 1));      // slice order rotated per item (HBM channels)
+        const W* twi = R.twi[i];
+        V keep[NV];
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            // c2 = a1 b1 R^-1 (lazy) for this half of the slots -> LDS
+#pragma unroll
+            for (int r = 0; r < NV; ++r) {
+                const u32 so = row + (u32)half * HALF + SLICE * (u32)((r + rot) & (NV - 1));
+                const V va = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(ra, lane16, so, 0));
+                const V vb = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rb, lane16, so, 0));
+                V v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = mont_mul_lazy(va[e], vb[e], q, qni);
+                *reinterpret_cast<V*>(&lds[swz<LOGM>((tid + T * ((r + rot) & (NV - 1))) * 4)]) = v;
+            }
+            lds_barrier();
+            NoEpilogue none;
+            const int prefix = 2 + half;
+            ntt_pass<LOGM, LT, W, 10, 4, true, false, false, W, NoEpilogue&, false>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
+            pair_sync<LOGM>();
+            ntt_pass<LOGM, LT, W, 6, 4, true, false, false, W, NoEpilogue&, false>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
+            lds_barrier();
+            ntt_pass<LOGM, LT, W, 2, 4, true, false, false, W, NoEpilogue&, false>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
+            lds_barrier();
+            ntt_pass<LOGM, LT, W, 0, 2, true, false, false, W, NoEpilogue&, false>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
+            lds_barrier();
+            if (half == 0) {
+#pragma unroll
+                for (int r = 0; r < NV; ++r) keep[r] = *reinterpret_cast<const V*>(&lds[swz<LOGM>((tid + T * r) * 4)]);
+            } else {
+                // stage 0 with n^-1 s folded in, centred lift, digit stores (lane-contiguous, 16 bytes per lane)
+                const W hq = (q - 1) >> 1;
+#pragma unroll
+                for (int r = 0; r < NV; ++r) {
+                    const V hi = *reinterpret_cast<const V*>(&lds[swz<LOGM>((tid + T * r) * 4)]);
+                    SV z0, z1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const W x = csub(keep[r][e], q), y = csub(hi[e], q);
+                        const W c0 = csub(mont_mul_lazy((W)(x + y), ninv_s, q, qni), q);
+                        const W c1 = csub(mont_mul_lazy((W)(x - y + q), w1ninv_s, q, qni), q);
+                        z0[e] = c0 > hq ? (int32_t)c0 - (int32_t)q : (int32_t)c0;
+                        z1[e] = c1 > hq ? (int32_t)c1 - (int32_t)q : (int32_t)c1;
+                    }
+                    const u32 so = drow + SLICE * (u32)r;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(rd, 0, 0, 0)), z0), rd, lane16, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(rd, 0, 0, 0)), z1), rd, lane16, so + HALF, 0);
+                }
+            }
+            lds_barrier();                      // LDS is refilled next
+        }
+    }
+}
+
+}  // namespace alch

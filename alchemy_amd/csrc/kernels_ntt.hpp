@@ -406,6 +406,7 @@ k_ks_accum(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
 
 }  // namespace alch
 #include "kernel_rescale_out.hpp"
+#include "kernel_tensor_split.hpp"
 namespace alch {
 
 // ---- launcher ----------------------------------------------------------------------------------------
@@ -437,6 +438,22 @@ inline hipError_t run_call(const NttCall<W>& c) {
         break;
     }
     case OP_TENSOR_INTT: {
+        if constexpr (std::is_same<W, u32>::value && LOGN == 15) {
+            // default: two sequential half-size sub-transforms, two workgroups per CU (kernel_tensor_split.hpp): +0.5..1 %
+            // on the op, +2 % on the full mul_ against the whole-polynomial kernel below (ALCH_TI_SPLIT=0 selects that;
+            // a value > 1 = that many persistent workgroups)
+            static const int split = getenv("ALCH_TI_SPLIT") ? atoi(getenv("ALCH_TI_SPLIT")) : 1;
+            if (split) {
+                auto k = k_tensor_intt_split<LOGN>;
+                const size_t half_lds = (size_t)lds_words<LOGN - 1>() * sizeof(W);
+                if ((e = set_lds(k, half_lds)) != hipSuccess) return e;
+                const unsigned nitems = (unsigned)(c.nct * (size_t)R.L);
+                const unsigned grid = split > 1 && (unsigned)split < nitems ? (unsigned)split : nitems;
+                hipLaunchKernelGGL(k, dim3(grid), dim3(1 << (LOGN - 6)), half_lds, c.stream, R, c.a, c.b, (int32_t*)c.digits, nitems,
+                                   c.spre_r2);
+                break;
+            }
+        }
         auto k = k_tensor_intt<LOGN, W>;
         if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
         const unsigned nitems = (unsigned)(c.nct * (size_t)R.L);

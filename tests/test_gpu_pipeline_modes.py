@@ -42,6 +42,9 @@ WORKER = textwrap.dedent("""
     ({"ALCH_CHUNK": "8", "ALCH_KS_GRID": "8", "ALCH_TI_GRID": "8"}, 15, 9),
     ({"ALCH_TI_GRID": "-1"}, 11, 5),
     ({}, 15, 3),
+    ({"ALCH_TI_SPLIT": "0"}, 15, 5),                            # whole-polynomial tensor kernel instead of the split one
+    ({"ALCH_TI_SPLIT": "0", "ALCH_TI_GRID": "8", "ALCH_CHUNK": "8"}, 15, 9),
+    ({"ALCH_TI_SPLIT": "7", "ALCH_CHUNK": "8"}, 15, 9),         # split kernel on 7 persistent workgroups
 ])
 def test_launch_structure_does_not_change_results(env, logn, batch):
     e = dict(os.environ, **env)
