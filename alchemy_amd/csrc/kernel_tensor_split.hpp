@@ -12,6 +12,10 @@
 #include <hip/hip_runtime.h>
 #include "ntt_engine.hpp"
 
+#ifndef ALCH_TI_SPLIT_PASSES
+#define ALCH_TI_SPLIT_PASSES 4
+#endif
+
 namespace alch {
 
 template <int LOGN>
@@ -63,6 +67,16 @@ k_tensor_intt_split(DevRing<u32> R, const u32* __restrict__ a, const u32* __rest
             lds_barrier();
             NoEpilogue none;
             const int prefix = 2 + half;
+#if ALCH_TI_SPLIT_PASSES == 3
+            // 14 stages as 5 + 5 + 4: three LDS round trips per half instead of four (radix-32 groups: 32 coefficients and
+            // up to 31 per-lane twiddles in registers -- affordable here, there are no accumulators to keep)
+            ntt_pass<LOGM, LT, W, 9, 5, true, false, false, W, NoEpilogue&, false>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
+            lds_barrier();
+            ntt_pass<LOGM, LT, W, 4, 5, true, false, false, W, NoEpilogue&, false>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
+            lds_barrier();
+            ntt_pass<LOGM, LT, W, 0, 4, true, false, false, W, NoEpilogue&, false>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
+            lds_barrier();
+#else
             ntt_pass<LOGM, LT, W, 10, 4, true, false, false, W, NoEpilogue&, false>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
             pair_sync<LOGM>();
             ntt_pass<LOGM, LT, W, 6, 4, true, false, false, W, NoEpilogue&, false>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
@@ -71,6 +85,7 @@ k_tensor_intt_split(DevRing<u32> R, const u32* __restrict__ a, const u32* __rest
             lds_barrier();
             ntt_pass<LOGM, LT, W, 0, 2, true, false, false, W, NoEpilogue&, false>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
             lds_barrier();
+#endif
             if (half == 0) {
 #pragma unroll
                 for (int r = 0; r < NV; ++r) keep[r] = *reinterpret_cast<const V*>(&lds[swz<LOGM>((tid + T * r) * 4)]);

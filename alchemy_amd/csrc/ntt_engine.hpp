@@ -143,6 +143,7 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const TW* __restri
     constexpr int LB = LOGN - S0 - NS;
     constexpr int NG = G::E / R;                     // groups per thread
     static_assert(NG >= 1, "group larger than the per-thread coefficient budget");
+    static_assert(NS >= 1 && NS <= 5, "one to five stages per pass");
     typedef typename Vec4<W>::type V;
     constexpr int VL = Vec4<W>::LANES;
     // all 64 lanes of a wave share h when a run of equal h covers a whole wave
@@ -174,15 +175,18 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const TW* __restri
 #pragma unroll
             for (int r = 0; r < NS; ++r) {
                 const int half = R >> (r + 1);
-                TW w[1 << 3];
+                TW w[1 << 4];                    // up to five stages per pass (radix 32)
                 if (r == 0) { TW t1[1]; load_tw<TW, 1, UNIFORM>(tw, gm, t1); w[0] = t1[0]; }
                 else if (r == 1) { TW t2[2]; load_tw<TW, 2, UNIFORM>(tw, gm << 1, t2); w[0] = t2[0]; w[1] = t2[1]; }
                 else if (r == 2) { TW t4[4]; load_tw<TW, 4, UNIFORM>(tw, gm << 2, t4);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) w[c] = t4[c]; }
-                else { TW t8[8]; load_tw<TW, 8, UNIFORM>(tw, gm << 3, t8);
+                else if (r == 3) { TW t8[8]; load_tw<TW, 8, UNIFORM>(tw, gm << 3, t8);
 #pragma unroll
                     for (int c = 0; c < 8; ++c) w[c] = t8[c]; }
+                else { TW t16[16]; load_tw<TW, 16, UNIFORM>(tw, gm << 4, t16);
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) w[c] = t16[c]; }
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     if (k & half) continue;
@@ -193,15 +197,18 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const TW* __restri
 #pragma unroll
             for (int r = NS - 1; r >= 0; --r) {
                 const int half = R >> (r + 1);
-                TW w[1 << 3];
+                TW w[1 << 4];                    // up to five stages per pass (radix 32)
                 if (r == 0) { TW t1[1]; load_tw<TW, 1, UNIFORM>(tw, gm, t1); w[0] = t1[0]; }
                 else if (r == 1) { TW t2[2]; load_tw<TW, 2, UNIFORM>(tw, gm << 1, t2); w[0] = t2[0]; w[1] = t2[1]; }
                 else if (r == 2) { TW t4[4]; load_tw<TW, 4, UNIFORM>(tw, gm << 2, t4);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) w[c] = t4[c]; }
-                else { TW t8[8]; load_tw<TW, 8, UNIFORM>(tw, gm << 3, t8);
+                else if (r == 3) { TW t8[8]; load_tw<TW, 8, UNIFORM>(tw, gm << 3, t8);
 #pragma unroll
                     for (int c = 0; c < 8; ++c) w[c] = t8[c]; }
+                else { TW t16[16]; load_tw<TW, 16, UNIFORM>(tw, gm << 4, t16);
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) w[c] = t16[c]; }
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     if (k & half) continue;
