@@ -146,7 +146,7 @@ __global__ void k_scale(DevRing<W> R, W* dst, const W* src, size_t words, Scal<W
 // TrivGad decompose + reduce on one Pow-basis element: digits[i] (limb-major element i) limb j =
 // centred(c limb i) mod q_j.
 template <typename W>
-__global__ void k_decompose_triv(DevRing<W> R, const W* c, W* digits) {
+__global__ void k_decompose_triv(DevRing<W> R, const W* c, W* digits, int balanced) {
     typedef typename Signed<W>::type SW;
     const size_t n = (size_t)1 << R.logn;
     const size_t L = (size_t)R.L;
@@ -158,8 +158,9 @@ __global__ void k_decompose_triv(DevRing<W> R, const W* c, W* digits) {
         const W qi = R.mod[i].q, qj = R.mod[j].q;
         const W v = c[i * n + k];
         const SW z = v > ((qi - 1) >> 1) ? (SW)v - (SW)qi : (SW)v;
-        SW r = z % (SW)qj;
-        if (r < 0) r += (SW)qj;
+        SW r;
+        if (balanced) r = z < 0 ? z + (SW)qj : z;            // |z| < q_j for every pair of limbs: one add
+        else { r = z % (SW)qj; if (r < 0) r += (SW)qj; }
         digits[w] = (W)r;
     }
 }
@@ -771,8 +772,8 @@ extern "C" int alch_decompose_triv(alch_ring* r, const int64_t* c_pow, int64_t* 
     if ((rc = alch_buf_upload(s.b, 0, 1, c_pow)) != ALCH_OK) return rc;
     char* dig = reinterpret_cast<char*>(s.b->dptr) + elem_bytes(r);
     const size_t total = (size_t)r->L * elem_words(r);
-    if (r->word == 4) hipLaunchKernelGGL((k_decompose_triv<u32>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d32, (const u32*)s.b->dptr, (u32*)dig);
-    else hipLaunchKernelGGL((k_decompose_triv<u64>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d64, (const u64*)s.b->dptr, (u64*)dig);
+    if (r->word == 4) hipLaunchKernelGGL((k_decompose_triv<u32>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d32, (const u32*)s.b->dptr, (u32*)dig, r->balanced ? 1 : 0);
+    else hipLaunchKernelGGL((k_decompose_triv<u64>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d64, (const u64*)s.b->dptr, (u64*)dig, r->balanced ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return alch_buf_download(s.b, 1, (size_t)r->L, digits);
 }
@@ -859,8 +860,8 @@ extern "C" int alch_buf_decompose_triv(const alch_buf* src, size_t src_index, al
     const char* c = reinterpret_cast<const char*>(src->dptr) + src_index * elem_bytes(r);
     char* dig = reinterpret_cast<char*>(dst->dptr) + dst_first * elem_bytes(r);
     const size_t total = (size_t)r->L * elem_words(r);
-    if (r->word == 4) hipLaunchKernelGGL((k_decompose_triv<u32>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d32, (const u32*)c, (u32*)dig);
-    else hipLaunchKernelGGL((k_decompose_triv<u64>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d64, (const u64*)c, (u64*)dig);
+    if (r->word == 4) hipLaunchKernelGGL((k_decompose_triv<u32>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d32, (const u32*)c, (u32*)dig, r->balanced ? 1 : 0);
+    else hipLaunchKernelGGL((k_decompose_triv<u64>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d64, (const u64*)c, (u64*)dig, r->balanced ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return ALCH_OK;
 }
@@ -940,7 +941,7 @@ static int do_mul_relin_unfused(alch_ring* r, const alch_hint* hint, const void*
                                    dev_ring<W>(r), src, dst, first, kd, D);
             else
                 hipLaunchKernelGGL((k_decompose_triv<W>), dim3(ew_grid((size_t)r->L * elem_words(r)), ny), dim3(256), 0,
-                                   r->stream, dev_ring<W>(r), src, dst);
+                                   r->stream, dev_ring<W>(r), src, dst, r->balanced ? 1 : 0);
             HIP_TRY(hipGetLastError());
         }
         if ((rc = do_crt<W>(r, dig, 0, now * D, false)) != ALCH_OK) return rc;
@@ -1185,7 +1186,7 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
         for (size_t y0 = 0; y0 < now; y0 += 32768) {
             const unsigned ny = (unsigned)std::min<size_t>(32768, now - y0);
             hipLaunchKernelGGL((k_decompose_triv<W>), dim3(ew_grid((size_t)L * elem_words(rh)), ny), dim3(256), 0, rh->stream,
-                               dev_ring<W>(rh), reinterpret_cast<const W*>(c2 + y0 * eb), reinterpret_cast<W*>(dig + y0 * L * eb));
+                               dev_ring<W>(rh), reinterpret_cast<const W*>(c2 + y0 * eb), reinterpret_cast<W*>(dig + y0 * L * eb), rh->balanced ? 1 : 0);
             HIP_TRY(hipGetLastError());
         }
         if ((rc = do_crt<W>(rh, dig, 0, now * L, false)) != ALCH_OK) return rc;
