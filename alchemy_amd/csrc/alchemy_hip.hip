@@ -898,6 +898,9 @@ extern "C" int alch_hint_free(alch_hint* h) {
 // ------------------------------------------------------------------------------------------------------
 // the hot path
 // ------------------------------------------------------------------------------------------------------
+// rings whose limb-polynomial does not fit one LDS-resident transform (k_crt_split)
+static bool split_ring(const alch_ring* r) { return r->logn > (r->word == 4 ? 15 : 14); }
+
 // keySwitchQuadCirc hint (a * b), unfused: element-wise tensor product, batched crtInv of c2, decompose, batched crt
 // of the digits, hint inner product.  Serves
 //   * BaseBGad 2 hints (PT2CT.hs:140; Tunnel.hs:24 / HomomRLWR.hs:46 pick that gadget): D = sum_i ceil(log2 q_i)
@@ -932,6 +935,22 @@ static int do_mul_relin_unfused(alch_ring* r, const alch_hint* hint, const void*
                            (W*)c2, now, sr2, 0);
         HIP_TRY(hipGetLastError());
         if ((rc = do_crt<W>(r, c2, 0, now, true)) != ALCH_OK) return rc;
+        if (!base2 && split_ring(r)) {                              // decompose fused into the digit transforms
+            NttCall<W> dc{};
+            dc.op = OP_CRT_DIGITS;
+            dc.ring = &dev_ring<W>(r);
+            dc.stream = r->stream;
+            dc.src = reinterpret_cast<const W*>(c2);
+            dc.data = reinterpret_cast<W*>(dig);
+            dc.npoly = now * (size_t)r->L * (size_t)r->L;
+            dc.balanced = r->balanced;
+            hipError_t e = dispatch(r->logn, dc);
+            if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("crt_digits launch: ") + hipGetErrorString(e));
+            hipLaunchKernelGGL((k_hint_mac<W>), dim3(ew_grid(words)), dim3(256), 0, r->stream, dev_ring<W>(r), po, (const W*)dig,
+                               (const W*)hint->dptr, now, D);
+            HIP_TRY(hipGetLastError());
+            continue;
+        }
         for (size_t y0 = 0; y0 < now; y0 += 32768) {             // grid.y is 16-bit
             const unsigned ny = (unsigned)std::min<size_t>(32768, now - y0);
             const W* src = reinterpret_cast<const W*>(c2 + y0 * eb);
@@ -951,9 +970,6 @@ static int do_mul_relin_unfused(alch_ring* r, const alch_hint* hint, const void*
     }
     return ALCH_OK;
 }
-
-// rings whose limb-polynomial does not fit one LDS-resident transform (k_crt_split)
-static bool split_ring(const alch_ring* r) { return r->logn > (r->word == 4 ? 15 : 14); }
 
 template <typename W>
 static int do_mul_relin(alch_ring* r, const alch_hint* hint, const void* a, const void* b, void* out, size_t batch,
@@ -1183,13 +1199,18 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
         HIP_TRY(hipGetLastError());
         // keySwitchQuadCirc on ring_h
         if ((rc = do_crt<W>(rh, c2, 0, now, true)) != ALCH_OK) return rc;
-        for (size_t y0 = 0; y0 < now; y0 += 32768) {
-            const unsigned ny = (unsigned)std::min<size_t>(32768, now - y0);
-            hipLaunchKernelGGL((k_decompose_triv<W>), dim3(ew_grid((size_t)L * elem_words(rh)), ny), dim3(256), 0, rh->stream,
-                               dev_ring<W>(rh), reinterpret_cast<const W*>(c2 + y0 * eb), reinterpret_cast<W*>(dig + y0 * L * eb), rh->balanced ? 1 : 0);
-            HIP_TRY(hipGetLastError());
+        {   // decompose + reduce fused into the digit transforms (k_crt_split_digits)
+            NttCall<W> dc{};
+            dc.op = OP_CRT_DIGITS;
+            dc.ring = &dev_ring<W>(rh);
+            dc.stream = rh->stream;
+            dc.src = reinterpret_cast<const W*>(c2);
+            dc.data = reinterpret_cast<W*>(dig);
+            dc.npoly = now * (size_t)L * (size_t)L;
+            dc.balanced = rh->balanced;
+            hipError_t e = dispatch(rh->logn, dc);
+            if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("crt_digits launch: ") + hipGetErrorString(e));
         }
-        if ((rc = do_crt<W>(rh, dig, 0, now * L, false)) != ALCH_OK) return rc;
         hipLaunchKernelGGL((k_hint_mac<W>), dim3(ew_grid(words)), dim3(256), 0, rh->stream, dev_ring<W>(rh), (W*)ks, (const W*)dig,
                            (const W*)hint->dptr, now, (u32)L);
         HIP_TRY(hipGetLastError());

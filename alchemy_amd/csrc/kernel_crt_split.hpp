@@ -110,6 +110,75 @@ __global__ void __launch_bounds__(Geo<LOGN - 1>::T) k_crt_split(DevRing<W> R, W*
     }
 }
 
+// crt of the reduced TrivGad digits for the unfused key switch on split rings, decompose fused into the loader:
+// workgroup p = (ciphertext, digit i, target limb j) reads limb i of c2 (Pow basis, [0, q_i)), takes the centred
+// lift, reduces it mod q_j on the fly (Lol: decompose, then reduce) and runs the forward transform of limb j into
+// digits[p].  Saves the separate decompose pass (L^2 polynomials written and read back).
+template <int LOGN, typename W>
+__global__ void __launch_bounds__(Geo<LOGN - 1>::T) k_crt_split_digits(DevRing<W> R, const W* __restrict__ c2pow, W* __restrict__ digits,
+                                                                       int balanced) {
+    constexpr int LOGM = LOGN - 1;
+    typedef Geo<LOGM> G;
+    typedef typename Vec4<W>::type V;
+    typedef typename Signed<W>::type SW;
+    constexpr int VL = Vec4<W>::LANES;
+    constexpr int M = G::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W* lds = reinterpret_cast<W*>(smem);
+    const size_t p = blockIdx.x;
+    const int L = R.L;
+    const int j = (int)(p % (size_t)L), i = (int)((p / (size_t)L) % (size_t)L);
+    const size_t ct = p / ((size_t)L * L);
+    const W* src = c2pow + (ct * (size_t)L + i) * (size_t)(2 * M);
+    W* lo = digits + p * (size_t)(2 * M);
+    W* hi = lo + M;
+    const ModP<W> m = R.mod[j];
+    const W q = m.q, qni = m.qni, qi = R.mod[i].q, hqi = (qi - 1) >> 1;
+    const int tid = threadIdx.x;
+    auto reduce = [&](W v) -> W {                         // centred lift of v mod q_i, reduced mod q_j
+        const SW z = v > hqi ? (SW)v - (SW)qi : (SW)v;
+        if (balanced) return z < 0 ? (W)(z + (SW)q) : (W)z;
+        SW r = z % (SW)q;
+        return r < 0 ? (W)(r + (SW)q) : (W)r;
+    };
+    const W w1 = R.twf[j][1];
+#pragma unroll
+    for (int r = 0; r < G::E / VL; ++r) {
+        const int idx = (tid + G::T * r) * VL;
+        const V x = *reinterpret_cast<const V*>(src + idx), y = *reinterpret_cast<const V*>(src + M + idx);
+        V u0, u1;
+#pragma unroll
+        for (int e = 0; e < VL; ++e) {
+            const W xr = reduce(x[e]);
+            const W t = csub(mont_mul_lazy(reduce(y[e]), w1, q, qni), q);
+            u0[e] = xr + t;
+            u1[e] = csub((W)(xr + (q - t)), q);
+        }
+        *reinterpret_cast<V*>(&lds[swz<LOGM>(idx)]) = u0;
+        *reinterpret_cast<V*>(hi + idx) = u1;
+    }
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        W* dst = half ? hi : lo;
+        if (half) {
+            stage_in<LOGM, W>(lds, [&](int idx) { return *reinterpret_cast<const V*>(hi + idx); });
+        }
+        lds_barrier();
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));
+        ntt_forward<LOGM, W, false>(lds, fwd_tw(R, j), R.twf[j], q, qni, t2, NoEpilogue(), 2 + half);
+#pragma unroll
+        for (int r = 0; r < G::E / VL; ++r) {
+            const int idx = (t2 + G::T * r) * VL;
+            V v = *reinterpret_cast<const V*>(&lds[swz<LOGM>(idx)]);
+#pragma unroll
+            for (int e = 0; e < VL; ++e) v[e] = csub(v[e], q);
+            *reinterpret_cast<V*>(dst + idx) = v;
+        }
+        lds_barrier();
+    }
+}
+
 template <typename W, int LOGN>
 inline hipError_t run_call_split(const NttCall<W>& c) {
     typedef Geo<LOGN - 1> G;
@@ -123,6 +192,10 @@ inline hipError_t run_call_split(const NttCall<W>& c) {
         auto k = k_crt_split<LOGN, W, true>;
         if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(G::T), lds_bytes, c.stream, *c.ring, c.data, c.first_poly);
+    } else if (c.op == OP_CRT_DIGITS) {
+        auto k = k_crt_split_digits<LOGN, W>;
+        if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(G::T), lds_bytes, c.stream, *c.ring, c.src, c.data, c.balanced ? 1 : 0);
     } else {
         return hipErrorInvalidValue;        // the fused kernels exist for LDS-resident sizes only
     }

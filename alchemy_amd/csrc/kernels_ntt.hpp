@@ -55,7 +55,8 @@ template <> struct Signed<u64> { typedef int64_t type; };
 #include "kernel_ks_half.hpp"
 namespace alch {
 
-enum OpKind { OP_CRT = 0, OP_CRTINV = 1, OP_TENSOR_INTT = 2, OP_KS_ACCUM = 3, OP_RESCALE_OUT = 4 };
+enum OpKind { OP_CRT = 0, OP_CRTINV = 1, OP_TENSOR_INTT = 2, OP_KS_ACCUM = 3, OP_RESCALE_OUT = 4,
+              OP_CRT_DIGITS = 5 /* split rings: src = c2 (Pow), data = digits [ct][L][L][n], npoly = ct*L*L */ };
 
 constexpr int MAXDROP = 3;
 template <typename W>
