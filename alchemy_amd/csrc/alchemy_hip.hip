@@ -201,7 +201,9 @@ __global__ void k_decompose_base2(DevRing<W> R, const W* c, W* digits, Scal<u32>
 // SymmSHE (*) on linear ciphertexts, element-wise on the CRT basis: c0 = a0 b0 s, c1 = (a0 b1 + a1 b0) s -> out,
 // c2 = a1 b1 s -> c2buf (one element per ciphertext).  sr2 = s R^2 (Montgomery).  Used by the BaseBGad key switch.
 template <typename W>
-__global__ void k_tensor_ew(DevRing<W> R, const W* a, const W* b, W* out, W* c2buf, size_t nct, Scal<W> sr2, int dup) {
+__global__ void k_tensor_ew(DevRing<W> R, const W* a, const W* b, W* out, W* c2buf, size_t nct, Scal<W> sr2, int dup,
+                            W* c2crt = nullptr) {
+    // c2crt != null: a second copy of c2 that stays in the CRT basis (the diagonal digits of the key switch)
     // R: the ring of out / c2buf (L limbs); a, b live on its last L - dup limbs; the dup leading limbs of the
     // results are zero (modSwitch up: Rescale b -> (a,b), its q_a factor folded into sr2 by the host)
     const size_t n = (size_t)1 << R.logn;
@@ -210,6 +212,7 @@ __global__ void k_tensor_ew(DevRing<W> R, const W* a, const W* b, W* out, W* c2b
         const size_t ct = w / Ln, rem = w % Ln;
         if (rem < off) {
             out[2 * ct * Ln + rem] = 0; out[(2 * ct + 1) * Ln + rem] = 0; c2buf[ct * Ln + rem] = 0;
+            if (c2crt) c2crt[ct * Ln + rem] = 0;
             continue;
         }
         const size_t rs = rem - off, js = rs / n;
@@ -219,14 +222,18 @@ __global__ void k_tensor_ew(DevRing<W> R, const W* a, const W* b, W* out, W* c2b
         const W x0 = mont_mul(a0, sr2.v[js], m), x1 = mont_mul(a1, sr2.v[js], m);      // a s R
         out[2 * ct * Ln + rem] = mont_mul(b0, x0, m);
         out[(2 * ct + 1) * Ln + rem] = add_mod(mont_mul(b1, x0, m), mont_mul(b0, x1, m), m.q);
-        c2buf[ct * Ln + rem] = mont_mul(b1, x1, m);
+        const W c2v = mont_mul(b1, x1, m);
+        c2buf[ct * Ln + rem] = c2v;
+        if (c2crt) c2crt[ct * Ln + rem] = c2v;
     }
 }
 
 // keySwitchQuadCirc's inner product for a many-digit gadget: out_c += sum_d digit_d * hint_{d,c} (CRT basis).
 // digits: [ct][D][L][n]; hint: [D][2][L][n] in Montgomery form.
 template <typename W>
-__global__ void k_hint_mac(DevRing<W> R, W* out, const W* digits, const W* hint, size_t nct, u32 D) {
+__global__ void k_hint_mac(DevRing<W> R, W* out, const W* digits, const W* hint, size_t nct, u32 D, const W* diag = nullptr) {
+    // diag != null (TrivGad, D = L): digit d reduced into its own limb d is c2's limb d itself, read from the CRT-basis
+    // copy `diag` [ct][L][n] instead of a transformed digit (those slots of `digits` are never written)
     const size_t n = (size_t)1 << R.logn;
     const size_t Ln = (size_t)R.L * n;
     for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < nct * Ln; w += (size_t)gridDim.x * blockDim.x) {
@@ -235,7 +242,7 @@ __global__ void k_hint_mac(DevRing<W> R, W* out, const W* digits, const W* hint,
         W acc0 = out[2 * ct * Ln + rem], acc1 = out[(2 * ct + 1) * Ln + rem];
         const W* dg = digits + ct * (size_t)D * Ln + rem;
         for (u32 d = 0; d < D; ++d) {
-            const W x = dg[(size_t)d * Ln];
+            const W x = (diag && d == (u32)(rem / n)) ? diag[ct * Ln + rem] : dg[(size_t)d * Ln];
             acc0 = add_mod(acc0, mont_mul(x, hint[(size_t)(2 * d) * Ln + rem], m), m.q);
             acc1 = add_mod(acc1, mont_mul(x, hint[(size_t)(2 * d + 1) * Ln + rem], m), m.q);
         }
@@ -916,12 +923,14 @@ static int do_mul_relin_unfused(alch_ring* r, const alch_hint* hint, const void*
     const u32 D = base2 ? (u32)base2_layout(r, first, kd) : (u32)r->L;
     const size_t eb = elem_bytes(r);
     // scratch: c2 (1 element) + digits (D elements) per ciphertext of a chunk, at most ~1 GiB
-    size_t chunk = std::max<size_t>(1, ((size_t)1 << 30) / ((D + 1) * eb));
+    size_t chunk = std::max<size_t>(1, ((size_t)1 << 30) / ((D + 2) * eb));
     chunk = std::min(chunk, batch);
-    int rc = ensure_ws(&r->ws_digits, &r->ws_digits_bytes, chunk * (D + 1) * eb);
+    int rc = ensure_ws(&r->ws_digits, &r->ws_digits_bytes, chunk * (D + 2) * eb);
     if (rc != ALCH_OK) return rc;
     char* c2 = reinterpret_cast<char*>(r->ws_digits);
-    char* dig = c2 + chunk * eb;
+    char* c2crt = c2 + chunk * eb;                       // CRT-basis copy of c2 (diagonal digits, split rings)
+    char* dig = c2crt + chunk * eb;
+    const bool fused_digits = !base2 && split_ring(r);
     Scal<W> sr2;
     scal_to_mont<W>(r, s_pre, 2, sr2);
     const size_t ct_bytes = 2 * eb;
@@ -932,10 +941,10 @@ static int do_mul_relin_unfused(alch_ring* r, const alch_hint* hint, const void*
         W* po = reinterpret_cast<W*>(reinterpret_cast<char*>(out) + done * ct_bytes);
         const size_t words = now * elem_words(r);
         hipLaunchKernelGGL((k_tensor_ew<W>), dim3(ew_grid(words)), dim3(256), 0, r->stream, dev_ring<W>(r), pa, pb, po,
-                           (W*)c2, now, sr2, 0);
+                           (W*)c2, now, sr2, 0, fused_digits ? (W*)c2crt : (W*)nullptr);
         HIP_TRY(hipGetLastError());
         if ((rc = do_crt<W>(r, c2, 0, now, true)) != ALCH_OK) return rc;
-        if (!base2 && split_ring(r)) {                              // decompose fused into the digit transforms
+        if (fused_digits) {                                         // decompose fused into the digit transforms
             NttCall<W> dc{};
             dc.op = OP_CRT_DIGITS;
             dc.ring = &dev_ring<W>(r);
@@ -947,7 +956,7 @@ static int do_mul_relin_unfused(alch_ring* r, const alch_hint* hint, const void*
             hipError_t e = dispatch(r->logn, dc);
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("crt_digits launch: ") + hipGetErrorString(e));
             hipLaunchKernelGGL((k_hint_mac<W>), dim3(ew_grid(words)), dim3(256), 0, r->stream, dev_ring<W>(r), po, (const W*)dig,
-                               (const W*)hint->dptr, now, D);
+                               (const W*)hint->dptr, now, D, (const W*)c2crt);
             HIP_TRY(hipGetLastError());
             continue;
         }
@@ -1158,15 +1167,16 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
                                const void* b, void* out, size_t batch, const uint64_t* s_pre, bool pow_out) {
     const int L = rh->L, dup = L - rin->L, ddn = L - rout->L;
     const size_t eb = elem_bytes(rh);
-    // scratch per ciphertext: key-switched pair (2) + c2 (1) + digits (L) + rescale ping-pong (2 + 2), in ring_h elements
-    const size_t per_ct = (size_t)(2 + 1 + L + 4) * eb;
+    // scratch per ciphertext: key-switched pair (2) + c2 in both bases (2) + digits (L) + rescale ping-pong (2 + 2), in ring_h elements
+    const size_t per_ct = (size_t)(2 + 2 + L + 4) * eb;
     size_t chunk = std::max<size_t>(1, ((size_t)1 << 30) / per_ct);
     chunk = std::min(chunk, batch);
     int rc = ensure_ws(&rh->ws_full, &rh->ws_full_bytes, chunk * per_ct);
     if (rc != ALCH_OK) return rc;
     char* ks = reinterpret_cast<char*>(rh->ws_full);
     char* c2 = ks + chunk * 2 * eb;
-    char* dig = c2 + chunk * eb;
+    char* c2crt = c2 + chunk * eb;
+    char* dig = c2crt + chunk * eb;
     char* ping = dig + chunk * (size_t)L * eb;
     char* pong = ping + chunk * 2 * eb;
     uint64_t s_eff[MAXL];
@@ -1195,7 +1205,7 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
         const size_t words = now * elem_words(rh);
         // (*) and modSwitch up
         hipLaunchKernelGGL((k_tensor_ew<W>), dim3(ew_grid(words)), dim3(256), 0, rh->stream, dev_ring<W>(rh), pa, pb, (W*)ks,
-                           (W*)c2, now, sr2, dup);
+                           (W*)c2, now, sr2, dup, (W*)c2crt);
         HIP_TRY(hipGetLastError());
         // keySwitchQuadCirc on ring_h
         if ((rc = do_crt<W>(rh, c2, 0, now, true)) != ALCH_OK) return rc;
@@ -1212,7 +1222,7 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("crt_digits launch: ") + hipGetErrorString(e));
         }
         hipLaunchKernelGGL((k_hint_mac<W>), dim3(ew_grid(words)), dim3(256), 0, rh->stream, dev_ring<W>(rh), (W*)ks, (const W*)dig,
-                           (const W*)hint->dptr, now, (u32)L);
+                           (const W*)hint->dptr, now, (u32)L, (const W*)c2crt);
         HIP_TRY(hipGetLastError());
         // modSwitch down: Pow basis, one limb at a time, then back to the CRT basis on ring_out
         if ((rc = do_crt<W>(rh, ks, 0, 2 * now, true)) != ALCH_OK) return rc;

@@ -128,6 +128,7 @@ __global__ void __launch_bounds__(Geo<LOGN - 1>::T) k_crt_split_digits(DevRing<W
     const size_t p = blockIdx.x;
     const int L = R.L;
     const int j = (int)(p % (size_t)L), i = (int)((p / (size_t)L) % (size_t)L);
+    if (i == j) return;          // the diagonal digit is c2's own limb in the CRT basis: the inner product reads it there
     const size_t ct = p / ((size_t)L * L);
     const W* src = c2pow + (ct * (size_t)L + i) * (size_t)(2 * M);
     W* lo = digits + p * (size_t)(2 * M);
