@@ -233,21 +233,41 @@ __global__ void k_tensor_ew(DevRing<W> R, const W* a, const W* b, W* out, W* c2b
 template <typename W>
 __global__ void k_hint_mac(DevRing<W> R, W* out, const W* digits, const W* hint, size_t nct, u32 D, const W* diag = nullptr) {
     // diag != null (TrivGad, D = L): digit d reduced into its own limb d is c2's limb d itself, read from the CRT-basis
-    // copy `diag` [ct][L][n] instead of a transformed digit (those slots of `digits` are never written)
+    // copy `diag` [ct][L][n] instead of a transformed digit (those slots of `digits` are never written).
+    // One thread owns one (limb, slot) of TILE consecutive ciphertexts, so a hint word is loaded once per TILE
+    // products (the hint is the larger stream for a many-digit gadget: 2 D words against D per ciphertext).
+    constexpr int TILE = 4;
     const size_t n = (size_t)1 << R.logn;
     const size_t Ln = (size_t)R.L * n;
-    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < nct * Ln; w += (size_t)gridDim.x * blockDim.x) {
-        const size_t ct = w / Ln, rem = w % Ln;
+    const size_t ntile = (nct + TILE - 1) / TILE;
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < ntile * Ln; w += (size_t)gridDim.x * blockDim.x) {
+        const size_t ct0 = (w / Ln) * TILE, rem = w % Ln;
         const ModP<W> m = R.mod[rem / n];
-        W acc0 = out[2 * ct * Ln + rem], acc1 = out[(2 * ct + 1) * Ln + rem];
-        const W* dg = digits + ct * (size_t)D * Ln + rem;
-        for (u32 d = 0; d < D; ++d) {
-            const W x = (diag && d == (u32)(rem / n)) ? diag[ct * Ln + rem] : dg[(size_t)d * Ln];
-            acc0 = add_mod(acc0, mont_mul(x, hint[(size_t)(2 * d) * Ln + rem], m), m.q);
-            acc1 = add_mod(acc1, mont_mul(x, hint[(size_t)(2 * d + 1) * Ln + rem], m), m.q);
+        const u32 limb = (u32)(rem / n);
+        W acc0[TILE], acc1[TILE];
+#pragma unroll
+        for (int c = 0; c < TILE; ++c) {
+            const bool live = ct0 + c < nct;
+            acc0[c] = live ? out[2 * (ct0 + c) * Ln + rem] : (W)0;
+            acc1[c] = live ? out[(2 * (ct0 + c) + 1) * Ln + rem] : (W)0;
         }
-        out[2 * ct * Ln + rem] = acc0;
-        out[(2 * ct + 1) * Ln + rem] = acc1;
+        for (u32 d = 0; d < D; ++d) {
+            const W h0 = hint[(size_t)(2 * d) * Ln + rem], h1 = hint[(size_t)(2 * d + 1) * Ln + rem];
+#pragma unroll
+            for (int c = 0; c < TILE; ++c) {
+                if (ct0 + c >= nct) continue;
+                const size_t ct = ct0 + c;
+                const W x = (diag && d == limb) ? diag[ct * Ln + rem] : digits[(ct * (size_t)D + d) * Ln + rem];
+                acc0[c] = add_mod(acc0[c], mont_mul(x, h0, m), m.q);
+                acc1[c] = add_mod(acc1[c], mont_mul(x, h1, m), m.q);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < TILE; ++c) {
+            if (ct0 + c >= nct) continue;
+            out[2 * (ct0 + c) * Ln + rem] = acc0[c];
+            out[(2 * (ct0 + c) + 1) * Ln + rem] = acc1[c];
+        }
     }
 }
 
