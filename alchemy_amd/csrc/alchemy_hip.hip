@@ -980,6 +980,22 @@ static int do_mul_relin_unfused(alch_ring* r, const alch_hint* hint, const void*
             HIP_TRY(hipGetLastError());
             continue;
         }
+        if (base2 && !split_ring(r)) {                              // BaseBGad: digits computed in the transforms' loader
+            NttCall<W> dc{};
+            dc.op = OP_CRT_BASE2;
+            dc.ring = &dev_ring<W>(r);
+            dc.stream = r->stream;
+            dc.src = reinterpret_cast<const W*>(c2);
+            dc.data = reinterpret_cast<W*>(dig);
+            dc.npoly = now * (size_t)D * (size_t)r->L;
+            dc.b2_first = first; dc.b2_kd = kd; dc.b2_D = D;
+            hipError_t e = dispatch(r->logn, dc);
+            if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("crt_base2 launch: ") + hipGetErrorString(e));
+            hipLaunchKernelGGL((k_hint_mac<W>), dim3(ew_grid(words)), dim3(256), 0, r->stream, dev_ring<W>(r), po, (const W*)dig,
+                               (const W*)hint->dptr, now, D);
+            HIP_TRY(hipGetLastError());
+            continue;
+        }
         for (size_t y0 = 0; y0 < now; y0 += 32768) {             // grid.y is 16-bit
             const unsigned ny = (unsigned)std::min<size_t>(32768, now - y0);
             const W* src = reinterpret_cast<const W*>(c2 + y0 * eb);

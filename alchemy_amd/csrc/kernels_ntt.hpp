@@ -56,7 +56,8 @@ template <> struct Signed<u64> { typedef int64_t type; };
 namespace alch {
 
 enum OpKind { OP_CRT = 0, OP_CRTINV = 1, OP_TENSOR_INTT = 2, OP_KS_ACCUM = 3, OP_RESCALE_OUT = 4,
-              OP_CRT_DIGITS = 5 /* split rings: src = c2 (Pow), data = digits [ct][L][L][n], npoly = ct*L*L */ };
+              OP_CRT_DIGITS = 5 /* split rings: src = c2 (Pow), data = digits [ct][L][L][n], npoly = ct*L*L */,
+              OP_CRT_BASE2 = 6 /* src = c2 (Pow), data = digits [ct][D][L][n], npoly = ct*D*L; b2_first / b2_kd / b2_D */ };
 
 constexpr int MAXDROP = 3;
 template <typename W>
@@ -90,6 +91,8 @@ struct NttCall {
     void* stash;           // OP_RESCALE_OUT: Signed<W> [grid][ddn][n]
     unsigned stash_slots;
     bool pow_out;
+    Scal<u32> b2_first, b2_kd;   // OP_CRT_BASE2: BaseBGad 2 layout (first digit and digit count of every limb)
+    u32 b2_D;
 };
 
 // ---- staging helpers -------------------------------------------------------------------------------
@@ -131,6 +134,56 @@ __global__ void __launch_bounds__(Geo<LOGN>::T) k_crt(DevRing<W> R, W* data, con
 #pragma unroll
         for (int e = 0; e < VL; ++e) v[e] = csub(v[e], q);
         *reinterpret_cast<V*>(poly + idx) = v;
+    }
+}
+
+// crt of the reduced BaseBGad 2 digits with decompose + reduce in the loader (unfused key switch, LDS-resident
+// sizes): workgroup p = (ciphertext, digit d, target limb j).  Digit d is bit t of source limb i; with u = -(centred
+// lift of c2_i) the balanced binary digits have the closed form  d_t = -((u >> t) & 1)  for t < k - 1 and the top
+// digit is  -(u >> (k - 1))  (arithmetic shifts), so no digit depends on the ones below it.
+template <int LOGN, typename W>
+__global__ void __launch_bounds__(Geo<LOGN>::T) k_crt_base2_digits(DevRing<W> R, const W* __restrict__ c2pow, W* __restrict__ digits,
+                                                                   Scal<u32> first_digit, Scal<u32> kd, u32 D) {
+    typedef Geo<LOGN> G;
+    typedef typename Vec4<W>::type V;
+    typedef typename Signed<W>::type SW;
+    constexpr int VL = Vec4<W>::LANES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W* lds = reinterpret_cast<W*>(smem);
+    const size_t p = blockIdx.x;
+    const int L = R.L;
+    const int j = (int)(p % (size_t)L);
+    const u32 d = (u32)((p / (size_t)L) % D);
+    const size_t ct = p / ((size_t)L * D);
+    int i = 0;
+    for (int c = 1; c < L; ++c) if (d >= first_digit.v[c]) i = c;
+    const u32 t = d - first_digit.v[i];
+    const bool top = t + 1 == kd.v[i];
+    const W* src = c2pow + (ct * (size_t)L + i) * (size_t)G::N;
+    W* dst = digits + p * (size_t)G::N;
+    const W q = R.mod[j].q, qni = R.mod[j].qni, qi = R.mod[i].q, hqi = (qi - 1) >> 1;
+    stage_in<LOGN, W>(lds, [&](int idx) {
+        const V v = *reinterpret_cast<const V*>(src + idx);
+        V o;
+#pragma unroll
+        for (int e = 0; e < VL; ++e) {
+            const SW z = v[e] > hqi ? (SW)v[e] - (SW)qi : (SW)v[e];
+            const SW u = -z;
+            SW dg = top ? -(u >> t) : -((u >> t) & 1);
+            if (top) { dg %= (SW)q; }                       // the top digit is tiny but its size depends on q_i vs 2^k
+            o[e] = dg < 0 ? (W)(dg + (SW)q) : (W)dg;
+        }
+        return o;
+    });
+    lds_barrier();
+    ntt_forward<LOGN, W, false>(lds, fwd_tw(R, j), R.twf[j], q, qni, (int)threadIdx.x, NoEpilogue());
+#pragma unroll
+    for (int r = 0; r < G::E / VL; ++r) {
+        const int idx = (threadIdx.x + G::T * r) * VL;
+        V v = *reinterpret_cast<const V*>(&lds[swz<LOGN>(idx)]);
+#pragma unroll
+        for (int e = 0; e < VL; ++e) v[e] = csub(v[e], q);
+        *reinterpret_cast<V*>(dst + idx) = v;
     }
 }
 
@@ -525,6 +578,12 @@ inline hipError_t run_call(const NttCall<W>& c) {
             hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), lds_bytes, c.stream, R, c.a, c.b, (const SW*)c.digits,
                                c.hint, c.out, (unsigned)c.nct, c.spre_r2, c.dup);
         }
+        break;
+    }
+    case OP_CRT_BASE2: {
+        auto k = k_crt_base2_digits<LOGN, W>;
+        if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(G::T), lds_bytes, c.stream, R, c.src, c.data, c.b2_first, c.b2_kd, c.b2_D);
         break;
     }
     case OP_RESCALE_OUT: {
