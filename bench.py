@@ -99,6 +99,7 @@ def main():
     dev_index = int(os.environ.get("ALCH_FORCE_DEVICE", local_rank))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    torch.empty(1, device=dev)          # make this rank's device current in the shared HIP runtime before the library binds to it
     red_dev = None if os.environ.get("ALCH_DIST_BACKEND") == "gloo" else dev
 
     ring = Ring(2 << LOGN, CFG3_QS)
