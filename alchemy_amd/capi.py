@@ -25,6 +25,7 @@ SYMBOLS = [
     "alch_buf_crtinv", "alch_buf_mul", "alch_buf_add", "alch_buf_checksum", "alch_hint_load", "alch_hint_from_buf",
     "alch_hint_free", "alch_ct_mul_relin", "alch_buf_rescale_drop0", "alch_buf_sub", "alch_buf_scale",
     "alch_buf_decompose_triv", "alch_buf_rescale_add0", "alch_decompose_base2", "alch_ct_mul_full", "alch_buf_device_ptr",
+    "alch_ring_set_option",
 ]
 
 
@@ -35,7 +36,7 @@ class AlchemyError(RuntimeError):
 
 
 def lib_path() -> str:
-    # ALCH_LIB_PATH selects an experimental build of the same library (tools/build_variants.sh)
+    # ALCH_LIB_PATH selects an experimental build of the same library (tools/build_variant.sh)
     return os.environ.get("ALCH_LIB_PATH") or os.path.join(_HERE, "lib", "libalchemy_hip.so")
 
 
@@ -86,6 +87,7 @@ def load_library():
         "alch_ring_n": [VP, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "alch_ring_set_stream": [VP, VP],
         "alch_sync": [VP],
+        "alch_ring_set_option": [VP, C.c_char_p, C.c_long],
         "alch_timer_start": [VP],
         "alch_timer_stop": [VP, C.POINTER(C.c_float)],
         "alch_crt": [VP, P64], "alch_crtinv": [VP, P64],
@@ -179,6 +181,10 @@ class Ring:
 
     def sync(self):
         _check(self._l.alch_sync(self._h))
+
+    def set_option(self, name: str, value: int):
+        """Launch-structure option of the fused kernels (chunk, one_stream, ks_grid, ti_grid, ti_split, rs_slots)."""
+        _check(self._l.alch_ring_set_option(self._h, name.encode(), int(value)))
 
     def timer_start(self):
         _check(self._l.alch_timer_start(self._h))

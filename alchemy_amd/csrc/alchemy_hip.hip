@@ -44,6 +44,11 @@ struct alch_ring {
     void* ws_full = nullptr;                   // ct_mul_full scratch: per pipeline digits + key-switched chunk + stash
     size_t ws_full_bytes = 0;
     hipEvent_t ev_x = nullptr;                 // cross-ring ordering (ct_mul_full)
+    int device = 0;                            // HIP device the ring's streams, tables and buffers live on
+    LaunchOpts opts;                           // launch-structure options (alch_ring_set_option)
+    bool one_stream = false;
+    unsigned rs_slots = 512;                   // resident workgroups of k_rescale_out (each owns a stash slot)
+    alch_buf* scratch = nullptr;               // staging elements of the host-buffer Tensor methods
 };
 
 struct alch_buf {
@@ -73,6 +78,14 @@ static int fail(int code, const std::string& msg) {
         hipError_t _e = (expr);                                                                         \
         if (_e != hipSuccess)                                                                           \
             return fail(ALCH_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+    } while (0)
+
+// HIP's current device is per host thread: every entry point first makes the ring's device current, so a host that
+// calls from another OS thread (Haskell `safe` FFI calls on a -threaded RTS) still launches on the right GPU.
+#define BIND(ringp)                                                                                     \
+    do {                                                                                                \
+        if (hipSetDevice((ringp)->device) != hipSuccess)                                                \
+            return fail(ALCH_E_HIP, "hipSetDevice(" + std::to_string((ringp)->device) + ") failed");    \
     } while (0)
 
 extern "C" const char* alch_last_error(void) { return g_err.c_str(); }
@@ -426,10 +439,7 @@ extern "C" int alch_ring_create(uint32_t m, int L, const uint64_t* q, alch_ring*
     u64 qmin = ~0ull, qmax = 0;
     for (int j = 0; j < L; ++j) { qmin = std::min(qmin, q[j]); qmax = std::max(qmax, q[j]); }
     r->balanced = (qmax - 1) / 2 < qmin;
-    if (const char* c = getenv("ALCH_CHUNK")) {
-        long v = atol(c);
-        if (v >= 8) r->chunk = (size_t)v;
-    }
+    r->device = dev;
     hipError_t e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete r; return fail(ALCH_E_HIP, "hipStreamCreate failed"); }
     r->own_stream = true;
@@ -446,6 +456,8 @@ extern "C" int alch_ring_create(uint32_t m, int L, const uint64_t* q, alch_ring*
 
 extern "C" int alch_ring_destroy(alch_ring* r) {
     if (!r) return ALCH_OK;
+    (void)hipSetDevice(r->device);
+    if (r->scratch) { alch_buf* b = r->scratch; r->scratch = nullptr; (void)hipFree(b->dptr); delete b; }
     if (r->stream) (void)hipStreamSynchronize(r->stream);
     if (r->tables) (void)hipFree(r->tables);
     if (r->tables_p) (void)hipFree(r->tables_p);
@@ -475,6 +487,7 @@ extern "C" int alch_ring_n(const alch_ring* r, uint32_t* n, int* L, int* word_by
 
 extern "C" int alch_ring_set_stream(alch_ring* r, void* s) {
     if (!r) return fail(ALCH_E_INVALID, "null ring");
+    BIND(r);
     HIP_TRY(hipStreamSynchronize(r->stream));
     if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
     r->stream = (hipStream_t)s;
@@ -482,20 +495,36 @@ extern "C" int alch_ring_set_stream(alch_ring* r, void* s) {
     return ALCH_OK;
 }
 
+extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) {
+    if (!r || !name) return fail(ALCH_E_INVALID, "null argument");
+    const std::string k(name);
+    if (k == "chunk") { if (value < 8) return fail(ALCH_E_INVALID, "chunk must be >= 8"); r->chunk = (size_t)value; }
+    else if (k == "one_stream") r->one_stream = value != 0;
+    else if (k == "ks_grid") { if (value < 1) return fail(ALCH_E_INVALID, "ks_grid must be >= 1"); r->opts.ks_grid = (unsigned)value; }
+    else if (k == "ti_grid") r->opts.ti_grid = (int)value;
+    else if (k == "ti_split") { if (value < 0) return fail(ALCH_E_INVALID, "ti_split must be >= 0"); r->opts.ti_split = (int)value; }
+    else if (k == "rs_slots") { if (value < 1) return fail(ALCH_E_INVALID, "rs_slots must be >= 1"); r->rs_slots = (unsigned)value; }
+    else return fail(ALCH_E_INVALID, "unknown option '" + k + "'");
+    return ALCH_OK;
+}
+
 extern "C" int alch_sync(alch_ring* r) {
     if (!r) return fail(ALCH_E_INVALID, "null ring");
+    BIND(r);
     HIP_TRY(hipStreamSynchronize(r->stream));
     return ALCH_OK;
 }
 
 extern "C" int alch_timer_start(alch_ring* r) {
     if (!r) return fail(ALCH_E_INVALID, "null ring");
+    BIND(r);
     HIP_TRY(hipEventRecord(r->ev0, r->stream));
     return ALCH_OK;
 }
 
 extern "C" int alch_timer_stop(alch_ring* r, float* ms) {
     if (!r || !ms) return fail(ALCH_E_INVALID, "null argument");
+    BIND(r);
     HIP_TRY(hipEventRecord(r->ev1, r->stream));
     HIP_TRY(hipEventSynchronize(r->ev1));
     HIP_TRY(hipEventElapsedTime(ms, r->ev0, r->ev1));
@@ -562,6 +591,7 @@ static int buf_crt(alch_buf* b, size_t first, size_t count, bool inverse) {
     if (!b) return fail(ALCH_E_INVALID, "null buffer");
     if (first + count > b->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
     alch_ring* r = b->ring;
+    BIND(r);
     return r->word == 4 ? do_crt<u32>(r, b->dptr, first, count, inverse) : do_crt<u64>(r, b->dptr, first, count, inverse);
 }
 
@@ -570,6 +600,8 @@ static int buf_crt(alch_buf* b, size_t first, size_t count, bool inverse) {
 // ------------------------------------------------------------------------------------------------------
 extern "C" int alch_buf_alloc(alch_ring* r, size_t n_elems, alch_buf** out) {
     if (!r || !out || n_elems == 0) return fail(ALCH_E_INVALID, "alch_buf_alloc: bad argument");
+    if (n_elems > (size_t)-1 / elem_bytes(r)) return fail(ALCH_E_INVALID, "alch_buf_alloc: n_elems * element size overflows size_t");
+    BIND(r);
     void* p = nullptr;
     if (hipMalloc(&p, n_elems * elem_bytes(r)) != hipSuccess)
         return fail(ALCH_E_NOMEM, "hipMalloc of " + std::to_string(n_elems * elem_bytes(r)) + " bytes failed");
@@ -579,6 +611,7 @@ extern "C" int alch_buf_alloc(alch_ring* r, size_t n_elems, alch_buf** out) {
 
 extern "C" int alch_buf_free(alch_buf* b) {
     if (!b) return ALCH_OK;
+    (void)hipSetDevice(b->ring->device);
     (void)hipStreamSynchronize(b->ring->stream);
     (void)hipFree(b->dptr);
     delete b;
@@ -622,6 +655,7 @@ static int do_transfer(alch_ring* r, void* dev, size_t count, int64_t* host, boo
 }
 
 static int transfer(alch_ring* r, void* dev_base, size_t first, size_t count, int64_t* host, bool to_device) {
+    BIND(r);
     // bounded staging: move at most 64 MiB of int64 at a time
     const size_t per = std::max<size_t>(1, ((size_t)64 << 20) / (elem_words(r) * sizeof(int64_t)));
     size_t done = 0;
@@ -651,6 +685,7 @@ extern "C" int alch_buf_download(const alch_buf* b, size_t first, size_t count, 
 extern "C" int alch_buf_fill_uniform(alch_buf* b, uint64_t seed) {
     if (!b) return fail(ALCH_E_INVALID, "null buffer");
     alch_ring* r = b->ring;
+    BIND(r);
     const size_t words = b->n_elems * elem_words(r);
     if (r->word == 4)
         hipLaunchKernelGGL((k_fill_uniform<u32>), dim3(ew_grid(words)), dim3(256), 0, r->stream, r->d32, (u32*)b->dptr, words, seed);
@@ -677,6 +712,7 @@ static int buf_pointwise(alch_buf* dst, const alch_buf* a, const alch_buf* b, si
     if (a->ring != dst->ring || b->ring != dst->ring) return fail(ALCH_E_INVALID, "buffers belong to different rings");
     if (count > dst->n_elems || count > a->n_elems || count > b->n_elems) return fail(ALCH_E_INVALID, "count out of bounds");
     alch_ring* r = dst->ring;
+    BIND(r);
     if (r->word == 4) {
         if (op == PW_MUL) return do_pointwise<u32, PW_MUL>(r, dst->dptr, a->dptr, b->dptr, count);
         if (op == PW_ADD) return do_pointwise<u32, PW_ADD>(r, dst->dptr, a->dptr, b->dptr, count);
@@ -695,6 +731,7 @@ extern "C" int alch_buf_checksum(const alch_buf* b, size_t first, size_t count, 
     if (!b || !sum) return fail(ALCH_E_INVALID, "null argument");
     if (first + count > b->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
     alch_ring* r = b->ring;
+    BIND(r);
     const size_t words = count * elem_words(r);
     const char* base = reinterpret_cast<const char*>(b->dptr) + first * elem_bytes(r);
     HIP_TRY(hipMemsetAsync(r->ws_sum, 0, sizeof(u64), r->stream));
@@ -709,15 +746,25 @@ extern "C" int alch_buf_checksum(const alch_buf* b, size_t first, size_t count, 
 // ------------------------------------------------------------------------------------------------------
 // host-buffer Tensor methods: stage one element through a scratch device buffer
 // ------------------------------------------------------------------------------------------------------
+// The host-buffer Tensor methods stage their operands through a per-ring scratch array that is kept between
+// calls (no hipMalloc / hipFree per ring element); it only ever grows.
 struct ScratchBuf {
     alch_buf* b = nullptr;
-    ~ScratchBuf() { if (b) alch_buf_free(b); }
 };
+static int scratch_get(alch_ring* r, size_t n_elems, alch_buf** out) {
+    BIND(r);
+    if (r->scratch && r->scratch->n_elems >= n_elems) { *out = r->scratch; return ALCH_OK; }
+    if (r->scratch) { alch_buf* old = r->scratch; r->scratch = nullptr; alch_buf_free(old); }
+    int rc = alch_buf_alloc(r, n_elems, &r->scratch);
+    if (rc != ALCH_OK) return rc;
+    *out = r->scratch;
+    return ALCH_OK;
+}
 
 static int host_unary(alch_ring* r, int64_t* data, int which) {
     if (!r || !data) return fail(ALCH_E_INVALID, "null argument");
     ScratchBuf s;
-    int rc = alch_buf_alloc(r, 1, &s.b);
+    int rc = scratch_get(r, 1, &s.b);
     if (rc != ALCH_OK) return rc;
     if ((rc = alch_buf_upload(s.b, 0, 1, data)) != ALCH_OK) return rc;
     if ((rc = buf_crt(s.b, 0, 1, which == 1)) != ALCH_OK) return rc;
@@ -730,7 +777,7 @@ extern "C" int alch_crtinv(alch_ring* r, int64_t* data) { return host_unary(r, d
 static int host_binary(alch_ring* r, int64_t* a, const int64_t* b, int op) {
     if (!r || !a || !b) return fail(ALCH_E_INVALID, "null argument");
     ScratchBuf s;
-    int rc = alch_buf_alloc(r, 2, &s.b);
+    int rc = scratch_get(r, 2, &s.b);
     if (rc != ALCH_OK) return rc;
     if ((rc = alch_buf_upload(s.b, 0, 1, a)) != ALCH_OK) return rc;
     if ((rc = alch_buf_upload(s.b, 1, 1, b)) != ALCH_OK) return rc;
@@ -771,7 +818,7 @@ static int do_scale(alch_ring* r, void* dst, const void* src, size_t count, cons
 extern "C" int alch_scale(alch_ring* r, int64_t* a, const uint64_t* s) {
     if (!r || !a || !s) return fail(ALCH_E_INVALID, "null argument");
     ScratchBuf t;
-    int rc = alch_buf_alloc(r, 1, &t.b);
+    int rc = scratch_get(r, 1, &t.b);
     if (rc != ALCH_OK) return rc;
     if ((rc = alch_buf_upload(t.b, 0, 1, a)) != ALCH_OK) return rc;
     rc = r->word == 4 ? do_scale<u32>(r, t.b->dptr, t.b->dptr, 1, s) : do_scale<u64>(r, t.b->dptr, t.b->dptr, 1, s);
@@ -794,7 +841,7 @@ extern "C" int alch_divg_crt(alch_ring* r, int64_t* a) { return identity_op(r, a
 extern "C" int alch_decompose_triv(alch_ring* r, const int64_t* c_pow, int64_t* digits) {
     if (!r || !c_pow || !digits) return fail(ALCH_E_INVALID, "null argument");
     ScratchBuf s;
-    int rc = alch_buf_alloc(r, 1 + (size_t)r->L, &s.b);
+    int rc = scratch_get(r, 1 + (size_t)r->L, &s.b);
     if (rc != ALCH_OK) return rc;
     if ((rc = alch_buf_upload(s.b, 0, 1, c_pow)) != ALCH_OK) return rc;
     char* dig = reinterpret_cast<char*>(s.b->dptr) + elem_bytes(r);
@@ -833,7 +880,7 @@ extern "C" int alch_decompose_base2(alch_ring* r, const int64_t* c_pow, int64_t*
     if (!digits) return ALCH_OK;
     if (!c_pow) return fail(ALCH_E_INVALID, "null argument");
     ScratchBuf s;
-    int rc = alch_buf_alloc(r, 1 + (size_t)D, &s.b);
+    int rc = scratch_get(r, 1 + (size_t)D, &s.b);
     if (rc != ALCH_OK) return rc;
     if ((rc = alch_buf_upload(s.b, 0, 1, c_pow)) != ALCH_OK) return rc;
     char* dig = reinterpret_cast<char*>(s.b->dptr) + elem_bytes(r);
@@ -848,6 +895,7 @@ extern "C" int alch_decompose_base2(alch_ring* r, const int64_t* c_pow, int64_t*
 // hint
 // ------------------------------------------------------------------------------------------------------
 static int hint_from_device(alch_ring* r, int gadget, const void* src_crt, alch_hint** out) {
+    BIND(r);
     if (gadget != ALCH_GAD_TRIV && gadget != ALCH_GAD_BASE2) return fail(ALCH_E_INVALID, "unknown gadget");
     const int digits = gadget_digits(r, gadget);
     const size_t elems = 2 * (size_t)digits;
@@ -876,6 +924,7 @@ extern "C" int alch_buf_scale(alch_buf* dst, const alch_buf* src, size_t count, 
     if (dst->ring != src->ring) return fail(ALCH_E_INVALID, "buffers belong to different rings");
     if (count > dst->n_elems || count > src->n_elems) return fail(ALCH_E_INVALID, "count out of bounds");
     alch_ring* r = dst->ring;
+    BIND(r);
     return r->word == 4 ? do_scale<u32>(r, dst->dptr, src->dptr, count, s) : do_scale<u64>(r, dst->dptr, src->dptr, count, s);
 }
 
@@ -883,6 +932,7 @@ extern "C" int alch_buf_decompose_triv(const alch_buf* src, size_t src_index, al
     if (!src || !dst) return fail(ALCH_E_INVALID, "null buffer");
     if (src->ring != dst->ring) return fail(ALCH_E_INVALID, "buffers belong to different rings");
     alch_ring* r = src->ring;
+    BIND(r);
     if (src_index >= src->n_elems || dst_first + (size_t)r->L > dst->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
     const char* c = reinterpret_cast<const char*>(src->dptr) + src_index * elem_bytes(r);
     char* dig = reinterpret_cast<char*>(dst->dptr) + dst_first * elem_bytes(r);
@@ -898,7 +948,7 @@ extern "C" int alch_hint_load(alch_ring* r, int gadget, const int64_t* host_crt,
     if (gadget != ALCH_GAD_TRIV && gadget != ALCH_GAD_BASE2) return fail(ALCH_E_INVALID, "unknown gadget");
     const size_t elems = 2 * (size_t)gadget_digits(r, gadget);
     ScratchBuf s;
-    int rc = alch_buf_alloc(r, elems, &s.b);
+    int rc = scratch_get(r, elems, &s.b);
     if (rc != ALCH_OK) return rc;
     if ((rc = alch_buf_upload(s.b, 0, elems, host_crt)) != ALCH_OK) return rc;
     rc = hint_from_device(r, gadget, s.b->dptr, out);
@@ -916,6 +966,7 @@ extern "C" int alch_hint_from_buf(alch_ring* r, int gadget, const alch_buf* src,
 
 extern "C" int alch_hint_free(alch_hint* h) {
     if (!h) return ALCH_OK;
+    (void)hipSetDevice(h->ring->device);
     (void)hipStreamSynchronize(h->ring->stream);
     (void)hipFree(h->dptr);
     delete h;
@@ -1035,10 +1086,10 @@ static int do_mul_relin(alch_ring* r, const alch_hint* hint, const void* a, cons
     c.ring = &dev_ring<W>(r);
     c.hint = reinterpret_cast<const W*>(hint->dptr);
     c.balanced = r->balanced;
+    c.opts = r->opts;
     scal_to_mont<W>(r, s_pre, 2, c.spre_r2);
     const size_t ct_words = 2 * elem_words(r);
-    static const bool one_stream = getenv("ALCH_ONE_STREAM") != nullptr;
-    const bool two = batch > chunk && !one_stream;
+    const bool two = batch > chunk && !r->one_stream;
     if (two) {
         HIP_TRY(hipEventRecord(r->ev_fork, r->stream));
         HIP_TRY(hipStreamWaitEvent(r->aux, r->ev_fork, 0));
@@ -1072,6 +1123,7 @@ extern "C" int alch_ct_mul_relin(alch_ring* r, const alch_hint* hint, const alch
     if (!r || !hint || !a || !b || !out) return fail(ALCH_E_INVALID, "null argument");
     if (hint->ring != r || a->ring != r || b->ring != r || out->ring != r) return fail(ALCH_E_INVALID, "handles belong to different rings");
     if (batch == 0) return ALCH_OK;
+    BIND(r);
     if (a->n_elems < 2 * batch || b->n_elems < 2 * batch || out->n_elems < 2 * batch)
         return fail(ALCH_E_INVALID, "buffers must hold 2*batch ring elements");
     if (out == a || out == b) return fail(ALCH_E_INVALID, "out must not alias an input");
@@ -1117,8 +1169,7 @@ static int do_mul_full(alch_ring* rh, alch_ring* rin, alch_ring* rout, const alc
     // per pipeline: digits [chunk][L_in][n] signed | key-switched chunk [chunk][2][Lh][n] | stash [slots][ddn][n] signed
     const size_t cap = std::max<size_t>(8, (((size_t)1 << 32) - 1) / (2 * elem_bytes(rh)) / 8 * 8);   // 32-bit byte offsets per array
     const size_t chunk = std::min(std::min(rh->chunk, cap), (batch + 7) / 8 * 8);
-    // resident workgroups of k_rescale_out (each owns a stash slot); ALCH_RS_SLOTS: test knob
-    static const unsigned slots = getenv("ALCH_RS_SLOTS") ? (unsigned)std::max(1, atoi(getenv("ALCH_RS_SLOTS"))) : 512u;
+    const unsigned slots = rh->rs_slots;       // resident workgroups of k_rescale_out (each owns a stash slot)
     const size_t dig_bytes = chunk * (size_t)rin->L * n * sizeof(SW);
     const size_t ks_bytes = chunk * 2 * (size_t)rh->L * n * sizeof(W);
     const size_t stash_bytes = (size_t)slots * (size_t)ddn * n * sizeof(SW);
@@ -1136,6 +1187,7 @@ static int do_mul_full(alch_ring* rh, alch_ring* rin, alch_ring* rout, const alc
     NttCall<W> c{};
     c.hint = reinterpret_cast<const W*>(hint->dptr);
     c.balanced = rh->balanced;
+    c.opts = rh->opts;
     scal_to_mont<W>(rin, s_eff, 2, c.spre_r2);
     c.drop.ddn = ddn;
     c.drop.balanced = 1;
@@ -1152,8 +1204,7 @@ static int do_mul_full(alch_ring* rh, alch_ring* rin, alch_ring* rout, const alc
     c.stash_slots = slots;
     c.pow_out = pow_out;
 
-    static const bool one_stream = getenv("ALCH_ONE_STREAM") != nullptr;
-    const bool two = batch > chunk && !one_stream;
+    const bool two = batch > chunk && !rh->one_stream;
     if (two) {
         HIP_TRY(hipEventRecord(rh->ev_fork, rh->stream));
         HIP_TRY(hipStreamWaitEvent(rh->aux, rh->ev_fork, 0));
@@ -1309,6 +1360,7 @@ extern "C" int alch_ct_mul_full(const alch_hint* hint, const alch_buf* a, const 
     if (rh->L - rout->L > MAXDROP) return fail(ALCH_E_UNSUPPORTED, "at most 3 limbs dropped per call");
     if (flags & ~(unsigned)ALCH_POW_OUT) return fail(ALCH_E_UNSUPPORTED, "only ALCH_POW_OUT is accepted");
     if (batch == 0) return ALCH_OK;
+    BIND(rh);
     if (a->n_elems < 2 * batch || b->n_elems < 2 * batch || out->n_elems < 2 * batch)
         return fail(ALCH_E_INVALID, "buffers must hold 2*batch ring elements");
     if (!rh->ev_x) HIP_TRY(hipEventCreateWithFlags(&rh->ev_x, hipEventDisableTiming));
@@ -1342,6 +1394,7 @@ extern "C" int alch_buf_rescale_drop0(const alch_buf* src, alch_buf* dst, size_t
     if (!src || !dst) return fail(ALCH_E_INVALID, "null buffer");
     alch_ring* rs = src->ring;
     alch_ring* rd = dst->ring;
+    BIND(rs);
     if (rs->L < 2 || rd->L != rs->L - 1 || rd->n != rs->n || rd->word != rs->word)
         return fail(ALCH_E_INVALID, "destination ring must be the source ring minus limb 0");
     for (int j = 1; j < rs->L; ++j)
@@ -1367,6 +1420,7 @@ extern "C" int alch_buf_rescale_add0(const alch_buf* src, alch_buf* dst, size_t 
     if (!src || !dst) return fail(ALCH_E_INVALID, "null buffer");
     alch_ring* rs = src->ring;
     alch_ring* rd = dst->ring;
+    BIND(rd);
     if (rd->L != rs->L + 1 || rd->n != rs->n || rd->word != rs->word)
         return fail(ALCH_E_INVALID, "destination ring must be the source ring plus one limb in front");
     for (int j = 0; j < rs->L; ++j)

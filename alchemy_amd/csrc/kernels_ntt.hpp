@@ -67,9 +67,17 @@ struct DropTab {
     W qinv_m[MAXDROP][MAXL];       // q_u^-1 mod q_t in Montgomery form (t > u)
 };
 
+// Launch-structure options of the fused kernels (alch_ring_set_option; defaults are the measured optima).
+struct LaunchOpts {
+    int ti_split = 1;        // n = 2^15 tensor kernel: 1 = split form, one workgroup per item; 0 = whole-polynomial kernel; > 1 = that many persistent workgroups
+    int ti_grid = -1;        // whole-polynomial tensor kernel: -1 = one resident set of persistent workgroups, 0 = one workgroup per item, n > 0 = n workgroups
+    unsigned ks_grid = 4096; // persistent workgroups of k_ks_accum_half (measured, 1024-ciphertext chunks: 2048 -> 511k, 4096 -> 517k, 8192 -> 513k op/s)
+};
+
 template <typename W>
 struct NttCall {
     OpKind op;
+    LaunchOpts opts;
     const DevRing<W>* ring;
     hipStream_t stream;
     // OP_CRT / OP_CRTINV
@@ -496,7 +504,7 @@ inline hipError_t run_call(const NttCall<W>& c) {
             // default: two sequential half-size sub-transforms, two workgroups per CU (kernel_tensor_split.hpp): +0.5..1 %
             // on the op, +2 % on the full mul_ against the whole-polynomial kernel below (ALCH_TI_SPLIT=0 selects that;
             // a value > 1 = that many persistent workgroups)
-            static const int split = getenv("ALCH_TI_SPLIT") ? atoi(getenv("ALCH_TI_SPLIT")) : 1;
+            const int split = c.opts.ti_split;
             if (split) {
                 auto k = k_tensor_intt_split<LOGN>;
                 const size_t half_lds = (size_t)lds_words<LOGN - 1>() * sizeof(W);
@@ -520,11 +528,15 @@ inline hipError_t run_call(const NttCall<W>& c) {
         // ALCH_TI_GRID: -1 = one resident set of persistent workgroups (default: kernel time -4 % once the next
         // item's loads are issued behind the last vector-twiddle pass), 0 = one workgroup per item, n > 0 = n
         // persistent workgroups
-        static const int ti_grid = getenv("ALCH_TI_GRID") ? atoi(getenv("ALCH_TI_GRID")) : -1;
+        const int ti_grid = c.opts.ti_grid;
         unsigned grid = nitems < 256u * per_cu ? nitems : 256u * per_cu;
         if (ti_grid == 0) grid = nitems;
         else if (ti_grid > 0 && (unsigned)ti_grid < nitems) grid = (unsigned)ti_grid;
-        static const unsigned dbg_a = getenv("ALCH_EXP_A") ? (unsigned)atoi(getenv("ALCH_EXP_A")) : 0u;
+#ifdef ALCH_ABLATE
+        static const unsigned dbg_a = getenv("ALCH_EXP_A") ? (unsigned)atoi(getenv("ALCH_EXP_A")) : 0u;   // diagnostic builds only
+#else
+        constexpr unsigned dbg_a = 0u;
+#endif
         hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), lds_bytes, c.stream, R, c.a, c.b, (SW*)c.digits, nitems,
                            c.spre_r2, dbg_a);
         break;
@@ -532,11 +544,15 @@ inline hipError_t run_call(const NttCall<W>& c) {
     case OP_KS_ACCUM: {
         if constexpr (std::is_same<W, u32>::value && (LOGN == 15 || LOGN == 11)) {
             // two workgroups per (ciphertext, limb): see kernel_ks_half.hpp
-            static const unsigned dbg_mask = getenv("ALCH_EXP_FLAGS") ? (unsigned)strtoul(getenv("ALCH_EXP_FLAGS"), nullptr, 0) : 0u;   // 1 inputs, 2 digits, 4 outputs, 8 hints aliased (wrong results, timing only)
+#ifdef ALCH_ABLATE
+            static const unsigned dbg_mask = getenv("ALCH_EXP_FLAGS") ? (unsigned)strtoul(getenv("ALCH_EXP_FLAGS"), nullptr, 0) : 0u;   // diagnostic builds only: 1 inputs, 2 digits, 4 outputs, 8 hints aliased (wrong results, timing only)
+#else
+            constexpr unsigned dbg_mask = 0u;
+#endif
             if ((size_t)c.nct * 2 * (size_t)R.L * G::N * sizeof(W) >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // 32-bit byte offsets
             const size_t groups = (c.nct + 7) / 8;
             const unsigned nitems = (unsigned)(groups * 16 * (size_t)R.L);
-            static const unsigned persist = getenv("ALCH_KS_GRID") ? (unsigned)atoi(getenv("ALCH_KS_GRID")) : 4096u;  // measured (1024-ciphertext chunks = 8192 items): 2048 -> 511k, 3072 -> 510k, 4096 (two items per workgroup) -> 517k, 8192 (one each) -> 513k op/s
+            const unsigned persist = c.opts.ks_grid ? c.opts.ks_grid : 4096u;
             const unsigned grid = nitems < persist ? nitems : persist;
             constexpr int TH = 1 << (LOGN - 6);
             const size_t half_lds = (size_t)lds_words<LOGN - 1>() * sizeof(W);

@@ -82,6 +82,18 @@ def max_over_ranks(value: float, dist, device=None) -> float:
     return float(t.item())
 
 
+def gather_scalars(value: float, dist, device=None):
+    """All ranks' values of one scalar, in rank order (per-rank step times in the bench line)."""
+    if dist is None:
+        return [float(value)]
+    import torch
+    world = dist.get_world_size()
+    t = torch.zeros(world, dtype=torch.float64, device=device if device is not None else "cpu")
+    t[dist.get_rank()] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.cpu().tolist()]
+
+
 def sum_over_ranks(value: float, dist, device=None) -> float:
     if dist is None:
         return float(value)

@@ -27,8 +27,9 @@ sys.path.insert(0, ROOT)
 CFG3_QS = [2147352577, 2146959361, 2146041857, 2145976321]
 FULL_EXTRA_Q = 2144796673                              # next prime = 1 mod 2^16 below CFG3_QS: the hint's extra limb (--full)
 LOGN = 15
-ALGO_BYTES_PER_OP = 6 * 4 * (1 << LOGN) * 8          # 6,291,456 B  
+ALGO_BYTES_PER_OP = 6 * 4 * (1 << LOGN) * 8          # 6,291,456 B  (the reference's 8-byte ZqBasic q Int64 word)
 HINT_BYTES = 2 * 4 * 4 * (1 << LOGN) * 8              # 8 MiB, counted once per batch
+DEVICE_WORD_BYTES_PER_OP = 6 * 4 * (1 << LOGN) * 4   # 3,145,728 B: the same six ciphertext components at the 4-byte word the device stores
 HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -40,6 +41,17 @@ def _cpu_model() -> str:
     except OSError:
         pass
     return "unknown CPU"
+
+
+def kernel_src_sha16() -> str:
+    """Fingerprint of the HIP sources the library is built from (what a committed PMC summary is valid for)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "alchemy_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(sample_ops: int):
@@ -74,6 +86,38 @@ def cpu_baseline_all_cores(ops_per_thread: int):
             "sample": f"{ops_per_thread} ops on each of {threads} threads, slowest thread {max(secs):.1f} s"}
 
 
+def general_index_line():
+    """Extra line: the same op on the ring the reference's HomomRLWR example multiplies in -- H5' = F20475 =
+    3^2 5^2 7 13 (examples/Common.hs:54), phi = 8640, the first four HomomRLWR moduli (examples/HomomRLWR.hs:37-43),
+    TrivGad, CRT basis in/out -- through the general-index kernels (kernel_gen.hpp)."""
+    from alchemy_amd import Ring
+    m, qs = 20475, [1543651201, 689270401, 718099201, 720720001]
+    ring = Ring(m, qs)
+    n, Bg = ring.n, 4096
+    a, b, out, hs = ring.alloc(2 * Bg), ring.alloc(2 * Bg), ring.alloc(2 * Bg), ring.alloc(2 * ring.L)
+    a.fill_uniform(11); b.fill_uniform(12); hs.fill_uniform(13)
+    hint = ring.hint_from_buf(hs)
+    ring.ct_mul_relin(hint, a, b, out, Bg)
+    ring.sync()
+    ring.timer_start()
+    for _ in range(3):
+        ring.ct_mul_relin(hint, a, b, out, Bg)
+    ops = 3 * Bg / (ring.timer_stop() * 1e-3)
+    algo = 6 * len(qs) * n * 8
+    tr = ring.alloc(4096 * 2)
+    tr.fill_uniform(5)
+    tr.crt(); ring.sync()
+    ring.timer_start()
+    for _ in range(3):
+        tr.crt()
+    crt_s = 3 * tr.n_elems * ring.L / (ring.timer_stop() * 1e-3)
+    return {"workload": "keySwitchQuadCirc(hint, a*b), index m'=20475 (phi=8640), L=4 HomomRLWR moduli, TrivGad, CRT in/out",
+            "ops_per_s": ops, "batch": Bg, "algorithmic_bytes_per_op": algo, "achieved_GBs": ops * algo / 1e9,
+            "frac_of_hbm_peak": ops * algo / 1e9 / HBM_PEAK_GBS, "frac_at_device_word": ops * algo / 2 / 1e9 / HBM_PEAK_GBS,
+            "limb_crt_per_s": crt_s, "limb_crt_algorithmic_GBs": crt_s * 2 * n * 8 / 1e9,
+            "out_checksum": f"{out.checksum(0, 2):016x}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,9 +125,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8192, help="ciphertext pairs per GPU per step (weak scaling)")
     ap.add_argument("--cpu-ops", type=int, default=384, help="ops in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--pow", action="store_true", help="also time the Pow-basis in/out variant (extra field)")
-    ap.add_argument("--full", action="store_true",
-                    help="also time PT2CT's whole mul_ (modSwitch . keySwitchQuad . modSwitch . (*)), 4 -> 5 -> 3 limbs")
+    ap.add_argument("--no-pow", dest="pow", action="store_false",
+                    help="skip the Pow-basis in/out variant (SURVEY 8d's COEFF line; extra field, after the timed region)")
+    ap.add_argument("--no-full", dest="full", action="store_false",
+                    help="skip PT2CT's whole mul_ (modSwitch . keySwitchQuad . modSwitch . (*)), 4 -> 5 -> 3 limbs (extra field)")
+    ap.add_argument("--no-general", dest="general", action="store_false",
+                    help="skip the general-index line (keySwitchQuadCirc(a*b) on the reference's H5' = F20475 ring)")
     args = ap.parse_args()
 
     import torch
@@ -96,6 +143,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    rehearsal = os.environ.get("ALCH_DIST_BACKEND") == "gloo"
+    if world > 1 and not rehearsal and world > torch.cuda.device_count():
+        raise SystemExit(f"{world} ranks but only {torch.cuda.device_count()} GPUs visible: one rank per GPU")
     dev_index = int(os.environ.get("ALCH_FORCE_DEVICE", local_rank))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -111,22 +161,21 @@ def main():
     a.fill_uniform(2026 + 2 * sh.first * 7919)
     b.fill_uniform(900_000_007 + 2 * sh.first * 7919)
     # The hint is generated once (rank 0, seed 0xA1C4E5) and broadcast over RCCL before anything is timed -- the
-    # one collective of the path.  Should the broadcast fail, every rank generates the same hint from
-    # the seed instead and the JSON line says so.
+    # one collective of the path.  A failing broadcast is fatal: a bench line from ranks that do not
+    # share one hint would not be a measurement of the path.
     hint_dist = "single rank"
     hint_src.fill_uniform(0xA1C4E5)
     if dist is not None:
-        try:
-            h = hint_src.download()
-            if rank != 0:
-                h[...] = 0
-            shard.broadcast_array(h, dist, src=0, device=red_dev)
-            hint_src.upload(h)
-            hint_dist = "rccl broadcast from rank 0" if red_dev is not None else "gloo broadcast from rank 0"
-        except Exception as e:                      # noqa: BLE001 -- keep the bench alive, report the fallback
-            print(f"[bench] hint broadcast failed ({e!r}); using the seeded replica", file=sys.stderr, flush=True)
-            hint_src.fill_uniform(0xA1C4E5)
-            hint_dist = "seeded replica on every rank (broadcast failed)"
+        h = hint_src.download()
+        if rank != 0:
+            h[...] = 0
+        if os.environ.get("ALCH_TEST_FAIL_BROADCAST"):      # tests: prove that a broken collective ends the run
+            raise SystemExit("[bench] hint broadcast failed (forced by ALCH_TEST_FAIL_BROADCAST)")
+        shard.broadcast_array(h, dist, src=0, device=red_dev)
+        if rank != 0 and not h.any():
+            raise SystemExit("[bench] hint broadcast delivered zeros")
+        hint_src.upload(h)
+        hint_dist = "rccl broadcast from rank 0" if red_dev is not None else "gloo broadcast from rank 0"
     hint = ring.hint_from_buf(hint_src)
     ring.sync()
 
@@ -150,49 +199,62 @@ def main():
     wall = time.perf_counter() - t0
     wall_max = shard.max_over_ranks(wall, dist, red_dev)
     ev_ms_max = shard.max_over_ranks(ev_ms, dist, red_dev)
+    ev_ms_ranks = shard.gather_scalars(ev_ms, dist, red_dev)     # one entry per rank: a straggler is visible
     checksum = out.checksum(0, 2)
+    # whole-batch result check on rank 0 (its shard always starts at ciphertext 0, so the seeds are those of the
+    # committed fixture): alch_buf_checksum of every result word against the value the C oracle produced offline
+    # (tests/golden/batch_checksums.json, generated by tests/golden/make_batch_checksums.py)
+    batch_check = None
+    if rank == 0:
+        try:
+            ref = json.load(open(os.path.join(ROOT, "tests", "golden", "batch_checksums.json")))["bench_mul_relin"]
+        except (OSError, KeyError, ValueError):
+            ref = None
+        if ref is not None and ref.get("batch") == B:
+            got = out.checksum()
+            batch_check = {"batch": B, "expected": ref["checksum"], "got": f"{got:016x}", "ok": f"{got:016x}" == ref["checksum"]}
+            if not batch_check["ok"]:
+                raise SystemExit(f"[bench] result batch differs from the oracle's: {batch_check}")
 
     # The batch gather (north star: "RCCL over xGMI for the batch gather only"): after timing, every rank
     # contributes a slice of its result batch to an all-gather, zero-copy from the library's buffer.  Reported next
     # to the throughput, never inside it: gathering every result would be bound by xGMI ingress (7 x ~153 GB/s per
     # GPU), far below what the ranks produce.
     gather = None
-    if dist is not None:
-        try:
-            G_CTS = min(B, 256)                               # 256 ciphertexts = 256 MiB of device words per rank
-            mine = out.as_torch(0, 2 * G_CTS)
-            everyone = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
-            ring.sync()
+    if dist is not None:            # any exception here ends the run with a non-zero exit code: no healthy-looking line from a broken RCCL path
+        G_CTS = min(B, 256)                               # 256 ciphertexts = 256 MiB of device words per rank
+        mine = out.as_torch(0, 2 * G_CTS)
+        everyone = torch.empty(world * mine.numel(), dtype=mine.dtype, device=mine.device)
+        ring.sync()
 
-            def all_gather():
-                if red_dev is not None:
-                    dist.all_gather_into_tensor(everyone, mine)                  # RCCL
-                else:
-                    dist.all_gather(list(everyone.chunk(world)), mine)           # gloo rehearsal
+        def all_gather():
+            if red_dev is not None:
+                dist.all_gather_into_tensor(everyone, mine)                  # RCCL
+            else:
+                dist.all_gather(list(everyone.chunk(world)), mine)           # gloo rehearsal
 
+        all_gather()
+        torch.cuda.synchronize()
+        ok = bool(torch.equal(everyone[rank * mine.numel():(rank + 1) * mine.numel()], mine))
+        if not ok:
+            raise SystemExit("[bench] all-gather returned a different slice than this rank contributed")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        shard.barrier(dist)
+        e0.record()
+        for _ in range(5):
             all_gather()
-            torch.cuda.synchronize()
-            ok = bool(torch.equal(everyone[rank * mine.numel():(rank + 1) * mine.numel()], mine))
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            shard.barrier(dist)
-            e0.record()
-            for _ in range(5):
-                all_gather()
-            e1.record()
-            torch.cuda.synchronize()
-            ms = shard.max_over_ranks(e0.elapsed_time(e1) / 5, dist, red_dev)
-            nbytes = mine.numel() * mine.element_size()
-            gather = {"ciphertexts_per_rank": G_CTS, "bytes_per_rank": nbytes, "ms": ms,
-                      "ingress_GBs_per_gpu": (world - 1) * nbytes / (ms * 1e-3) / 1e9,
-                      "xgmi_ingress_bound_GBs": 7 * 153.0, "own_slice_intact": ok,
-                      "backend": "rccl" if red_dev is not None else "gloo"}
-            del everyone
-        except Exception as e:                      # noqa: BLE001 -- report, do not lose the throughput line
-            print(f"[bench] result all-gather failed: {e!r}", file=sys.stderr, flush=True)
-            gather = {"error": repr(e)}
+        e1.record()
+        torch.cuda.synchronize()
+        ms = shard.max_over_ranks(e0.elapsed_time(e1) / 5, dist, red_dev)
+        nbytes = mine.numel() * mine.element_size()
+        gather = {"ciphertexts_per_rank": G_CTS, "bytes_per_rank": nbytes, "ms": ms,
+                  "ingress_GBs_per_gpu": (world - 1) * nbytes / (ms * 1e-3) / 1e9,
+                  "xgmi_ingress_bound_GBs": 7 * 153.0, "own_slice_intact": ok,
+                  "backend": "rccl" if red_dev is not None else "gloo"}
+        del everyone
 
     pow_ops = None
-    if args.pow:
+    if args.pow and rank == 0:
         from alchemy_amd.capi import ALCH_POW_IN, ALCH_POW_OUT
         Bp = min(B, 2048)
         ring.ct_mul_relin(hint, a, b, out, Bp, flags=ALCH_POW_IN | ALCH_POW_OUT)
@@ -203,7 +265,7 @@ def main():
         pow_ops = 3 * Bp / (ring.timer_stop() * 1e-3)
 
     full = None
-    if args.full:
+    if args.full and rank == 0:
         # operands on 4 limbs, TrivGad hint one limb longer (KSPNoise, PT2CT.hs:139), result on 3
         from alchemy_amd import capi
         qs_h = [FULL_EXTRA_Q] + CFG3_QS
@@ -225,7 +287,13 @@ def main():
         full = {"ops_per_s": ops, "workload": "PT2CT mul_: (*) on 4 limbs, modSwitch to the 5-limb hint modulus, "
                 "keySwitchQuadCirc, modSwitch to 3 limbs; CRT-basis in/out", "moduli_hint": qs_h, "batch": Bf,
                 "algorithmic_bytes_per_op": algo, "achieved_GBs": ops * algo / 1e9,
-                "frac_of_hbm_peak": ops * algo / 1e9 / HBM_PEAK_GBS, "out_checksum": f"{fout.checksum(0, 2):016x}"}
+                "frac_of_hbm_peak": ops * algo / 1e9 / HBM_PEAK_GBS,
+                "frac_at_device_word": ops * (algo // 2) / 1e9 / HBM_PEAK_GBS, "out_checksum": f"{fout.checksum(0, 2):016x}"}
+        del fout, hint_h, hsrc
+
+    general = None
+    if args.general and rank == 0:
+        general = general_index_line()
 
     if rank == 0:
         total_ops = B * world * args.steps
@@ -236,12 +304,20 @@ def main():
         # physical HBM-side bytes per op from the committed PMC passes (profiles/traffic_latest.json: separate
         # FETCH_SIZE and WRITE_SIZE runs of this script, gfx950 FETCH_SIZE correction applied), turned into
         # a rate with this run's op rate so that it compares with `achieved`
-        traffic = traffic_per_op = None
+        traffic = traffic_per_op = traffic_src = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic_per_op = float(json.load(open(tpath))["hbm_bytes_per_op"])
-                traffic = per_gpu_ops_s * traffic_per_op / 1e9
+                tj = json.load(open(tpath))
+                # only a PMC summary taken on these very kernel sources counts; a stale one is reported as null
+                if tj.get("kernel_src_sha16") == kernel_src_sha16():
+                    traffic_per_op = float(tj["hbm_bytes_per_op"])
+                    traffic = per_gpu_ops_s * traffic_per_op / 1e9
+                    traffic_src = {"file": "profiles/traffic_latest.json", "kernel_src_sha16": tj["kernel_src_sha16"],
+                                   "collected": tj.get("collected")}
+                else:
+                    traffic_src = {"file": "profiles/traffic_latest.json", "stale": True,
+                                   "kernel_src_sha16_of_file": tj.get("kernel_src_sha16"), "kernel_src_sha16_now": kernel_src_sha16()}
             except Exception:
                 traffic = traffic_per_op = None
         line = {
@@ -254,20 +330,28 @@ def main():
                                    "CRT-basis in/out, inputs resident in HBM",
                        "batch_per_gpu": B, "global_batch": B * world, "sharding": f"dp{world} by ciphertext, no collective in the timed region", "hint": hint_dist,
                        "moduli": CFG3_QS, "device_word_bytes": ring.word_bytes},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_bytes_per_op": traffic_per_op,
-                         "note": "achieved = ops/s per GPU (HIP events over the timed launches) x 6,291,456 B "
-                                 "algorithmic bytes per op at the reference's 8-byte word (SURVEY 8d); "
-                                 "traffic = physical GB/s = PMC (FETCH_SIZE x2 + WRITE_SIZE) bytes per op from profiles/traffic_latest.json x "
-                                 "this run's ops/s; the device stores 4-byte words and moves intermediates (digits, hint, "
-                                 "re-read operands) on top of the 3.1 MB it must move per op"},
+            "roofline": {"bound": "hbm", "limiter": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "frac_at_device_word": per_gpu_ops_s * (DEVICE_WORD_BYTES_PER_OP + HINT_BYTES / 2 / B) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_bytes_per_op": traffic_per_op, "traffic_source": traffic_src,
+                         "note": "frac prices an op at SURVEY 8d's 6,291,456 B (six ciphertext components at the reference's "
+                                 "8-byte Int64 word); frac_at_device_word prices the same components at the 4-byte word the "
+                                 "device actually moves (3,145,728 B) -- the honest fraction of the 8 TB/s peak for this "
+                                 "build.  bound names the roofline SURVEY 8d prescribes; limiter says what the kernels are "
+                                 "actually bound by (integer VALU issue, DESIGN.md 4).  traffic = physical GB/s = PMC "
+                                 "(FETCH_SIZE x2 + WRITE_SIZE) bytes per op x this run's ops/s, null when the committed PMC "
+                                 "summary was taken on other kernel sources"},
             "hip_event_ms_per_step": ev_ms_max / args.steps,
+            "hip_event_ms_per_step_by_rank": [x / args.steps for x in ev_ms_ranks],
+            "batch_checksum": batch_check,
             "out_checksum": f"{checksum:016x}",
         }
         if pow_ops is not None:
             line["pow_basis_in_out_ops_per_s"] = pow_ops
         if full is not None:
             line["full_mul"] = full
+        if general is not None:
+            line["general_index"] = general
         line["result_gather"] = gather
         if world == 1 and args.cpu_ops > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_ops)

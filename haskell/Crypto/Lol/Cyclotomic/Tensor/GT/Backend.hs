@@ -32,6 +32,7 @@ foreign import ccall safe   "alch_ring_destroy"        c_ringDestroy     :: Ptr 
 foreign import ccall unsafe "alch_host_root"           c_hostRoot        :: Word32 -> Word64 -> Ptr Word64 -> Ptr Word64 -> IO CInt
 foreign import ccall unsafe "alch_ring_n"              c_ringN           :: Ptr AlchRing -> Ptr Word32 -> Ptr CInt -> Ptr CInt -> IO CInt
 foreign import ccall unsafe "alch_ring_set_stream"     c_ringSetStream   :: Ptr AlchRing -> Ptr () -> IO CInt
+foreign import ccall unsafe "alch_ring_set_option"     c_ringSetOption   :: Ptr AlchRing -> CString -> CLong -> IO CInt
 foreign import ccall safe   "alch_sync"                c_sync            :: Ptr AlchRing -> IO CInt
 foreign import ccall unsafe "alch_timer_start"         c_timerStart      :: Ptr AlchRing -> IO CInt
 foreign import ccall safe   "alch_timer_stop"          c_timerStop       :: Ptr AlchRing -> Ptr CFloat -> IO CInt

@@ -24,7 +24,9 @@
  *   - Pow basis = coefficient vector; Dec basis == Pow basis for a two-power index; CRT basis slot k
  *     holds a(psi^(2*brev(k)+1)), psi = g^((q-1)/m), g = smallest generator of Z_q^*.
  *   - all work is queued on the ring's HIP stream; alch_sync() waits for it.  Entry points are
- *     re-entrant across rings; one ring must not be driven from two threads at once.
+ *     re-entrant across rings; one ring must not be driven from two threads at once.  A ring is bound to the
+ *     HIP device that was current when it was created; every entry point makes that device current for the
+ *     calling thread first, so rings may be used from any OS thread (Haskell `safe` calls on a -threaded RTS).
  *   - there is NO CPU fallback: without a gfx950 device every compute entry point fails with
  *     ALCH_E_NO_DEVICE.
  */
@@ -81,6 +83,12 @@ int alch_host_root(uint32_t m, uint64_t q, uint64_t *psi, uint64_t *generator);
 int alch_ring_n(const alch_ring *ring, uint32_t *n, int *L, int *word_bytes);
 /* Use an externally created hipStream_t (e.g. torch's current stream) for all work of this ring. */
 int alch_ring_set_stream(alch_ring *ring, void *hip_stream);
+/* Launch-structure options of the fused hot-path kernels (results never depend on them; tests sweep them).  The
+ * library reads no environment variable.  Names: "chunk" (ciphertexts per launch group, >= 8, default 1024),
+ * "one_stream" (0/1: do not alternate chunks over two streams), "ks_grid" (persistent workgroups of the key-switch
+ * kernel, default 4096), "ti_split" / "ti_grid" (form and grid of the tensor + crtInv kernel), "rs_slots" (resident
+ * workgroups of the closing rescale kernel; for alch_ct_mul_full the options of the hint's ring apply). */
+int alch_ring_set_option(alch_ring *ring, const char *name, long value);
 int alch_sync(alch_ring *ring);
 /* HIP-event timer on the ring's stream (what bench.py brackets the timed region with). */
 int alch_timer_start(alch_ring *ring);

@@ -1,7 +1,8 @@
 """GPU: the launch-structure knobs of ct_mul_relin must not change results -- multi-chunk batches on two
 streams, tiny chunks, persistent workgroup grids smaller than the item count, persistent tensor kernel.
-Each configuration runs in its own process (the knobs are read once per process) and is compared with the
-oracle."""
+Each configuration sets the library's launch options through alch_ring_set_option (the library reads no
+environment variable), runs in its own process and is compared with the oracle."""
+import json
 import os
 import subprocess
 import sys
@@ -19,9 +20,11 @@ WORKER = textwrap.dedent("""
     import alchemy_amd as A
     from oracle import cref
     qs = [2147352577, 2146959361, 2146041857, 2145976321]
-    logn, batch = int(sys.argv[1]), int(sys.argv[2])
+    logn, batch, opts = int(sys.argv[1]), int(sys.argv[2]), __import__("json").loads(sys.argv[3])
     n = 1 << logn
     g, o = A.Ring(2 * n, qs), cref.Ring(n, qs)
+    for k, v in opts.items():
+        g.set_option(k, v)
     rng = np.random.default_rng(5)
     rnd = lambda c: np.stack([np.stack([rng.integers(0, q, size=n, dtype=np.int64) for q in qs], axis=1) for _ in range(c)])
     hint, a, b = rnd(8), rnd(2 * batch), rnd(2 * batch)
@@ -35,20 +38,19 @@ WORKER = textwrap.dedent("""
 """ % ROOT)
 
 
-@pytest.mark.parametrize("env,logn,batch", [
-    ({"ALCH_CHUNK": "8"}, 11, 37),                              # 5 chunks, two streams, ragged last chunk
-    ({"ALCH_CHUNK": "8", "ALCH_ONE_STREAM": "1"}, 11, 21),
-    ({"ALCH_CHUNK": "16", "ALCH_KS_GRID": "24"}, 11, 40),       # persistent grid smaller than the item count
-    ({"ALCH_CHUNK": "8", "ALCH_KS_GRID": "8", "ALCH_TI_GRID": "8"}, 15, 9),
-    ({"ALCH_TI_GRID": "-1"}, 11, 5),
+@pytest.mark.parametrize("opts,logn,batch", [
+    ({"chunk": 8}, 11, 37),                              # 5 chunks, two streams, ragged last chunk
+    ({"chunk": 8, "one_stream": 1}, 11, 21),
+    ({"chunk": 16, "ks_grid": 24}, 11, 40),       # persistent grid smaller than the item count
+    ({"chunk": 8, "ks_grid": 8, "ti_grid": 8}, 15, 9),
+    ({"ti_grid": -1}, 11, 5),
     ({}, 15, 3),
-    ({"ALCH_TI_SPLIT": "0"}, 15, 5),                            # whole-polynomial tensor kernel instead of the split one
-    ({"ALCH_TI_SPLIT": "0", "ALCH_TI_GRID": "8", "ALCH_CHUNK": "8"}, 15, 9),
-    ({"ALCH_TI_SPLIT": "7", "ALCH_CHUNK": "8"}, 15, 9),         # split kernel on 7 persistent workgroups
+    ({"ti_split": 0}, 15, 5),                            # whole-polynomial tensor kernel instead of the split one
+    ({"ti_split": 0, "ti_grid": 8, "chunk": 8}, 15, 9),
+    ({"ti_split": 7, "chunk": 8}, 15, 9),         # split kernel on 7 persistent workgroups
 ])
-def test_launch_structure_does_not_change_results(env, logn, batch):
-    e = dict(os.environ, **env)
-    out = subprocess.run([sys.executable, "-c", WORKER, str(logn), str(batch)], env=e, capture_output=True,
+def test_launch_structure_does_not_change_results(opts, logn, batch):
+    out = subprocess.run([sys.executable, "-c", WORKER, str(logn), str(batch), json.dumps(opts)], capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.strip().endswith("OK")
@@ -61,9 +63,11 @@ WORKER_FULL = textwrap.dedent("""
     from oracle import cref
     from helpers import oracle_full_mul
     qs_h = [2144468993, 2147352577, 2146959361, 2146041857, 2145976321]      # all = 1 mod 2^16
-    logn, batch = int(sys.argv[1]), int(sys.argv[2])
+    logn, batch, opts = int(sys.argv[1]), int(sys.argv[2]), __import__("json").loads(sys.argv[3])
     n = 1 << logn
     rin, rh, rout = A.Ring(2 * n, qs_h[1:]), A.Ring(2 * n, qs_h), A.Ring(2 * n, qs_h[2:])
+    for k, v in opts.items():
+        rh.set_option(k, v); rin.set_option(k, v)
     rng = np.random.default_rng(6)
     rnd = lambda c, qs: np.stack([np.stack([rng.integers(0, q, size=n, dtype=np.int64) for q in qs], axis=1) for _ in range(c)])
     hint, a, b = rnd(10, qs_h), rnd(2 * batch, qs_h[1:]), rnd(2 * batch, qs_h[1:])
@@ -77,15 +81,14 @@ WORKER_FULL = textwrap.dedent("""
 """ % (ROOT, ROOT))
 
 
-@pytest.mark.parametrize("env,logn,batch", [
-    ({"ALCH_CHUNK": "8"}, 11, 37),                              # 5 chunks on two streams, ragged last chunk
-    ({"ALCH_CHUNK": "8", "ALCH_ONE_STREAM": "1"}, 11, 21),
-    ({"ALCH_CHUNK": "16", "ALCH_KS_GRID": "24", "ALCH_RS_SLOTS": "5"}, 11, 40),   # persistent grids smaller than the item counts
-    ({"ALCH_CHUNK": "8", "ALCH_RS_SLOTS": "3", "ALCH_TI_GRID": "8"}, 15, 9),
+@pytest.mark.parametrize("opts,logn,batch", [
+    ({"chunk": 8}, 11, 37),                              # 5 chunks on two streams, ragged last chunk
+    ({"chunk": 8, "one_stream": 1}, 11, 21),
+    ({"chunk": 16, "ks_grid": 24, "rs_slots": 5}, 11, 40),   # persistent grids smaller than the item counts
+    ({"chunk": 8, "rs_slots": 3, "ti_grid": 8}, 15, 9),
 ])
-def test_full_mul_launch_structure_does_not_change_results(env, logn, batch):
-    e = dict(os.environ, **env)
-    out = subprocess.run([sys.executable, "-c", WORKER_FULL, str(logn), str(batch)], env=e, capture_output=True,
+def test_full_mul_launch_structure_does_not_change_results(opts, logn, batch):
+    out = subprocess.run([sys.executable, "-c", WORKER_FULL, str(logn), str(batch), json.dumps(opts)], capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.strip().endswith("OK")

@@ -7,7 +7,8 @@ import re
 from conftest import ROOT
 
 CTYPE = {  # C parameter type (qualifiers stripped) -> Haskell FFI type
-    "uint32_t": "Word32", "uint64_t": "Word64", "int": "CInt", "size_t": "CSize", "unsigned": "CUInt",
+    "uint32_t": "Word32", "uint64_t": "Word64", "int": "CInt", "size_t": "CSize", "unsigned": "CUInt", "long": "CLong",
+    "char*": "CString",
     "uint64_t*": "Ptr Word64", "uint32_t*": "Ptr Word32", "int*": "Ptr CInt", "size_t*": "Ptr CSize",
     "float*": "Ptr CFloat", "int64_t*": "Ptr Int64", "void*": "Ptr ()", "void**": "Ptr (Ptr ())",
     "alch_ring*": "Ptr AlchRing", "alch_buf*": "Ptr AlchBuf", "alch_hint*": "Ptr AlchHint",

@@ -12,8 +12,8 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $root/bench.py --steps 5 --warmup 1 --cpu-ops 0"
-PMC="python3 $root/bench.py --steps 1 --warmup 0 --batch 2048 --cpu-ops 0"
+CMD="python3 $root/bench.py --steps 5 --warmup 1 --cpu-ops 0 --no-full --no-pow --no-general"
+PMC="python3 $root/bench.py --steps 1 --warmup 0 --batch 2048 --cpu-ops 0 --no-full --no-pow --no-general"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o stats -- $CMD > "$out/stats.log" 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out" -o fetch -- $PMC > "$out/fetch.log" 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out" -o write -- $PMC > "$out/write.log" 2>&1

@@ -2,10 +2,10 @@
 """Phase breakdown of k_tensor_intt from a -DALCH_STAMPS build (see tools/stamp_report.py)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["ALCH_ONE_STREAM"] = "1"; os.environ["ALCH_CHUNK"] = "2048"
 from alchemy_amd import Ring, load_library
 QS = [2147352577, 2146959361, 2146041857, 2145976321]
 ring = Ring(1 << 16, QS)
+ring.set_option("one_stream", 1); ring.set_option("chunk", 2048)
 B = 2048
 a, b, out, hs = ring.alloc(2*B), ring.alloc(2*B), ring.alloc(2*B), ring.alloc(8)
 a.fill_uniform(2); b.fill_uniform(3); hs.fill_uniform(4)

@@ -4,8 +4,10 @@ WRITE_SIZE collected separately, tools/profile_round.sh).  Units and the gfx950 
 MI355X_MICROARCH.md: both counters are in KiB; FETCH_SIZE is doubled (it reports half of a 16 B/lane coalesced
 read stream on gfx950 -- confirmed here on k_tensor_intt, which must read exactly 1 MiB per op).
 usage: traffic_summary.py DIR BATCH"""
-import csv, glob, json, os, sys
+import csv, glob, json, os, sys, time
 from collections import defaultdict
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_src_sha16
 
 d, batch = sys.argv[1], int(sys.argv[2])
 
@@ -28,7 +30,8 @@ for name in sorted(set(fetch) | set(write)):
     kernels[name] = {"fetch_bytes_per_op_corrected": f, "write_bytes_per_op": w}
     total += f + w
 print(json.dumps({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py "
-                             "--steps 1 --warmup 0 --batch %d --cpu-ops 0" % batch,
+                             "--steps 1 --warmup 0 --batch %d --cpu-ops 0 --no-full --no-pow --no-general" % batch,
                   "batch": batch,
                   "unit_note": "FETCH_SIZE/WRITE_SIZE in KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950)",
+                  "kernel_src_sha16": kernel_src_sha16(), "collected": time.strftime("%Y-%m-%d"),
                   "kernels": kernels, "hbm_bytes_per_op": total}, indent=1))
