@@ -98,6 +98,8 @@ static int is_prime_u64(u64 n) {
     return 1;
 }
 
+int orc_is_prime(u64 n) { return is_prime_u64(n); }      /* shared with oracle/lol_tensor_gen.c */
+
 /* smallest generator of Z_q^*: trial-division factorisation of q-1 (q-1 = 2^k * odd, odd < 2^46) */
 i64 orc_smallest_generator(i64 q) {
     u64 fac[64];
@@ -416,6 +418,36 @@ double orc_bench_mul_relin(const orc_ring *r, int ops, u64 seed) {
     for (int i = 0; i < 2 * L; ++i) free(hint[i]);
     free(hint); free(buf);
     return total;
+}
+
+/* alch_buf_checksum of the result batch of keySwitchQuadCirc(a*b) on synthetic inputs, for ciphertexts
+ * [first, first+count) of a batch whose operand buffers were filled with alch_buf_fill_uniform(seed_a / seed_b) and
+ * whose hint source with seed_h: the partial sum over those ciphertexts' words of splitmix64(w ^ value << 20), w = the
+ * word's limb-major position in the whole out buffer.  Partial sums of disjoint ranges add up (mod 2^64) to the
+ * whole-batch checksum: tests/golden/make_batch_checksums.py runs ranges on several threads. */
+u64 orc_mul_relin_checksum(const orc_ring *r, u64 seed_a, u64 seed_b, u64 seed_h, u64 first, u64 count) {
+    const i64 N = r->n * r->L;
+    const int L = r->L;
+    i64 *buf = malloc(sizeof(i64) * N * 6);
+    i64 **hint = malloc(sizeof(i64 *) * 2 * L);
+    i64 ones[ORC_MAX_LIMBS];
+    for (int j = 0; j < L; ++j) ones[j] = 1;
+    for (int i = 0; i < 2 * L; ++i) { hint[i] = malloc(sizeof(i64) * N); orc_fill_uniform(r, hint[i], seed_h, (u64)i); }
+    u64 sum = 0;
+    for (u64 ct = first; ct < first + count; ++ct) {
+        orc_fill_uniform(r, buf, seed_a, 2 * ct);         orc_fill_uniform(r, buf + N, seed_a, 2 * ct + 1);
+        orc_fill_uniform(r, buf + 2 * N, seed_b, 2 * ct); orc_fill_uniform(r, buf + 3 * N, seed_b, 2 * ct + 1);
+        orc_ct_mul_relin_crt(r, (const i64 *const *)hint, buf, buf + N, buf + 2 * N, buf + 3 * N, ones, buf + 4 * N, buf + 5 * N);
+        for (int c = 0; c < 2; ++c)
+            for (int j = 0; j < L; ++j)
+                for (i64 k = 0; k < r->n; ++k) {
+                    const u64 w = ((2 * ct + (u64)c) * (u64)L + (u64)j) * (u64)r->n + (u64)k;
+                    sum += splitmix64(w ^ ((u64)buf[(4 + c) * N + k * L + j] << 20));
+                }
+    }
+    for (int i = 0; i < 2 * L; ++i) free(hint[i]);
+    free(hint); free(buf);
+    return sum;
 }
 
 orc_ring *orc_ring_new(void) { return calloc(1, sizeof(orc_ring)); }

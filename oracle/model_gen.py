@@ -1,0 +1,410 @@
+"""Exact model of Lol's ``Tensor`` operations for an ARBITRARY cyclotomic index, by definition.
+
+TEST INFRASTRUCTURE ONLY (see oracle/model.py for the rules: nothing under ``alchemy_amd/`` imports this).
+
+PARITY UNPINNED.  The code these definitions stand for is Lol's (``lol`` / ``lol-cpp``, un-vendored, pinned by
+branch name in /root/reference/stack.yaml:54-60); the reference holds no tests or vectors for it.  What is restated
+here is the *published mathematics* of the ring-LWE toolkit (Lyubashevsky, Peikert, Regev, "A Toolkit for Ring-LWE
+Cryptography", Eurocrypt'13, sections 2-6) as Lol fixes it (Crockett & Peikert, CCS'16, section 3 and appendix C):
+
+  * the reference's composite indices: examples/Common.hs:38-54 (H0' = F11648 ... H5' = F20475), used by
+    examples/HomomRLWR.hs:29-35 and examples/Tunnel.hs:26-32;
+  * the Tensor methods concerned: ``crt``/``crtInv``, ``mulGPow/Dec/CRT``, ``divGPow/Dec/CRT``, ``l``/``lInv``,
+    ``twacePowDec``, ``embedPow``, reached from SymmSHE's ``(*)`` (Eval.hs:65-67: ``mulG`` on every
+    product coefficient), ``keySwitchQuadCirc`` (Eval.hs:133), ``modSwitch`` (Eval.hs:130: ``rescaleDec`` on c0,
+    ``rescalePow`` on c1) and ``decrypt`` (PT2CT.hs:91-99: lift in the decoding basis, ``divG`` k times).
+
+Definitions (m = prod_l p_l^e_l, primes ascending; m_l = p_l^e_l; m'_l = m_l / p_l; phi = Euler's totient):
+
+  ring          R = Z[zeta_m];  zeta_{m_l} := zeta_m^(m/m_l);  R = tensor product of the Z[zeta_{m_l}]
+  Pow basis     p_j = prod_l zeta_{m_l}^{j_l},  j_l in [phi(m_l)];  linear index = mixed radix, first factor outermost
+                (for a prime power the powerful basis is the power basis; toolkit Def. 4.1)
+  Dec basis     d^T = p^T L,  L = kron_l (L_{p_l} (x) I_{m'_l}),  L_p = lower-triangular all-ones (p-1 x p-1)
+                (decoding basis of R = (mhat/g) x decoding basis of R^dual; toolkit 6.3, Lol appendix C);  L_2 = (1)
+  l / lInv      Dec coefficients -> Pow coefficients = L c  (prefix sums along j0 of every odd-prime axis), and back
+  g             g_m = prod_{odd p | m} (1 - zeta_p)
+  CRT basis     slot s = (s_1..s_k) (first factor outermost) holds sigma_u(x), sigma_u: zeta_m -> omega_m^u, with
+                omega_m = gen^((q-1)/m), gen = smallest generator of Z_q^* (the root rule of oracle/model.py), and
+                u = i0 + p i1 (mod m_l) on axis l where s_l = (i0 - 1) m'_l + digitrev_p(i1), i0 in [1, p-1],
+                i1 in [m'_l].  For m = 2^k this is slot k <-> psi^(2 brev(k) + 1), the two-power rule of model.py.
+                (The slot ORDER is instance-internal in Lol -- only crtInv . crt = id and the ring homomorphism
+                are observable; this order is the one the sparse decomposition CRT_{p^e} = (DFT_{m'} (x) I) T (I (x)
+                CRT_p) with decimation-in-frequency DFTs produces in place.)
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from .model import centred, is_prime, smallest_generator
+
+
+# --------------------------------------------------------------------------------------
+# index bookkeeping
+# --------------------------------------------------------------------------------------
+
+def factor(m: int):
+    """[(p, e)] with primes ascending."""
+    out, p = [], 2
+    while p * p <= m:
+        if m % p == 0:
+            e = 0
+            while m % p == 0:
+                m //= p
+                e += 1
+            out.append((p, e))
+        p += 1 if p == 2 else 2
+    if m > 1:
+        out.append((m, 1))
+    return out
+
+
+def totient(m: int) -> int:
+    r = 1
+    for p, e in factor(m):
+        r *= (p - 1) * p ** (e - 1)
+    return r
+
+
+def digitrev(x: int, p: int, digits: int) -> int:
+    r = 0
+    for _ in range(digits):
+        r = r * p + x % p
+        x //= p
+    return r
+
+
+class Index:
+    """Factored cyclotomic index with the mixed-radix bookkeeping of the Pow / Dec / CRT bases."""
+
+    def __init__(self, m: int):
+        assert m >= 1
+        self.m = m
+        self.pps = factor(m)
+        self.mls = [p ** e for p, e in self.pps]
+        self.dims = [(p - 1) * p ** (e - 1) for p, e in self.pps]
+        self.n = 1
+        for d in self.dims:
+            self.n *= d
+        # strides of the mixed-radix linear index (first factor outermost)
+        self.strides = []
+        s = self.n
+        for d in self.dims:
+            s //= d
+            self.strides.append(s)
+
+    def unravel(self, lin: int):
+        return [(lin // s) % d for s, d in zip(self.strides, self.dims)]
+
+    def ravel(self, idx) -> int:
+        return sum(i * s for i, s in zip(idx, self.strides))
+
+    def pow_exponent(self, lin: int) -> int:
+        """p_j = zeta_m^e(j)."""
+        return sum(j * (self.m // ml) for j, ml in zip(self.unravel(lin), self.mls)) % self.m
+
+    def axis_unit(self, l: int, s: int) -> int:
+        """Unit of Z_{m_l}^* of slot s of axis l."""
+        p, e = self.pps[l]
+        mp = p ** (e - 1)
+        i0, r = s // mp + 1, s % mp
+        i1 = digitrev(r, p, e - 1)
+        return (i0 + p * i1) % (p ** e)
+
+    def slot_unit(self, lin: int) -> int:
+        """Unit u of Z_m^* of CRT slot `lin` (Chinese remaindering of the per-axis units)."""
+        u, mod = 0, 1
+        for l, s in enumerate(self.unravel(lin)):
+            ml = self.mls[l]
+            ul = self.axis_unit(l, s)
+            # solve x = u (mod mod), x = ul (mod ml)
+            t = (ul - u) * pow(mod, -1, ml) % ml if mod > 1 else ul
+            u, mod = u + mod * t, mod * ml
+        return u % self.m
+
+
+def omega_m(q: int, m: int) -> int:
+    """omega_m = gen^((q-1)/m): the root rule (same as model.root_2n for m = 2n a power of two)."""
+    assert is_prime(q) and (q - 1) % m == 0, "q must be prime and 1 mod m (Lol: crtFuncs = Nothing otherwise)"
+    return pow(smallest_generator(q), (q - 1) // m, q)
+
+
+# --------------------------------------------------------------------------------------
+# crt / crtInv by definition
+# --------------------------------------------------------------------------------------
+
+def crt_def(a: Sequence[int], idx: Index, q: int) -> List[int]:
+    """slot s = sum_j a_j omega_m^(u(s) e(j)): direct evaluation over the whole index (O(n^2), numpy rows)."""
+    n, m = idx.n, idx.m
+    w = omega_m(q, m)
+    powers = np.empty(m, dtype=np.uint64)
+    acc = 1
+    for t in range(m):
+        powers[t] = acc
+        acc = acc * w % q
+    ex = np.array([idx.pow_exponent(j) for j in range(n)], dtype=np.int64)
+    av = np.array([x % q for x in a], dtype=np.uint64)
+    out = []
+    for s in range(n):
+        u = idx.slot_unit(s)
+        row = powers[(ex * u) % m]
+        out.append(int(((row * av) % np.uint64(q)).sum(dtype=np.uint64) % np.uint64(q)))   # n * q < 2^64 for q < 2^31, n < 2^33
+    return out
+
+
+def _mat_inv_mod(M: List[List[int]], q: int) -> List[List[int]]:
+    n = len(M)
+    A = [list(r) + [1 if i == j else 0 for j in range(n)] for i, r in enumerate(M)]
+    for c in range(n):
+        piv = next(r for r in range(c, n) if A[r][c] % q)
+        A[c], A[piv] = A[piv], A[c]
+        inv = pow(A[c][c], -1, q)
+        A[c] = [x * inv % q for x in A[c]]
+        for r in range(n):
+            if r != c and A[r][c]:
+                f = A[r][c]
+                A[r] = [(x - f * y) % q for x, y in zip(A[r], A[c])]
+    return [r[n:] for r in A]
+
+
+def axis_crt_matrix(idx: Index, l: int, q: int) -> List[List[int]]:
+    """CRT_{m_l}[s][j] = omega_{m_l}^(u(s) j), by definition."""
+    ml, d = idx.mls[l], idx.dims[l]
+    w = pow(omega_m(q, idx.m), idx.m // ml, q)
+    return [[pow(w, idx.axis_unit(l, s) * j % ml, q) for j in range(d)] for s in range(d)]
+
+
+def apply_axis(a: Sequence[int], idx: Index, l: int, M: List[List[int]], q: Optional[int]) -> List[int]:
+    """out[.., s, ..] = sum_j M[s][j] a[.., j, ..] along axis l (q = None: over the integers)."""
+    n, d, st = idx.n, idx.dims[l], idx.strides[l]
+    out = [0] * n
+    for base in range(n):
+        if (base // st) % d:
+            continue
+        col = [a[base + j * st] for j in range(d)]
+        for s in range(d):
+            v = sum(M[s][j] * col[j] for j in range(d))
+            out[base + s * st] = v % q if q else v
+    return out
+
+
+def crt_kron(a: Sequence[int], idx: Index, q: int) -> List[int]:
+    """The same transform as the Kronecker product of the per-axis definitions (must equal crt_def)."""
+    x = [v % q for v in a]
+    for l in range(len(idx.pps)):
+        x = apply_axis(x, idx, l, axis_crt_matrix(idx, l, q), q)
+    return x
+
+
+def crtinv_def(v: Sequence[int], idx: Index, q: int) -> List[int]:
+    """crtInv: the unique a with crt(a) = v (per-axis matrix inverses by Gaussian elimination)."""
+    x = [t % q for t in v]
+    for l in range(len(idx.pps)):
+        x = apply_axis(x, idx, l, _mat_inv_mod(axis_crt_matrix(idx, l, q), q), q)
+    return x
+
+
+# --------------------------------------------------------------------------------------
+# ring product by definition (schoolbook in Z[X]/(X^m - 1), reduced to the powerful basis)
+# --------------------------------------------------------------------------------------
+
+def _reduce_to_pow(coef_by_exp, idx: Index, q: Optional[int]) -> List[int]:
+    """sum_t c_t zeta_m^t  ->  Pow-basis coefficients.  zeta_m^t = prod_l zeta_{m_l}^{t_l}; on every axis
+    zeta_{p^e}^((p-1) m' + r) = - sum_{i < p-1} zeta_{p^e}^(i m' + r)   (Phi_{p^e}(Y) = 1 + Y^m' + ... + Y^((p-1) m'))."""
+    k = len(idx.pps)
+    T = np.zeros(idx.mls if k else [1], dtype=object)
+    invs = [pow(idx.m // ml, -1, ml) if ml > 1 else 0 for ml in idx.mls]
+    for t, c in coef_by_exp.items():
+        if c:
+            T[tuple(t * inv % ml for inv, ml in zip(invs, idx.mls))] += c
+    for l, ((p, e), d) in enumerate(zip(idx.pps, idx.dims)):
+        mp = p ** (e - 1)
+        T = np.moveaxis(T, l, 0)
+        lo = T[:d].copy()
+        for r in range(mp):
+            top = T[d + r]
+            for i in range(p - 1):
+                lo[i * mp + r] = lo[i * mp + r] - top
+        T = np.moveaxis(lo, 0, l)
+    flat = [int(x) for x in T.reshape(-1)]
+    return [x % q for x in flat] if q else flat
+
+
+def ring_mul_def(a: Sequence[int], b: Sequence[int], idx: Index, q: Optional[int]) -> List[int]:
+    ex = [idx.pow_exponent(j) for j in range(idx.n)]
+    acc = {}
+    for i, ai in enumerate(a):
+        if not ai:
+            continue
+        for j, bj in enumerate(b):
+            if bj:
+                t = (ex[i] + ex[j]) % idx.m
+                acc[t] = acc.get(t, 0) + ai * bj
+    return _reduce_to_pow(acc, idx, q)
+
+
+def g_pow(idx: Index) -> List[int]:
+    """g_m = prod_{odd p | m} (1 - zeta_p) in the Pow basis (integers)."""
+    g = [0] * idx.n
+    g[0] = 1
+    for l, (p, e) in enumerate(idx.pps):
+        if p == 2:
+            continue
+        f = [0] * idx.n
+        f[0] = 1
+        f[p ** (e - 1) * idx.strides[l]] -= 1          # zeta_p = zeta_{p^e}^(p^(e-1)): index j_l = m'_l
+        g = ring_mul_def(g, f, idx, None)
+    return g
+
+
+# --------------------------------------------------------------------------------------
+# l / lInv, mulG / divG by definition
+# --------------------------------------------------------------------------------------
+
+def _axis_L(idx: Index, l: int, inverse: bool) -> List[List[int]]:
+    p, e = idx.pps[l]
+    mp, d = p ** (e - 1), idx.dims[l]
+    M = [[0] * d for _ in range(d)]
+    for i0 in range(p - 1):
+        for j0 in range(p - 1):
+            v = (1 if j0 <= i0 else 0) if not inverse else (1 if j0 == i0 else -1 if j0 == i0 - 1 else 0)
+            for r in range(mp):
+                M[i0 * mp + r][j0 * mp + r] = v
+    return M
+
+
+def l_def(c: Sequence[int], idx: Index, q: Optional[int]) -> List[int]:
+    """Dec coefficients -> Pow coefficients."""
+    x = list(c)
+    for l in range(len(idx.pps)):
+        x = apply_axis(x, idx, l, _axis_L(idx, l, False), q)
+    return x
+
+
+def linv_def(a: Sequence[int], idx: Index, q: Optional[int]) -> List[int]:
+    x = list(a)
+    for l in range(len(idx.pps)):
+        x = apply_axis(x, idx, l, _axis_L(idx, l, True), q)
+    return x
+
+
+def mulg_pow_def(a: Sequence[int], idx: Index, q: Optional[int]) -> List[int]:
+    return ring_mul_def(g_pow(idx), a, idx, q)
+
+
+def mulg_dec_def(c: Sequence[int], idx: Index, q: Optional[int]) -> List[int]:
+    return linv_def(mulg_pow_def(l_def(c, idx, q), idx, q), idx, q)
+
+
+def odd_rad(idx: Index) -> int:
+    r = 1
+    for p, _ in idx.pps:
+        if p != 2:
+            r *= p
+    return r
+
+
+def divg_pow_def(a: Sequence[int], idx: Index, q: Optional[int]) -> Optional[List[int]]:
+    """The b with g b = a, or None (Lol's Nothing).  rad = prod of the odd primes of m;  rad / g is in R, so
+    b = (rad / g) a / rad: over Z_q that needs rad invertible mod q, over Z every coefficient divisible by rad."""
+    rad = odd_rad(idx)
+    h = [0] * idx.n                                   # rad / g = prod_p (p / (1 - zeta_p)) = prod_p sum_i (p-1-i) zeta_p^i
+    h[0] = 1
+    for l, (p, e) in enumerate(idx.pps):
+        if p == 2:
+            continue
+        f = [0] * idx.n
+        for i in range(p - 1):
+            f[i * p ** (e - 1) * idx.strides[l]] = p - 1 - i
+        h = ring_mul_def(h, f, idx, None)
+    t = ring_mul_def(h, a, idx, q)
+    if q:
+        try:
+            inv = pow(rad, -1, q)
+        except ValueError:
+            return None
+        return [x * inv % q for x in t]
+    if any(x % rad for x in t):
+        return None
+    return [x // rad for x in t]
+
+
+def divg_dec_def(c: Sequence[int], idx: Index, q: Optional[int]) -> Optional[List[int]]:
+    r = divg_pow_def(l_def(c, idx, q), idx, q)
+    return None if r is None else linv_def(r, idx, q)
+
+
+def g_crt(idx: Index, q: int) -> List[int]:
+    """CRT-basis image of g: slot s = prod_p (1 - omega_p^u(s))."""
+    w = omega_m(q, idx.m)
+    out = []
+    for s in range(idx.n):
+        u = idx.slot_unit(s)
+        v = 1
+        for p, _ in idx.pps:
+            if p != 2:
+                v = v * (1 - pow(w, (idx.m // p) * u % idx.m, q)) % q
+        out.append(v)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# twace / embed on the Pow (and Dec) basis, m | m'
+# --------------------------------------------------------------------------------------
+
+def embed_indices(small: Index, big: Index) -> List[int]:
+    """Pow-basis index of R_m's basis element j inside R_m' (embedPow is this injection; twacePowDec reads the
+    same positions back, in the Pow and in the Dec basis alike)."""
+    assert big.m % small.m == 0
+    pos = []
+    sp = dict(small.pps)
+    for j in range(small.n):
+        js = dict(zip([p for p, _ in small.pps], small.unravel(j)))
+        idxb = []
+        for (p, eb) in big.pps:
+            es = sp.get(p, 0)
+            idxb.append(js[p] * p ** (eb - es) if es else 0)
+        pos.append(big.ravel(idxb))
+    return pos
+
+
+def embed_pow(a: Sequence[int], small: Index, big: Index) -> List[int]:
+    out = [0] * big.n
+    for j, pos in enumerate(embed_indices(small, big)):
+        out[pos] = a[j]
+    return out
+
+
+def twace_pow_dec(a: Sequence[int], small: Index, big: Index) -> List[int]:
+    return [a[pos] for pos in embed_indices(small, big)]
+
+
+# --------------------------------------------------------------------------------------
+# RNS helpers and SymmSHE on a general index
+# --------------------------------------------------------------------------------------
+
+def rns(fn, x, idx, qs, *args):
+    return [fn(xl, idx, q, *args) for xl, q in zip(x, qs)]
+
+
+def rns_ring_mul(a, b, idx: Index, qs):
+    return [ring_mul_def(al, bl, idx, q) for al, bl, q in zip(a, b, qs)]
+
+
+def lift_dec(x, idx: Index, qs) -> List[int]:
+    """Lol's liftDec: centred lift (mod Q = prod q) of the Dec-basis coefficients of an RNS ring element (Pow in)."""
+    from .model import _crt_lift
+    dec = [linv_def(xl, idx, q) for xl, q in zip(x, qs)]
+    return [_crt_lift([dec[j][i] for j in range(len(qs))], qs) for i in range(idx.n)]
+
+
+def rescale_down_basis(x, idx: Index, qs, drop: int, basis: str):
+    """Rescale (a, b) -> b, `drop` limbs, coefficient-wise in the Pow or the Dec basis (x given and returned in the
+    Pow basis): modSwitch rescales c0 with rescaleDec and c1 with rescalePow."""
+    from .model import rescale_down
+    if basis == "pow":
+        return rescale_down(x, qs, drop)
+    dec = [linv_def(xl, idx, q) for xl, q in zip(x, qs)]
+    y = rescale_down(dec, qs, drop)
+    return [l_def(yl, idx, q) for yl, q in zip(y, qs[drop:])]
