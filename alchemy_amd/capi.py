@@ -14,6 +14,8 @@ ALCH_E_INVALID, ALCH_E_NOT_PRIME, ALCH_E_NO_CRT, ALCH_E_UNSUPPORTED = -1, -2, -3
 ALCH_E_NO_DEVICE, ALCH_E_HIP, ALCH_E_NOMEM = -5, -6, -7
 ALCH_POW_IN, ALCH_POW_OUT = 1, 2
 ALCH_GAD_TRIV, ALCH_GAD_BASE2 = 0, 1
+ALCH_NOT_DIVISIBLE = 1
+ALCH_BASIS_POW, ALCH_BASIS_DEC, ALCH_BASIS_CRT = 0, 1, 2
 
 # every symbol include/alchemy_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
@@ -25,7 +27,8 @@ SYMBOLS = [
     "alch_buf_crtinv", "alch_buf_mul", "alch_buf_add", "alch_buf_checksum", "alch_hint_load", "alch_hint_from_buf",
     "alch_hint_free", "alch_ct_mul_relin", "alch_buf_rescale_drop0", "alch_buf_sub", "alch_buf_scale",
     "alch_buf_decompose_triv", "alch_buf_rescale_add0", "alch_decompose_base2", "alch_ct_mul_full", "alch_buf_device_ptr",
-    "alch_ring_set_option",
+    "alch_ring_set_option", "alch_ring_create_nocrt", "alch_l", "alch_linv", "alch_buf_l", "alch_buf_linv", "alch_buf_mulg",
+    "alch_buf_divg", "alch_buf_mul_public", "alch_buf_add_public",
 ]
 
 
@@ -82,7 +85,13 @@ def load_library():
     l.alch_version.restype = C.c_uint32
     sig = {
         "alch_ring_create": [C.c_uint32, C.c_int, PU64, C.POINTER(VP)],
+        "alch_ring_create_nocrt": [C.c_uint32, C.c_int, PU64, C.POINTER(VP)],
         "alch_ring_destroy": [VP],
+        "alch_l": [VP, P64], "alch_linv": [VP, P64],
+        "alch_buf_l": [VP, C.c_size_t, C.c_size_t], "alch_buf_linv": [VP, C.c_size_t, C.c_size_t],
+        "alch_buf_mulg": [VP, C.c_size_t, C.c_size_t, C.c_int], "alch_buf_divg": [VP, C.c_size_t, C.c_size_t, C.c_int],
+        "alch_buf_mul_public": [VP, VP, VP, C.c_size_t, C.c_size_t],
+        "alch_buf_add_public": [VP, VP, C.c_size_t, C.c_size_t],
         "alch_host_root": [C.c_uint32, C.c_uint64, PU64, PU64],
         "alch_ring_n": [VP, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "alch_ring_set_stream": [VP, VP],
@@ -154,15 +163,17 @@ def host_root(m: int, q: int):
 class Ring:
     """alch_ring: one (cyclotomic index, RNS modulus list) context, i.e. one `Cyc t m' zq` type."""
 
-    def __init__(self, m: int, qs):
+    def __init__(self, m: int, qs, nocrt: bool = False):
+        """nocrt: a ring without CRT basis (plaintext ring Z_p, or the integers with modulus 0): Pow / Dec ops only."""
         self._l = load_library()
-        self.m, self.n, self.qs, self.L = int(m), int(m) // 2, [int(q) for q in qs], len(qs)
+        self.m, self.qs, self.L = int(m), [int(q) for q in qs], len(qs)
         h = C.c_void_p()
-        _check(self._l.alch_ring_create(self.m, self.L, _pu64(self.qs), C.byref(h)))
+        create = self._l.alch_ring_create_nocrt if nocrt else self._l.alch_ring_create
+        _check(create(self.m, self.L, _pu64(self.qs), C.byref(h)))
         self._h = h
-        w = C.c_int()
-        _check(self._l.alch_ring_n(self._h, None, None, C.byref(w)))
-        self.word_bytes = int(w.value)
+        w, n = C.c_int(), C.c_uint32()
+        _check(self._l.alch_ring_n(self._h, C.byref(n), None, C.byref(w)))
+        self.word_bytes, self.n = int(w.value), int(n.value)          # n = phi(m)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -216,9 +227,18 @@ class Ring:
     def mulg_pow(self, a): return self._host1(self._l.alch_mulg_pow, a)
     def mulg_dec(self, a): return self._host1(self._l.alch_mulg_dec, a)
     def mulg_crt(self, a): return self._host1(self._l.alch_mulg_crt, a)
-    def divg_pow(self, a): return self._host1(self._l.alch_divg_pow, a)
-    def divg_dec(self, a): return self._host1(self._l.alch_divg_dec, a)
-    def divg_crt(self, a): return self._host1(self._l.alch_divg_crt, a)
+    def l(self, a): return self._host1(self._l.alch_l, a)
+    def linv(self, a): return self._host1(self._l.alch_linv, a)
+
+    def _maybe(self, fn, a):
+        """divG family: the new array, or None for Lol's Nothing (ALCH_NOT_DIVISIBLE)."""
+        out = np.ascontiguousarray(a, dtype=np.int64).copy()
+        assert out.shape == (self.n, self.L), out.shape
+        return None if _check(fn(self._h, _p64(out))) == ALCH_NOT_DIVISIBLE else out
+
+    def divg_pow(self, a): return self._maybe(self._l.alch_divg_pow, a)
+    def divg_dec(self, a): return self._maybe(self._l.alch_divg_dec, a)
+    def divg_crt(self, a): return self._maybe(self._l.alch_divg_crt, a)
 
     def scale(self, a, s):
         out = np.ascontiguousarray(a, dtype=np.int64).copy()
@@ -349,6 +369,25 @@ class Buf:
 
     def add(self, a: "Buf", b: "Buf", count: int):
         _check(self.ring._l.alch_buf_add(self._h, a._h, b._h, count))
+
+    def l(self, first: int = 0, count: int | None = None):
+        _check(self.ring._l.alch_buf_l(self._h, first, self.n_elems - first if count is None else count))
+
+    def linv(self, first: int = 0, count: int | None = None):
+        _check(self.ring._l.alch_buf_linv(self._h, first, self.n_elems - first if count is None else count))
+
+    def mulg(self, basis: int, first: int = 0, count: int | None = None):
+        _check(self.ring._l.alch_buf_mulg(self._h, first, self.n_elems - first if count is None else count, basis))
+
+    def divg(self, basis: int, first: int = 0, count: int | None = None) -> bool:
+        """True = divided; False = Lol's Nothing for some element of the range."""
+        return _check(self.ring._l.alch_buf_divg(self._h, first, self.n_elems - first if count is None else count, basis)) == ALCH_OK
+
+    def mul_public(self, src: "Buf", pub: "Buf", pub_index: int, count: int):
+        _check(self.ring._l.alch_buf_mul_public(self._h, src._h, pub._h, pub_index, count))
+
+    def add_public(self, pub: "Buf", pub_index: int, batch: int):
+        _check(self.ring._l.alch_buf_add_public(self._h, pub._h, pub_index, batch))
 
     def checksum(self, first: int = 0, count: int | None = None) -> int:
         s = C.c_uint64()

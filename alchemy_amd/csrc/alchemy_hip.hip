@@ -13,6 +13,7 @@
 #include "../../include/alchemy_hip.h"
 #include "kernels_ntt.hpp"
 #include "ring_host.hpp"
+#include "gen_host.hpp"
 
 using namespace alch;
 
@@ -49,6 +50,15 @@ struct alch_ring {
     bool one_stream = false;
     unsigned rs_slots = 512;                   // resident workgroups of k_rescale_out (each owns a stash slot)
     alch_buf* scratch = nullptr;               // staging elements of the host-buffer Tensor methods
+    // general cyclotomic index (kernel_gen.hpp); two-power rings with n >= 16 keep the radix-16 engine
+    bool gen = false;
+    bool has_crt = true;                       // false: ring created with alch_ring_create_nocrt (Pow / Dec operations only)
+    bool zdom = false;                         // "modulus" 0: the integers, signed 64-bit words
+    GenHost gh;
+    GenDev<u32> g32;
+    GenDev<u64> g64;
+    void* gen_tables = nullptr;
+    int* d_flag = nullptr;                     // divG failure flag
 };
 
 struct alch_buf {
@@ -89,7 +99,7 @@ static int fail(int code, const std::string& msg) {
     } while (0)
 
 extern "C" const char* alch_last_error(void) { return g_err.c_str(); }
-extern "C" uint32_t alch_version(void) { return (1u << 16) | 3u; }   // 1.3: + alch_decompose_base2, BaseBGad hints, alch_ct_mul_full, alch_buf_device_ptr, n = 2^16
+extern "C" uint32_t alch_version(void) { return (1u << 16) | 4u; }   // 1.4: general cyclotomic indices, l / lInv, real mulG / divG, mulPublic / addPublic, alch_ring_set_option; 1.3: + alch_decompose_base2, BaseBGad hints, alch_ct_mul_full, alch_buf_device_ptr, n = 2^16
 
 // ------------------------------------------------------------------------------------------------------
 // element-wise kernels (HBM-bound; 16 B per lane, grid-stride, ~2048 workgroups)
@@ -103,7 +113,7 @@ __host__ __device__ static inline u64 splitmix64(u64 x) {
 
 template <typename W>
 __global__ void k_fill_uniform(DevRing<W> R, W* data, size_t words, u64 seed) {
-    const size_t n = (size_t)1 << R.logn;
+    const size_t n = (size_t)R.n;
     for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < words; w += (size_t)gridDim.x * blockDim.x) {
         const int j = (int)((w / n) % (size_t)R.L);
         data[w] = (W)(splitmix64(seed + w) % (u64)R.mod[j].q);
@@ -113,7 +123,7 @@ __global__ void k_fill_uniform(DevRing<W> R, W* data, size_t words, u64 seed) {
 // Lol's tuple-interleaved int64 (coefficient-major, limb-minor) <-> limb-major device words.
 template <typename W, bool TO_DEVICE>
 __global__ void k_transpose(DevRing<W> R, W* dev, int64_t* host, size_t elems) {
-    const size_t n = (size_t)1 << R.logn;
+    const size_t n = (size_t)R.n;
     const size_t L = (size_t)R.L;
     const size_t total = elems * L * n;
     for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < total; w += (size_t)gridDim.x * blockDim.x) {
@@ -128,7 +138,7 @@ enum PwOp { PW_MUL = 0, PW_ADD = 1, PW_SUB = 2 };
 
 template <typename W, int OP>
 __global__ void k_pointwise(DevRing<W> R, W* dst, const W* a, const W* b, size_t words) {
-    const size_t n = (size_t)1 << R.logn;
+    const size_t n = (size_t)R.n;
     typedef typename Vec4<W>::type V;
     constexpr int VL = Vec4<W>::LANES;
     const size_t nv = words / VL;
@@ -146,10 +156,23 @@ __global__ void k_pointwise(DevRing<W> R, W* dst, const W* a, const W* b, size_t
     }
 }
 
+// The same, one word per lane: rings whose dimension is not a multiple of the vector width (general indices such as
+// m = 9, n = 6), where a 16-byte piece would straddle two limbs.
+template <typename W, int OP>
+__global__ void k_pointwise_scalar(DevRing<W> R, W* dst, const W* a, const W* b, size_t words) {
+    const size_t n = (size_t)R.n;
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < words; w += (size_t)gridDim.x * blockDim.x) {
+        const ModP<W> m = R.mod[(w / n) % (size_t)R.L];
+        if (OP == PW_MUL) dst[w] = mont_mul(mont_mul(a[w], m.r2, m), b[w], m);
+        else if (OP == PW_ADD) dst[w] = add_mod(a[w], b[w], m.q);
+        else dst[w] = sub_mod(a[w], b[w], m.q);
+    }
+}
+
 // dst = src * s_j (mod q_j); sm[j] = s_j in Montgomery form.  TO_MONT callers pass sm = R^2 mod q.
 template <typename W>
 __global__ void k_scale(DevRing<W> R, W* dst, const W* src, size_t words, Scal<W> sm) {
-    const size_t n = (size_t)1 << R.logn;
+    const size_t n = (size_t)R.n;
     for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < words; w += (size_t)gridDim.x * blockDim.x) {
         const int j = (int)((w / n) % (size_t)R.L);
         dst[w] = mont_mul(src[w], sm.v[j], R.mod[j]);
@@ -161,7 +184,7 @@ __global__ void k_scale(DevRing<W> R, W* dst, const W* src, size_t words, Scal<W
 template <typename W>
 __global__ void k_decompose_triv(DevRing<W> R, const W* c, W* digits, int balanced) {
     typedef typename Signed<W>::type SW;
-    const size_t n = (size_t)1 << R.logn;
+    const size_t n = (size_t)R.n;
     const size_t L = (size_t)R.L;
     const size_t total = L * L * n;
     c += (size_t)blockIdx.y * L * n;                       // blockIdx.y: which ring element
@@ -184,7 +207,7 @@ __global__ void k_decompose_triv(DevRing<W> R, const W* c, W* digits, int balanc
 template <typename W>
 __global__ void k_decompose_base2(DevRing<W> R, const W* c, W* digits, Scal<u32> first_digit, Scal<u32> kd, u32 D) {
     typedef typename Signed<W>::type SW;
-    const size_t n = (size_t)1 << R.logn;
+    const size_t n = (size_t)R.n;
     const size_t L = (size_t)R.L;
     c += (size_t)blockIdx.y * L * n;                       // blockIdx.y: which ring element
     digits += (size_t)blockIdx.y * D * L * n;
@@ -213,13 +236,17 @@ __global__ void k_decompose_base2(DevRing<W> R, const W* c, W* digits, Scal<u32>
 
 // SymmSHE (*) on linear ciphertexts, element-wise on the CRT basis: c0 = a0 b0 s, c1 = (a0 b1 + a1 b0) s -> out,
 // c2 = a1 b1 s -> c2buf (one element per ciphertext).  sr2 = s R^2 (Montgomery).  Used by the BaseBGad key switch.
+template <typename W> struct GTab { const W* p[MAXL]; };     // per limb: CRT image of g (Montgomery form), or null
+
 template <typename W>
 __global__ void k_tensor_ew(DevRing<W> R, const W* a, const W* b, W* out, W* c2buf, size_t nct, Scal<W> sr2, int dup,
-                            W* c2crt = nullptr) {
+                            W* c2crt, GTab<W> gt) {
+    // gt: general index -- SymmSHE's (*) applies mulG to every product coefficient (mulGCRT = pointwise product with the
+    // CRT image of g); all-null for a two-power index, where g = 1
     // c2crt != null: a second copy of c2 that stays in the CRT basis (the diagonal digits of the key switch)
     // R: the ring of out / c2buf (L limbs); a, b live on its last L - dup limbs; the dup leading limbs of the
     // results are zero (modSwitch up: Rescale b -> (a,b), its q_a factor folded into sr2 by the host)
-    const size_t n = (size_t)1 << R.logn;
+    const size_t n = (size_t)R.n;
     const size_t Ln = (size_t)R.L * n, Lsn = (size_t)(R.L - dup) * n, off = (size_t)dup * n;
     for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < nct * Ln; w += (size_t)gridDim.x * blockDim.x) {
         const size_t ct = w / Ln, rem = w % Ln;
@@ -233,9 +260,16 @@ __global__ void k_tensor_ew(DevRing<W> R, const W* a, const W* b, W* out, W* c2b
         const W a0 = a[2 * ct * Lsn + rs], a1 = a[(2 * ct + 1) * Lsn + rs];
         const W b0 = b[2 * ct * Lsn + rs], b1 = b[(2 * ct + 1) * Lsn + rs];
         const W x0 = mont_mul(a0, sr2.v[js], m), x1 = mont_mul(a1, sr2.v[js], m);      // a s R
-        out[2 * ct * Ln + rem] = mont_mul(b0, x0, m);
-        out[(2 * ct + 1) * Ln + rem] = add_mod(mont_mul(b1, x0, m), mont_mul(b0, x1, m), m.q);
-        const W c2v = mont_mul(b1, x1, m);
+        W c0v = mont_mul(b0, x0, m);
+        W c1v = add_mod(mont_mul(b1, x0, m), mont_mul(b0, x1, m), m.q);
+        W c2v = mont_mul(b1, x1, m);
+        const W* g = gt.p[rem / n];
+        if (g) {
+            const W gv = g[rem % n];
+            c0v = mont_mul(c0v, gv, m); c1v = mont_mul(c1v, gv, m); c2v = mont_mul(c2v, gv, m);
+        }
+        out[2 * ct * Ln + rem] = c0v;
+        out[(2 * ct + 1) * Ln + rem] = c1v;
         c2buf[ct * Ln + rem] = c2v;
         if (c2crt) c2crt[ct * Ln + rem] = c2v;
     }
@@ -250,7 +284,7 @@ __global__ void k_hint_mac(DevRing<W> R, W* out, const W* digits, const W* hint,
     // One thread owns one (limb, slot) of TILE consecutive ciphertexts, so a hint word is loaded once per TILE
     // products (the hint is the larger stream for a many-digit gadget: 2 D words against D per ciphertext).
     constexpr int TILE = 4;
-    const size_t n = (size_t)1 << R.logn;
+    const size_t n = (size_t)R.n;
     const size_t Ln = (size_t)R.L * n;
     const size_t ntile = (nct + TILE - 1) / TILE;
     for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < ntile * Ln; w += (size_t)gridDim.x * blockDim.x) {
@@ -288,7 +322,7 @@ __global__ void k_hint_mac(DevRing<W> R, W* out, const W* digits, const W* hint,
 template <typename W>
 __global__ void k_rescale_drop0(DevRing<W> R, const W* src, W* dst, size_t elems, Scal<W> q0inv_m) {
     typedef typename Signed<W>::type SW;
-    const size_t n = (size_t)1 << R.logn;
+    const size_t n = (size_t)R.n;
     const size_t L = (size_t)R.L;
     const size_t total = elems * (L - 1) * n;
     const W q0 = R.mod[0].q;
@@ -308,12 +342,43 @@ __global__ void k_rescale_drop0(DevRing<W> R, const W* src, W* dst, size_t elems
 // Rescale b -> (a,b): dst limb 0 = 0, dst limb j+1 = q_a * src limb j.  qa_m[j+1] = q_a mod q_{j+1} (Montgomery).
 template <typename W>
 __global__ void k_rescale_add0(DevRing<W> Rd, const W* src, W* dst, size_t elems, Scal<W> qa_m) {
-    const size_t n = (size_t)1 << Rd.logn;
+    const size_t n = (size_t)Rd.n;
     const size_t L = (size_t)Rd.L;
     const size_t total = elems * L * n;
     for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < total; w += (size_t)gridDim.x * blockDim.x) {
         const size_t k = w % n, j = (w / n) % L, e = w / (n * L);
         dst[w] = j == 0 ? (W)0 : mont_mul(src[(e * (L - 1) + (j - 1)) * n + k], qa_m.v[j], Rd.mod[j]);
+    }
+}
+
+// mulGCRT / divGCRT: element-wise product with a per-limb table of n words (Montgomery form).
+template <typename W>
+__global__ void k_mul_table(DevRing<W> R, W* data, size_t words, GTab<W> gt) {
+    const size_t n = (size_t)R.n;
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < words; w += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)((w / n) % (size_t)R.L);
+        data[w] = mont_mul(data[w], gt.p[j][w % n], R.mod[j]);
+    }
+}
+
+// SymmSHE mulPublic (Eval.hs:132): every ring element of src times one public ring element (CRT basis, pointwise).
+template <typename W>
+__global__ void k_mul_bcast(DevRing<W> R, W* dst, const W* src, const W* pub, size_t words) {
+    const size_t n = (size_t)R.n, Ln = (size_t)R.L * n;
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < words; w += (size_t)gridDim.x * blockDim.x) {
+        const ModP<W> m = R.mod[(w / n) % (size_t)R.L];
+        dst[w] = mont_mul(mont_mul(src[w], m.r2, m), pub[w % Ln], m);
+    }
+}
+
+// SymmSHE addPublic (Eval.hs:131): one public ring element added to the c0 of every ciphertext (elements 0, 2, 4, ..).
+template <typename W>
+__global__ void k_add_bcast(DevRing<W> R, W* dst, const W* pub, size_t cts) {
+    const size_t n = (size_t)R.n, Ln = (size_t)R.L * n;
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < cts * Ln; w += (size_t)gridDim.x * blockDim.x) {
+        const size_t ct = w / Ln, rem = w % Ln;
+        W* p = dst + 2 * ct * Ln + rem;
+        *p = add_mod(*p, pub[rem], R.mod[rem / n].q);
     }
 }
 
@@ -345,6 +410,7 @@ static int build_dev_ring(alch_ring* r, DevRing<W>& d) {
     memset(&d, 0, sizeof d);
     d.L = L;
     d.logn = r->logn;
+    d.n = r->n;
     u64 maxhalf = 0;
     for (int j = 0; j < L; ++j) maxhalf = std::max(maxhalf, (r->q[j] - 1) / 2);
     for (int j = 0; j < L; ++j) {
@@ -383,9 +449,96 @@ static int build_dev_ring(alch_ring* r, DevRing<W>& d) {
     return ALCH_OK;
 }
 
+template <typename W> static GenDev<W>& gen_dev(alch_ring* r);
+template <> GenDev<u32>& gen_dev<u32>(alch_ring* r) { return r->g32; }
+template <> GenDev<u64>& gen_dev<u64>(alch_ring* r) { return r->g64; }
+
+// General-index ring: moduli / Montgomery constants into DevRing, pass plan and tables into GenDev.
+template <typename W>
+static int build_gen_ring(alch_ring* r, DevRing<W>& d, GenDev<W>& g) {
+    const GenHost& h = r->gh;
+    const int L = r->L;
+    memset(&d, 0, sizeof d);
+    memset(&g, 0, sizeof g);
+    d.L = L; d.logn = 0; d.n = h.n;
+    g.n = h.n; g.npass = h.npass; g.nfact = h.nfact; g.rad = h.rad;
+    for (int i = 0; i < h.npass; ++i) g.pass[i] = h.pass[i];
+    for (int i = 0; i < h.nfact; ++i) g.fact[i] = h.fact[i];
+    g.plain = (!r->has_crt && !r->zdom) ? 1 : 0;
+    u64 maxhalf = 0;
+    for (int j = 0; j < L; ++j) maxhalf = std::max(maxhalf, r->q[j] ? (r->q[j] - 1) / 2 : 0);
+    if (!r->has_crt) {
+        for (int j = 0; j < L; ++j) {
+            d.mod[j].q = (W)r->q[j]; d.mod[j].qni = 0; d.mod[j].r1 = 1; d.mod[j].r2 = 1;
+            // plain inverse of the odd radical (0 when it is not a unit); the integers divide exactly instead
+            u64 inv = 0;
+            if (r->q[j]) {
+                // extended Euclid
+                int64_t r0 = (int64_t)r->q[j], r1 = (int64_t)(h.rad % r->q[j]), t0 = 0, t1 = 1;
+                while (r1) { int64_t k = r0 / r1, r2 = r0 - k * r1, t2 = t0 - k * t1; r0 = r1; r1 = r2; t0 = t1; t1 = t2; }
+                inv = r0 == 1 ? (u64)(((t0 % (int64_t)r->q[j]) + (int64_t)r->q[j]) % (int64_t)r->q[j]) : 0;
+            }
+            g.radinv_m[j] = (W)inv;
+        }
+        return ALCH_OK;
+    }
+    const size_t per_limb = 2 * (size_t)h.block_words + 2 * (size_t)h.n;
+    std::vector<W> all(per_limb * L);
+    HIP_TRY(hipMalloc(&r->gen_tables, all.size() * sizeof(W)));
+    const int bits = 8 * (int)sizeof(W);
+    for (int j = 0; j < L; ++j) {
+        const u64 q = r->q[j];
+        d.mod[j] = make_modp<W>(q);
+        d.dig_off[j] = (W)(((maxhalf + q - 1) / q) * q);
+        const u64 r1 = h_powmod(2, (u64)bits, q);
+        std::vector<u64> f, iv, gc, gci;
+        u64 iscale = 1;
+        if (!gen_tables(h, q, f, iv, gc, gci, iscale)) return fail(ALCH_E_INVALID, "general-index table construction failed");
+        W* base = all.data() + per_limb * j;
+        for (u32 k = 0; k < h.block_words; ++k) { base[k] = (W)h_mulmod(f[k], r1, q); base[h.block_words + k] = (W)h_mulmod(iv[k], r1, q); }
+        for (u32 k = 0; k < h.n; ++k) { base[2 * h.block_words + k] = (W)h_mulmod(gc[k], r1, q); base[2 * h.block_words + h.n + k] = (W)h_mulmod(gci[k], r1, q); }
+        W* dev = reinterpret_cast<W*>(r->gen_tables) + per_limb * j;
+        g.tabf[j] = dev; g.tabi[j] = dev + h.block_words;
+        g.gcrt[j] = dev + 2 * h.block_words; g.gcrt_inv[j] = dev + 2 * h.block_words + h.n;
+        g.iscale_m[j] = (W)h_mulmod(iscale, r1, q);
+        g.radinv_m[j] = (h.rad % q) ? (W)h_mulmod(h_invmod(h.rad % q, q), r1, q) : (W)0;
+    }
+    HIP_TRY(hipMemcpy(r->gen_tables, all.data(), all.size() * sizeof(W), hipMemcpyHostToDevice));
+    return ALCH_OK;
+}
+
+static bool two_power_engine(uint32_t m) { return m >= 32 && (m & (m - 1)) == 0; }
+
+// Argument checks of a general-index ring (or of a ring without CRT basis).  Fills gh; word size out.
+static int validate_gen_args(uint32_t m, int L, const uint64_t* q, bool nocrt, GenHost& gh, int* word_out, bool* zdom_out) {
+    if (!q || L < 1 || L > MAXL) return fail(ALCH_E_INVALID, "alch_ring_create: need 1 <= L <= 8 moduli");
+    if (m < 1) return fail(ALCH_E_INVALID, "cyclotomic index must be >= 1");
+    if (!gen_plan(m, gh)) return fail(ALCH_E_UNSUPPORTED, "cyclotomic index " + std::to_string(m) + ": " + gh.error);
+    bool all32 = true, zdom = false;
+    for (int j = 0; j < L; ++j) {
+        if (nocrt) {
+            if (q[j] == 0) { zdom = true; continue; }
+            if (q[j] < 2 || q[j] >= (1ull << 31)) return fail(ALCH_E_UNSUPPORTED, "a ring without CRT basis takes moduli 2 <= q < 2^31, or 0 for the integers");
+            continue;
+        }
+        if (q[j] >= (1ull << 62)) return fail(ALCH_E_UNSUPPORTED, "modulus must be below 2^62");
+        if (q[j] >= (1ull << 31)) all32 = false;
+        if (q[j] < 3 || !h_is_prime(q[j])) return fail(ALCH_E_NOT_PRIME, "modulus " + std::to_string(q[j]) + " is not prime");
+        if ((q[j] - 1) % m) return fail(ALCH_E_NO_CRT, "modulus " + std::to_string(q[j]) + " is not 1 mod m: no CRT basis (Lol: crtFuncs = Nothing)");
+        for (int i = 0; i < j; ++i)
+            if (q[i] == q[j]) return fail(ALCH_E_INVALID, "RNS moduli must be distinct");
+    }
+    if (zdom) for (int j = 0; j < L; ++j) if (q[j] != 0) return fail(ALCH_E_INVALID, "modulus 0 (the integers) cannot be mixed with other moduli");
+    const int word = (zdom || !all32) ? 8 : 4;
+    if ((size_t)gh.n * (size_t)word > 163840) return fail(ALCH_E_UNSUPPORTED, "ring dimension too large: a limb-polynomial must fit the 160 KiB LDS");
+    *word_out = word;
+    *zdom_out = zdom;
+    return ALCH_OK;
+}
+
 static int validate_ring_args(uint32_t m, int L, const uint64_t* q, int* logn_out, int* word_out) {
     if (!q || L < 1 || L > MAXL) return fail(ALCH_E_INVALID, "alch_ring_create: need 1 <= L <= 8 moduli");
-    if (m < 32 || (m & (m - 1))) return fail(ALCH_E_UNSUPPORTED, "cyclotomic index must be a power of two >= 32");
+    if (!two_power_engine(m)) return fail(ALCH_E_UNSUPPORTED, "internal: not a two-power index >= 32");
     int logn = 0;
     while ((1u << logn) < m / 2) ++logn;
     bool all32 = true;
@@ -406,18 +559,21 @@ static int validate_ring_args(uint32_t m, int L, const uint64_t* q, int* logn_ou
 }
 
 extern "C" int alch_host_root(uint32_t m, uint64_t q, uint64_t* psi, uint64_t* generator) {
-    if (m < 2 || (m & (m - 1)) || q < 3 || !h_is_prime(q)) return fail(ALCH_E_INVALID, "alch_host_root: bad (m, q)");
+    if (m < 1 || q < 3 || !h_is_prime(q)) return fail(ALCH_E_INVALID, "alch_host_root: bad (m, q)");
     if ((q - 1) % m) return fail(ALCH_E_NO_CRT, "q is not 1 mod m");
     if (generator) *generator = h_smallest_generator(q);
     if (psi) *psi = h_root(q, m);
     return ALCH_OK;
 }
 
-extern "C" int alch_ring_create(uint32_t m, int L, const uint64_t* q, alch_ring** out) {
+static int ring_create_impl(uint32_t m, int L, const uint64_t* q, bool nocrt, alch_ring** out) {
     if (!out) return fail(ALCH_E_INVALID, "alch_ring_create: null out");
     *out = nullptr;
     int logn = 0, word = 0;
-    int rc = validate_ring_args(m, L, q, &logn, &word);
+    const bool gen = nocrt || !two_power_engine(m);
+    GenHost gh;
+    bool zdom = false;
+    int rc = gen ? validate_gen_args(m, L, q, nocrt, gh, &word, &zdom) : validate_ring_args(m, L, q, &logn, &word);
     if (rc != ALCH_OK) return rc;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -431,14 +587,18 @@ extern "C" int alch_ring_create(uint32_t m, int L, const uint64_t* q, alch_ring*
 
     alch_ring* r = new alch_ring();
     r->m = m;
-    r->n = m / 2;
+    r->n = gen ? gh.n : m / 2;
     r->logn = logn;
+    r->gen = gen;
+    r->has_crt = !nocrt;
+    r->zdom = zdom;
+    r->gh = gh;
     r->L = L;
     r->word = word;
     for (int j = 0; j < L; ++j) r->q[j] = q[j];
     u64 qmin = ~0ull, qmax = 0;
     for (int j = 0; j < L; ++j) { qmin = std::min(qmin, q[j]); qmax = std::max(qmax, q[j]); }
-    r->balanced = (qmax - 1) / 2 < qmin;
+    r->balanced = qmax > 0 && (qmax - 1) / 2 < qmin;
     r->device = dev;
     hipError_t e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete r; return fail(ALCH_E_HIP, "hipStreamCreate failed"); }
@@ -448,11 +608,16 @@ extern "C" int alch_ring_create(uint32_t m, int L, const uint64_t* q, alch_ring*
         hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming) != hipSuccess) { delete r; return fail(ALCH_E_HIP, "aux stream/event creation failed"); }
     if (hipMalloc((void**)&r->ws_sum, sizeof(u64)) != hipSuccess) { delete r; return fail(ALCH_E_NOMEM, "hipMalloc failed"); }
-    rc = (word == 4) ? build_dev_ring<u32>(r, r->d32) : build_dev_ring<u64>(r, r->d64);
+    if (hipMalloc((void**)&r->d_flag, sizeof(int)) != hipSuccess) { alch_ring_destroy(r); return fail(ALCH_E_NOMEM, "hipMalloc failed"); }
+    if (gen) rc = (word == 4) ? build_gen_ring<u32>(r, r->d32, r->g32) : build_gen_ring<u64>(r, r->d64, r->g64);
+    else rc = (word == 4) ? build_dev_ring<u32>(r, r->d32) : build_dev_ring<u64>(r, r->d64);
     if (rc != ALCH_OK) { alch_ring_destroy(r); return rc; }
     *out = r;
     return ALCH_OK;
 }
+
+extern "C" int alch_ring_create(uint32_t m, int L, const uint64_t* q, alch_ring** out) { return ring_create_impl(m, L, q, false, out); }
+extern "C" int alch_ring_create_nocrt(uint32_t m, int L, const uint64_t* q, alch_ring** out) { return ring_create_impl(m, L, q, true, out); }
 
 extern "C" int alch_ring_destroy(alch_ring* r) {
     if (!r) return ALCH_OK;
@@ -460,6 +625,8 @@ extern "C" int alch_ring_destroy(alch_ring* r) {
     if (r->scratch) { alch_buf* b = r->scratch; r->scratch = nullptr; (void)hipFree(b->dptr); delete b; }
     if (r->stream) (void)hipStreamSynchronize(r->stream);
     if (r->tables) (void)hipFree(r->tables);
+    if (r->gen_tables) (void)hipFree(r->gen_tables);
+    if (r->d_flag) (void)hipFree(r->d_flag);
     if (r->tables_p) (void)hipFree(r->tables_p);
     if (r->ws_digits) (void)hipFree(r->ws_digits);
     if (r->ws_in) (void)hipFree(r->ws_in);
@@ -567,6 +734,26 @@ static int do_crt(alch_ring* r, void* data, size_t first_elem, size_t count, boo
                   hipStream_t stream = nullptr) {
     // src != null: transform src[first_elem ..) into data[first_elem ..) (LDS-resident sizes only)
     if (count == 0) return ALCH_OK;
+    if (!r->has_crt) return fail(ALCH_E_NO_CRT, "this ring has no CRT basis (created with alch_ring_create_nocrt)");
+    if (r->gen) {
+        GenCall<W> g{};
+        g.op = inverse ? GEN_CRTINV : GEN_CRT;
+        g.ring = &dev_ring<W>(r);
+        g.gen = &gen_dev<W>(r);
+        g.stream = stream ? stream : r->stream;
+        g.data = reinterpret_cast<W*>(data);
+        g.src = reinterpret_cast<const W*>(src);
+        const size_t polys = count * (size_t)r->L;
+        for (size_t done = 0; done < polys;) {
+            const size_t now = std::min<size_t>(polys - done, (size_t)1 << 30);
+            g.first_poly = first_elem * (size_t)r->L + done;
+            g.npoly = now;
+            hipError_t e = gen_dispatch(g);
+            if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("general-index crt launch: ") + hipGetErrorString(e));
+            done += now;
+        }
+        return ALCH_OK;
+    }
     NttCall<W> c{};
     c.src = reinterpret_cast<const W*>(src);
     c.op = inverse ? OP_CRTINV : OP_CRT;
@@ -701,6 +888,10 @@ extern "C" int alch_buf_crtinv(alch_buf* b, size_t first, size_t count) { return
 template <typename W, int OP>
 static int do_pointwise(alch_ring* r, void* dst, const void* a, const void* b, size_t count) {
     const size_t words = count * elem_words(r);
+    if (r->n % Vec4<W>::LANES)
+        hipLaunchKernelGGL((k_pointwise_scalar<W, OP>), dim3(ew_grid(words)), dim3(256), 0, r->stream, dev_ring<W>(r),
+                           (W*)dst, (const W*)a, (const W*)b, words);
+    else
     hipLaunchKernelGGL((k_pointwise<W, OP>), dim3(ew_grid(words / Vec4<W>::LANES)), dim3(256), 0, r->stream, dev_ring<W>(r),
                        (W*)dst, (const W*)a, (const W*)b, words);
     HIP_TRY(hipGetLastError());
@@ -713,6 +904,7 @@ static int buf_pointwise(alch_buf* dst, const alch_buf* a, const alch_buf* b, si
     if (count > dst->n_elems || count > a->n_elems || count > b->n_elems) return fail(ALCH_E_INVALID, "count out of bounds");
     alch_ring* r = dst->ring;
     BIND(r);
+    if (!r->has_crt && op == PW_MUL) return fail(ALCH_E_NO_CRT, "pointwise products need the CRT basis; this ring has none");
     if (r->word == 4) {
         if (op == PW_MUL) return do_pointwise<u32, PW_MUL>(r, dst->dptr, a->dptr, b->dptr, count);
         if (op == PW_ADD) return do_pointwise<u32, PW_ADD>(r, dst->dptr, a->dptr, b->dptr, count);
@@ -807,6 +999,7 @@ static int scal_to_mont(const alch_ring* r, const uint64_t* s, int power_of_R, S
 
 template <typename W>
 static int do_scale(alch_ring* r, void* dst, const void* src, size_t count, const uint64_t* s) {
+    if (!r->has_crt) return fail(ALCH_E_UNSUPPORTED, "scalar products are implemented for rings with Montgomery constants (prime moduli) only");
     Scal<W> sm;
     scal_to_mont<W>(r, s, 1, sm);
     const size_t words = count * elem_words(r);
@@ -826,17 +1019,31 @@ extern "C" int alch_scale(alch_ring* r, int64_t* a, const uint64_t* s) {
     return alch_buf_download(t.b, 0, 1, a);
 }
 
-// g_m = 1 for a two-power index: mulG/divG are the identity in every basis.
-static int identity_op(alch_ring* r, int64_t* a) {
+// mulG / divG / l / lInv on one host ring element: staged through the per-ring scratch element.
+static int buf_mulg_divg(alch_buf* b, size_t first, size_t count, int basis, bool divide);
+static int buf_l(alch_buf* b, size_t first, size_t count, bool inverse);
+static int host_g(alch_ring* r, int64_t* a, int basis, int which /* 0 mulG, 1 divG, 2 l, 3 lInv */) {
     if (!r || !a) return fail(ALCH_E_INVALID, "null argument");
-    return ALCH_OK;
+    if (basis == ALCH_BASIS_CRT && !r->has_crt) return fail(ALCH_E_NO_CRT, "this ring has no CRT basis");
+    if (!r->gen || r->gh.rad == 1) return ALCH_OK;                    // two-power index: g = 1, L = identity
+    ScratchBuf s;
+    int rc = scratch_get(r, 1, &s.b);
+    if (rc != ALCH_OK) return rc;
+    if ((rc = alch_buf_upload(s.b, 0, 1, a)) != ALCH_OK) return rc;
+    if (which == 0) rc = buf_mulg_divg(s.b, 0, 1, basis, false);
+    else if (which == 1) rc = buf_mulg_divg(s.b, 0, 1, basis, true);
+    else rc = buf_l(s.b, 0, 1, which == 3);
+    if (rc != ALCH_OK) return rc;                                     // includes ALCH_NOT_DIVISIBLE: the host data stay untouched
+    return alch_buf_download(s.b, 0, 1, a);
 }
-extern "C" int alch_mulg_pow(alch_ring* r, int64_t* a) { return identity_op(r, a); }
-extern "C" int alch_mulg_dec(alch_ring* r, int64_t* a) { return identity_op(r, a); }
-extern "C" int alch_mulg_crt(alch_ring* r, int64_t* a) { return identity_op(r, a); }
-extern "C" int alch_divg_pow(alch_ring* r, int64_t* a) { return identity_op(r, a); }
-extern "C" int alch_divg_dec(alch_ring* r, int64_t* a) { return identity_op(r, a); }
-extern "C" int alch_divg_crt(alch_ring* r, int64_t* a) { return identity_op(r, a); }
+extern "C" int alch_mulg_pow(alch_ring* r, int64_t* a) { return host_g(r, a, ALCH_BASIS_POW, 0); }
+extern "C" int alch_mulg_dec(alch_ring* r, int64_t* a) { return host_g(r, a, ALCH_BASIS_DEC, 0); }
+extern "C" int alch_mulg_crt(alch_ring* r, int64_t* a) { return host_g(r, a, ALCH_BASIS_CRT, 0); }
+extern "C" int alch_divg_pow(alch_ring* r, int64_t* a) { return host_g(r, a, ALCH_BASIS_POW, 1); }
+extern "C" int alch_divg_dec(alch_ring* r, int64_t* a) { return host_g(r, a, ALCH_BASIS_DEC, 1); }
+extern "C" int alch_divg_crt(alch_ring* r, int64_t* a) { return host_g(r, a, ALCH_BASIS_CRT, 1); }
+extern "C" int alch_l(alch_ring* r, int64_t* a) { return host_g(r, a, ALCH_BASIS_POW, 2); }
+extern "C" int alch_linv(alch_ring* r, int64_t* a) { return host_g(r, a, ALCH_BASIS_POW, 3); }
 
 extern "C" int alch_decompose_triv(alch_ring* r, const int64_t* c_pow, int64_t* digits) {
     if (!r || !c_pow || !digits) return fail(ALCH_E_INVALID, "null argument");
@@ -974,6 +1181,115 @@ extern "C" int alch_hint_free(alch_hint* h) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// general index: l / lInv, mulG / divG on device buffers
+// ------------------------------------------------------------------------------------------------------
+// Runs one column operator (kernel_gen.hpp) on elements first, first + stride, ... (count of them) of `data`.
+template <typename W>
+static int do_columns(alch_ring* r, GenOp op, void* data, size_t first, size_t count, size_t stride, hipStream_t stream = nullptr) {
+    if (count == 0) return ALCH_OK;
+    GenCall<W> g{};
+    g.op = op;
+    g.ring = &dev_ring<W>(r);
+    g.gen = &gen_dev<W>(r);
+    g.stream = stream ? stream : r->stream;
+    g.data = reinterpret_cast<W*>(data);
+    g.elem_stride = stride;
+    g.zdom = r->zdom;
+    g.fail_flag = r->d_flag;
+    for (size_t done = 0; done < count;) {
+        const size_t now = std::min<size_t>(count - done, ((size_t)1 << 30) / (size_t)r->L);
+        g.first_poly = first + done * stride;
+        g.npoly = now * (size_t)r->L;
+        hipError_t e = gen_dispatch(g);
+        if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("general-index column launch: ") + hipGetErrorString(e));
+        done += now;
+    }
+    return ALCH_OK;
+}
+
+static int columns(alch_ring* r, GenOp op, void* data, size_t first, size_t count, size_t stride, hipStream_t stream = nullptr) {
+    return r->word == 4 ? do_columns<u32>(r, op, data, first, count, stride, stream) : do_columns<u64>(r, op, data, first, count, stride, stream);
+}
+
+// mulG (divide = false) or divG on elements [first, first + count) of a buffer, basis ALCH_BASIS_*.
+// Returns ALCH_OK, ALCH_NOT_DIVISIBLE (Lol's Nothing; the data are then unspecified) or an error.
+static int buf_mulg_divg(alch_buf* b, size_t first, size_t count, int basis, bool divide) {
+    if (!b) return fail(ALCH_E_INVALID, "null buffer");
+    if (first + count > b->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
+    if (basis != ALCH_BASIS_POW && basis != ALCH_BASIS_DEC && basis != ALCH_BASIS_CRT) return fail(ALCH_E_INVALID, "unknown basis");
+    alch_ring* r = b->ring;
+    BIND(r);
+    if (basis == ALCH_BASIS_CRT && !r->has_crt) return fail(ALCH_E_NO_CRT, "this ring has no CRT basis");
+    if (!r->gen || r->gh.rad == 1 || count == 0) return ALCH_OK;      // g = 1: two-power index
+    if (basis == ALCH_BASIS_CRT) {
+        const size_t words = count * elem_words(r);
+        char* base = reinterpret_cast<char*>(b->dptr) + first * elem_bytes(r);
+        if (r->word == 4) {
+            GTab<u32> gt{};
+            for (int j = 0; j < r->L; ++j) gt.p[j] = divide ? r->g32.gcrt_inv[j] : r->g32.gcrt[j];
+            hipLaunchKernelGGL((k_mul_table<u32>), dim3(ew_grid(words)), dim3(256), 0, r->stream, r->d32, (u32*)base, words, gt);
+        } else {
+            GTab<u64> gt{};
+            for (int j = 0; j < r->L; ++j) gt.p[j] = divide ? r->g64.gcrt_inv[j] : r->g64.gcrt[j];
+            hipLaunchKernelGGL((k_mul_table<u64>), dim3(ew_grid(words)), dim3(256), 0, r->stream, r->d64, (u64*)base, words, gt);
+        }
+        HIP_TRY(hipGetLastError());
+        return ALCH_OK;
+    }
+    if (!divide) return columns(r, basis == ALCH_BASIS_POW ? GEN_MULG_POW : GEN_MULG_DEC, b->dptr, first, count, 1);
+    HIP_TRY(hipMemsetAsync(r->d_flag, 0, sizeof(int), r->stream));
+    int rc = columns(r, basis == ALCH_BASIS_POW ? GEN_DIVG_POW : GEN_DIVG_DEC, b->dptr, first, count, 1);
+    if (rc != ALCH_OK) return rc;
+    int flag = 0;
+    HIP_TRY(hipMemcpyAsync(&flag, r->d_flag, sizeof(int), hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return flag ? ALCH_NOT_DIVISIBLE : ALCH_OK;
+}
+
+extern "C" int alch_buf_mulg(alch_buf* b, size_t first, size_t count, int basis) { return buf_mulg_divg(b, first, count, basis, false); }
+extern "C" int alch_buf_divg(alch_buf* b, size_t first, size_t count, int basis) { return buf_mulg_divg(b, first, count, basis, true); }
+
+static int buf_l(alch_buf* b, size_t first, size_t count, bool inverse) {
+    if (!b) return fail(ALCH_E_INVALID, "null buffer");
+    if (first + count > b->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
+    alch_ring* r = b->ring;
+    BIND(r);
+    if (!r->gen || r->gh.rad == 1) return ALCH_OK;                    // L = identity for a two-power index
+    return columns(r, inverse ? GEN_LINV : GEN_L, b->dptr, first, count, 1);
+}
+extern "C" int alch_buf_l(alch_buf* b, size_t first, size_t count) { return buf_l(b, first, count, false); }
+extern "C" int alch_buf_linv(alch_buf* b, size_t first, size_t count) { return buf_l(b, first, count, true); }
+
+extern "C" int alch_buf_mul_public(alch_buf* dst, const alch_buf* src, const alch_buf* pub, size_t pub_index, size_t count) {
+    if (!dst || !src || !pub) return fail(ALCH_E_INVALID, "null buffer");
+    alch_ring* r = dst->ring;
+    if (src->ring != r || pub->ring != r) return fail(ALCH_E_INVALID, "buffers belong to different rings");
+    if (!r->has_crt) return fail(ALCH_E_NO_CRT, "this ring has no CRT basis");
+    if (count > dst->n_elems || count > src->n_elems || pub_index >= pub->n_elems) return fail(ALCH_E_INVALID, "count out of bounds");
+    BIND(r);
+    const size_t words = count * elem_words(r);
+    const char* pp = reinterpret_cast<const char*>(pub->dptr) + pub_index * elem_bytes(r);
+    if (r->word == 4) hipLaunchKernelGGL((k_mul_bcast<u32>), dim3(ew_grid(words)), dim3(256), 0, r->stream, r->d32, (u32*)dst->dptr, (const u32*)src->dptr, (const u32*)pp, words);
+    else hipLaunchKernelGGL((k_mul_bcast<u64>), dim3(ew_grid(words)), dim3(256), 0, r->stream, r->d64, (u64*)dst->dptr, (const u64*)src->dptr, (const u64*)pp, words);
+    HIP_TRY(hipGetLastError());
+    return ALCH_OK;
+}
+
+extern "C" int alch_buf_add_public(alch_buf* cts, const alch_buf* pub, size_t pub_index, size_t batch) {
+    if (!cts || !pub) return fail(ALCH_E_INVALID, "null buffer");
+    alch_ring* r = cts->ring;
+    if (pub->ring != r) return fail(ALCH_E_INVALID, "buffers belong to different rings");
+    if (2 * batch > cts->n_elems || pub_index >= pub->n_elems) return fail(ALCH_E_INVALID, "count out of bounds");
+    BIND(r);
+    const size_t words = batch * elem_words(r);
+    const char* pp = reinterpret_cast<const char*>(pub->dptr) + pub_index * elem_bytes(r);
+    if (r->word == 4) hipLaunchKernelGGL((k_add_bcast<u32>), dim3(ew_grid(words)), dim3(256), 0, r->stream, r->d32, (u32*)cts->dptr, (const u32*)pp, batch);
+    else hipLaunchKernelGGL((k_add_bcast<u64>), dim3(ew_grid(words)), dim3(256), 0, r->stream, r->d64, (u64*)cts->dptr, (const u64*)pp, batch);
+    HIP_TRY(hipGetLastError());
+    return ALCH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // the hot path
 // ------------------------------------------------------------------------------------------------------
 // rings whose limb-polynomial does not fit one LDS-resident transform (k_crt_split)
@@ -1001,9 +1317,11 @@ static int do_mul_relin_unfused(alch_ring* r, const alch_hint* hint, const void*
     char* c2 = reinterpret_cast<char*>(r->ws_digits);
     char* c2crt = c2 + chunk * eb;                       // CRT-basis copy of c2 (diagonal digits, split rings)
     char* dig = c2crt + chunk * eb;
-    const bool fused_digits = !base2 && split_ring(r);
+    const bool fused_digits = !base2 && (split_ring(r) || r->gen);
     Scal<W> sr2;
     scal_to_mont<W>(r, s_pre, 2, sr2);
+    GTab<W> gt{};
+    if (r->gen) for (int j = 0; j < r->L; ++j) gt.p[j] = r->gh.rad > 1 ? gen_dev<W>(r).gcrt[j] : nullptr;
     const size_t ct_bytes = 2 * eb;
     for (size_t done = 0; done < batch; done += chunk) {
         const size_t now = std::min(chunk, batch - done);
@@ -1012,9 +1330,26 @@ static int do_mul_relin_unfused(alch_ring* r, const alch_hint* hint, const void*
         W* po = reinterpret_cast<W*>(reinterpret_cast<char*>(out) + done * ct_bytes);
         const size_t words = now * elem_words(r);
         hipLaunchKernelGGL((k_tensor_ew<W>), dim3(ew_grid(words)), dim3(256), 0, r->stream, dev_ring<W>(r), pa, pb, po,
-                           (W*)c2, now, sr2, 0, fused_digits ? (W*)c2crt : (W*)nullptr);
+                           (W*)c2, now, sr2, 0, fused_digits ? (W*)c2crt : (W*)nullptr, gt);
         HIP_TRY(hipGetLastError());
         if ((rc = do_crt<W>(r, c2, 0, now, true)) != ALCH_OK) return rc;
+        if (fused_digits && r->gen) {                               // general index: the same, on the pass engine
+            GenCall<W> g{};
+            g.op = GEN_CRT_DIGITS;
+            g.ring = &dev_ring<W>(r);
+            g.gen = &gen_dev<W>(r);
+            g.stream = r->stream;
+            g.src = reinterpret_cast<const W*>(c2);
+            g.data = reinterpret_cast<W*>(dig);
+            g.npoly = now * (size_t)r->L * (size_t)r->L;
+            g.balanced = r->balanced;
+            hipError_t e = gen_dispatch(g);
+            if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("general-index crt_digits launch: ") + hipGetErrorString(e));
+            hipLaunchKernelGGL((k_hint_mac<W>), dim3(ew_grid(words)), dim3(256), 0, r->stream, dev_ring<W>(r), po, (const W*)dig,
+                               (const W*)hint->dptr, now, D, (const W*)c2crt);
+            HIP_TRY(hipGetLastError());
+            continue;
+        }
         if (fused_digits) {                                         // decompose fused into the digit transforms
             NttCall<W> dc{};
             dc.op = OP_CRT_DIGITS;
@@ -1031,7 +1366,7 @@ static int do_mul_relin_unfused(alch_ring* r, const alch_hint* hint, const void*
             HIP_TRY(hipGetLastError());
             continue;
         }
-        if (base2 && !split_ring(r)) {                              // BaseBGad: digits computed in the transforms' loader
+        if (base2 && !split_ring(r) && !r->gen) {                   // BaseBGad: digits computed in the transforms' loader
             NttCall<W> dc{};
             dc.op = OP_CRT_BASE2;
             dc.ring = &dev_ring<W>(r);
@@ -1121,6 +1456,7 @@ static int do_mul_relin(alch_ring* r, const alch_hint* hint, const void* a, cons
 extern "C" int alch_ct_mul_relin(alch_ring* r, const alch_hint* hint, const alch_buf* a, const alch_buf* b, alch_buf* out,
                                  size_t batch, const uint64_t* s_pre, unsigned flags) {
     if (!r || !hint || !a || !b || !out) return fail(ALCH_E_INVALID, "null argument");
+    if (!r->has_crt) return fail(ALCH_E_NO_CRT, "this ring has no CRT basis");
     if (hint->ring != r || a->ring != r || b->ring != r || out->ring != r) return fail(ALCH_E_INVALID, "handles belong to different rings");
     if (batch == 0) return ALCH_OK;
     BIND(r);
@@ -1135,7 +1471,7 @@ extern "C" int alch_ct_mul_relin(alch_ring* r, const alch_hint* hint, const alch
         if ((rc = ensure_ws(&r->ws_in, &r->ws_in_bytes, 2 * bytes)) != ALCH_OK) return rc;
         char* wa = reinterpret_cast<char*>(r->ws_in);
         char* wb = wa + bytes;
-        if (split_ring(r)) {                 // the split transform works in place: copy first
+        if (split_ring(r)) {                 // the split transform works in place: copy first (general-index kernels take src)
             HIP_TRY(hipMemcpyAsync(wa, a->dptr, bytes, hipMemcpyDeviceToDevice, r->stream));
             HIP_TRY(hipMemcpyAsync(wb, b->dptr, bytes, hipMemcpyDeviceToDevice, r->stream));
             rc = r->word == 4 ? do_crt<u32>(r, wa, 0, 4 * batch, false) : do_crt<u64>(r, wa, 0, 4 * batch, false);
@@ -1148,7 +1484,7 @@ extern "C" int alch_ct_mul_relin(alch_ring* r, const alch_hint* hint, const alch
         pa = wa;
         pb = wb;
     }
-    if (hint->gadget == ALCH_GAD_BASE2 || split_ring(r))
+    if (hint->gadget == ALCH_GAD_BASE2 || split_ring(r) || r->gen)
         rc = r->word == 4 ? do_mul_relin_unfused<u32>(r, hint, pa, pb, out->dptr, batch, s_pre)
                           : do_mul_relin_unfused<u64>(r, hint, pa, pb, out->dptr, batch, s_pre);
     else
@@ -1274,6 +1610,9 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
     }
     Scal<W> sr2;
     scal_to_mont<W>(rin, s_eff, 2, sr2);
+    GTab<W> gt{};
+    if (rh->gen) for (int j = 0; j < L; ++j) gt.p[j] = rh->gh.rad > 1 ? gen_dev<W>(rh).gcrt[j] : nullptr;
+    const bool dec_c0 = rh->gen && rh->gh.rad > 1;     // general index: modSwitch rescales c0 on the Dec basis (rescaleDec), c1 on Pow
     // DevRing of the suffix ring that starts at limb u of ring_h
     auto suffix = [&](int u) {
         DevRing<W> d = dev_ring<W>(rh);
@@ -1292,11 +1631,23 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
         const size_t words = now * elem_words(rh);
         // (*) and modSwitch up
         hipLaunchKernelGGL((k_tensor_ew<W>), dim3(ew_grid(words)), dim3(256), 0, rh->stream, dev_ring<W>(rh), pa, pb, (W*)ks,
-                           (W*)c2, now, sr2, dup, (W*)c2crt);
+                           (W*)c2, now, sr2, dup, (W*)c2crt, gt);
         HIP_TRY(hipGetLastError());
         // keySwitchQuadCirc on ring_h
         if ((rc = do_crt<W>(rh, c2, 0, now, true)) != ALCH_OK) return rc;
-        {   // decompose + reduce fused into the digit transforms (k_crt_split_digits)
+        if (rh->gen) {
+            GenCall<W> g{};
+            g.op = GEN_CRT_DIGITS;
+            g.ring = &dev_ring<W>(rh);
+            g.gen = &gen_dev<W>(rh);
+            g.stream = rh->stream;
+            g.src = reinterpret_cast<const W*>(c2);
+            g.data = reinterpret_cast<W*>(dig);
+            g.npoly = now * (size_t)L * (size_t)L;
+            g.balanced = rh->balanced;
+            hipError_t e = gen_dispatch(g);
+            if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("general-index crt_digits launch: ") + hipGetErrorString(e));
+        } else {   // decompose + reduce fused into the digit transforms (k_crt_split_digits)
             NttCall<W> dc{};
             dc.op = OP_CRT_DIGITS;
             dc.ring = &dev_ring<W>(rh);
@@ -1311,8 +1662,9 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
         hipLaunchKernelGGL((k_hint_mac<W>), dim3(ew_grid(words)), dim3(256), 0, rh->stream, dev_ring<W>(rh), (W*)ks, (const W*)dig,
                            (const W*)hint->dptr, now, (u32)L, (const W*)c2crt);
         HIP_TRY(hipGetLastError());
-        // modSwitch down: Pow basis, one limb at a time, then back to the CRT basis on ring_out
+        // modSwitch down: Pow basis (c0: Dec basis for a general index), one limb at a time, then back to the CRT basis on ring_out
         if ((rc = do_crt<W>(rh, ks, 0, 2 * now, true)) != ALCH_OK) return rc;
+        if (dec_c0 && (rc = do_columns<W>(rh, GEN_LINV, ks, 0, now, 2)) != ALCH_OK) return rc;
         char* cur = ks;
         for (int u = 0; u < ddn; ++u) {
             char* nxt = (u + 1 == ddn) ? reinterpret_cast<char*>(out) + done * out_bytes : ((u & 1) ? pong : ping);
@@ -1332,6 +1684,7 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
             HIP_TRY(hipGetLastError());
             cur = nxt;
         }
+        if (dec_c0 && (rc = do_columns<W>(rout, GEN_L, out, 2 * done, now, 2, rh->stream)) != ALCH_OK) return rc;
         if (!pow_out) {
             // crt on ring_out, queued on ring_h's stream (same device tables: ring_out is a suffix of ring_h)
             if ((rc = do_crt<W>(rout, out, 2 * done, 2 * now, false, nullptr, rh->stream)) != ALCH_OK) return rc;
@@ -1374,7 +1727,8 @@ extern "C" int alch_ct_mul_full(const alch_hint* hint, const alch_buf* a, const 
     }
     const bool pow_out = (flags & ALCH_POW_OUT) != 0;
     int rc;
-    if (split_ring(rh))
+    if (!rh->has_crt) return fail(ALCH_E_NO_CRT, "the hint's ring has no CRT basis");
+    if (split_ring(rh) || rh->gen)
         rc = rh->word == 4 ? do_mul_full_unfused<u32>(rh, rin, rout, hint, a->dptr, b->dptr, out->dptr, batch, s_pre, pow_out)
                            : do_mul_full_unfused<u64>(rh, rin, rout, hint, a->dptr, b->dptr, out->dptr, batch, s_pre, pow_out);
     else

@@ -1,0 +1,211 @@
+// Host-side construction of the general-index pass plan and its tables (kernel_gen.hpp runs it).
+// Lol computes the corresponding twiddles in Haskell and hands lol-cpp raw pointers on every call; here they are
+// built once per ring from the documented root rule and stay device-resident.
+#pragma once
+#include <string>
+#include <vector>
+#include "kernel_gen.hpp"
+#include "ring_host.hpp"
+
+namespace alch {
+
+struct GenHost {
+    u32 m = 0, n = 0;
+    int nfact = 0, npass = 0;
+    GenFact fact[GEN_MAXFACT];
+    GenPass pass[GEN_MAXPASS];
+    u32 block_words = 0;      // words of one limb's table block
+    u32 rad = 1;              // product of the odd primes of m
+    std::string error;
+};
+
+inline u64 h_invmod(u64 a, u64 q) { return h_powmod(a % q, q - 2, q); }      // q prime
+
+inline u32 h_digitrev(u32 x, u32 p, int digits) {
+    u32 r = 0;
+    for (int t = 0; t < digits; ++t) { r = r * p + x % p; x /= p; }
+    return r;
+}
+
+// Factor m and lay out the passes.  Returns false (with g.error) for an index this backend does not serve.
+inline bool gen_plan(u32 m, GenHost& g) {
+    g = GenHost();
+    g.m = m;
+    u32 rem = m;
+    for (u32 p = 2; (u64)p * p <= rem; p += (p == 2 ? 1 : 2)) {
+        if (rem % p) continue;
+        if (g.nfact == GEN_MAXFACT) { g.error = "too many prime factors"; return false; }
+        GenFact& f = g.fact[g.nfact++];
+        f.p = (int)p; f.e = 0; f.mp = 1;
+        while (rem % p == 0) { rem /= p; if (f.e++) f.mp *= p; }
+    }
+    if (rem > 1) {
+        if (g.nfact == GEN_MAXFACT) { g.error = "too many prime factors"; return false; }
+        GenFact& f = g.fact[g.nfact++];
+        f.p = (int)rem; f.e = 1; f.mp = 1;
+    }
+    u64 n = 1;
+    for (int l = 0; l < g.nfact; ++l) {
+        GenFact& f = g.fact[l];
+        if (f.p > 13) { g.error = "odd prime factors of the index must be <= 13 (the reference's indices use 3, 5, 7, 13)"; return false; }
+        if (f.p != 2) g.rad *= (u32)f.p;
+        f.dim = (u32)(f.p - 1) * f.mp;
+        n *= f.dim;
+    }
+    if (n > (1u << 20)) { g.error = "ring dimension too large"; return false; }
+    g.n = (u32)n;
+    u32 s = g.n;
+    for (int l = 0; l < g.nfact; ++l) { s /= g.fact[l].dim; g.fact[l].rts = s; }
+    u32 off = 0;
+    auto push = [&](int kind, int r, u32 stride, const GenFact& f, bool mat, bool tw) {
+        if (g.npass == GEN_MAXPASS) { g.error = "too many passes"; return false; }
+        GenPass& P = g.pass[g.npass++];
+        P.kind = kind; P.r = r; P.stride = stride; P.axis_stride = f.rts; P.axis_len = f.dim;
+        P.mat_off = off; if (mat) off += (u32)(r * r);
+        P.tw_off = tw ? off : 0xffffffffu; if (tw) off += f.dim;
+        return true;
+    };
+    for (int l = 0; l < g.nfact; ++l) {
+        const GenFact& f = g.fact[l];
+        if (f.p == 2) {
+            for (u32 t = f.dim / 2; t >= 1; t /= 2)
+                if (!push(GK_RADIX2, 2, t * f.rts, f, false, true)) return false;
+        } else {
+            if (!push(GK_DENSE, f.p - 1, f.mp * f.rts, f, true, false)) return false;
+            for (u32 B = f.mp; B > 1; B /= (u32)f.p)
+                if (!push(GK_DENSE, f.p, (B / (u32)f.p) * f.rts, f, true, true)) return false;
+        }
+    }
+    g.block_words = off ? off : 1;
+    return true;
+}
+
+inline bool h_mat_inv(std::vector<u64>& M, int d, u64 q) {       // in place, Gauss-Jordan mod prime q
+    std::vector<u64> A((size_t)d * 2 * d, 0);
+    for (int i = 0; i < d; ++i) { for (int j = 0; j < d; ++j) A[(size_t)i * 2 * d + j] = M[(size_t)i * d + j]; A[(size_t)i * 2 * d + d + i] = 1; }
+    for (int c = 0; c < d; ++c) {
+        int piv = -1;
+        for (int r = c; r < d; ++r) if (A[(size_t)r * 2 * d + c]) { piv = r; break; }
+        if (piv < 0) return false;
+        for (int j = 0; j < 2 * d; ++j) std::swap(A[(size_t)c * 2 * d + j], A[(size_t)piv * 2 * d + j]);
+        const u64 inv = h_invmod(A[(size_t)c * 2 * d + c], q);
+        for (int j = 0; j < 2 * d; ++j) A[(size_t)c * 2 * d + j] = h_mulmod(A[(size_t)c * 2 * d + j], inv, q);
+        for (int r = 0; r < d; ++r) {
+            if (r == c || !A[(size_t)r * 2 * d + c]) continue;
+            const u64 f = A[(size_t)r * 2 * d + c];
+            for (int j = 0; j < 2 * d; ++j)
+                A[(size_t)r * 2 * d + j] = (A[(size_t)r * 2 * d + j] + q - h_mulmod(f, A[(size_t)c * 2 * d + j], q)) % q;
+        }
+    }
+    for (int i = 0; i < d; ++i) for (int j = 0; j < d; ++j) M[(size_t)i * d + j] = A[(size_t)i * 2 * d + d + j];
+    return true;
+}
+
+// Tables of one limb: forward and inverse blocks (plain residues; the caller converts to Montgomery form), the CRT
+// image of g and its inverse, and crtInv's closing scalar.
+inline bool gen_tables(const GenHost& g, u64 q, std::vector<u64>& fwd, std::vector<u64>& inv, std::vector<u64>& gcrt,
+                       std::vector<u64>& gcrt_inv, u64& iscale) {
+    const u32 m = g.m;
+    const u64 wm = h_powmod(h_smallest_generator(q), (q - 1) / m, q);        // the root rule: omega_m
+    fwd.assign(g.block_words, 0);
+    inv.assign(g.block_words, 0);
+    iscale = 1;
+    int ps = 0;
+    for (int l = 0; l < g.nfact; ++l) {
+        const GenFact& f = g.fact[l];
+        const u32 p = (u32)f.p, pe = f.mp * p;
+        const u64 w = h_powmod(wm, m / pe, q), wi = h_invmod(w, q);        // omega_{p^e}
+        std::vector<u64> pw(pe), pwi(pe);
+        { u64 a = 1, b = 1; for (u32 t = 0; t < pe; ++t) { pw[t] = a; pwi[t] = b; a = h_mulmod(a, w, q); b = h_mulmod(b, wi, q); } }
+        if (p == 2) {
+            // merged-twiddle Cooley-Tukey: stage s (t = dim / 2^(s+1)), group gidx = pos / (2t): the upper element
+            // (pos / t odd) is multiplied by psi^brev(2^s + gidx), psi = omega_{2^e}, brev on log2(dim) bits
+            int lg = 0;
+            while ((1u << lg) < f.dim) ++lg;
+            int s = 0;
+            for (u32 t = f.dim / 2; t >= 1; t /= 2, ++s, ++ps) {
+                const GenPass& P = g.pass[ps];
+                for (u32 pos = 0; pos < f.dim; ++pos) {
+                    const u32 gidx = pos / (2 * t);
+                    const u32 e = h_brev((1u << s) + gidx, lg);
+                    fwd[P.tw_off + pos] = pw[e % pe];
+                    inv[P.tw_off + pos] = pwi[e % pe];
+                }
+                iscale = h_mulmod(iscale, h_invmod(2, q), q);
+            }
+            continue;
+        }
+        {   // CRT_p[i0-1][j0] = omega_p^(i0 j0), omega_p = omega_{p^e}^(m')
+            const GenPass& P = g.pass[ps++];
+            const int d = (int)p - 1;
+            std::vector<u64> M((size_t)d * d);
+            for (int i0 = 1; i0 < (int)p; ++i0)
+                for (int j0 = 0; j0 < d; ++j0) M[(size_t)(i0 - 1) * d + j0] = pw[(size_t)(((u64)i0 * j0) % p) * f.mp];
+            for (size_t k = 0; k < M.size(); ++k) fwd[P.mat_off + k] = M[k];
+            if (!h_mat_inv(M, d, q)) return false;
+            for (size_t k = 0; k < M.size(); ++k) inv[P.mat_off + k] = M[k];
+        }
+        bool first = true;
+        u32 Bprev = 0;
+        for (u32 B = f.mp; B > 1; B /= p, ++ps) {
+            const GenPass& P = g.pass[ps];
+            const u64 pinv = h_invmod(p, q);
+            for (u32 a = 0; a < p; ++a)
+                for (u32 b = 0; b < p; ++b) {
+                    fwd[P.mat_off + a * p + b] = pw[(size_t)((a * b) % p) * f.mp];
+                    inv[P.mat_off + a * p + b] = h_mulmod(pwi[(size_t)((a * b) % p) * f.mp], pinv, q);
+                }
+            // twiddles in front of this stage, by axis position a = (i0 - 1) m' + j1:
+            //   first stage: T = omega_{p^e}^(i0 j1);  later stages: the previous stage's omega_{Bprev}^(fq off)
+            for (u32 i0 = 1; i0 < p; ++i0)
+                for (u32 j1 = 0; j1 < f.mp; ++j1) {
+                    u32 e;
+                    if (first) e = (u32)(((u64)i0 * j1) % pe);
+                    else {
+                        const u32 sub = Bprev / p, within = j1 % Bprev;
+                        const u32 fq = within / sub, offv = within % sub;
+                        e = (u32)(((u64)p * (f.mp / Bprev) * fq * offv) % pe);
+                    }
+                    fwd[P.tw_off + (i0 - 1) * f.mp + j1] = pw[e];
+                    inv[P.tw_off + (i0 - 1) * f.mp + j1] = pwi[e];
+                }
+            first = false;
+            Bprev = B;
+        }
+    }
+    // CRT image of g = prod_{odd p | m} (1 - zeta_p): slot s holds prod (1 - omega_p^u(s))
+    gcrt.assign(g.n, 1);
+    gcrt_inv.assign(g.n, 1);
+    for (u32 sl = 0; sl < g.n; ++sl) {
+        u64 u = 0, mod = 1;
+        for (int l = 0; l < g.nfact; ++l) {
+            const GenFact& f = g.fact[l];
+            const u64 ml = (u64)f.mp * f.p;
+            const u32 s = (sl / f.rts) % f.dim;
+            const u64 i0 = s / f.mp + 1, i1 = h_digitrev(s % f.mp, (u32)f.p, f.e - 1);
+            const u64 ul = (i0 + (u64)f.p * i1) % ml;
+            u64 t = ul;
+            if (mod > 1) {
+                // t = (ul - u) / mod  (mod ml); mod and ml are coprime
+                u64 minv = 1;
+                for (u64 c = 1; c < ml; ++c) if ((mod % ml) * c % ml == 1) { minv = c; break; }
+                t = ((ul + ml - u % ml) % ml) * minv % ml;
+            }
+            u += mod * t;
+            mod *= ml;
+        }
+        u %= m;
+        u64 v = 1;
+        for (int l = 0; l < g.nfact; ++l) {
+            const u32 p = (u32)g.fact[l].p;
+            if (p == 2) continue;
+            const u64 wp = h_powmod(wm, ((u64)(m / p) * u) % m, q);
+            v = h_mulmod(v, (1 + q - wp) % q, q);
+        }
+        gcrt[sl] = v;
+        gcrt_inv[sl] = h_invmod(v, q);
+    }
+    return true;
+}
+
+}  // namespace alch

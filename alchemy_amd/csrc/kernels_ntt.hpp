@@ -21,7 +21,8 @@ constexpr int MAXL = 8;
 template <typename W>
 struct DevRing {
     int L;
-    int logn;
+    int logn;            // two-power rings: log2 n; general-index rings: 0
+    u32 n;               // ring dimension phi(m)
     ModP<W> mod[MAXL];
     W ninv_m[MAXL];      // n^-1 in Montgomery form
     W w1ninv_m[MAXL];    // tw_inv[1] * n^-1 in Montgomery form

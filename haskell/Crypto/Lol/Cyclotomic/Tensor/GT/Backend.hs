@@ -28,6 +28,7 @@ foreign import ccall unsafe "alch_version"             c_version         :: IO W
 
 -- ring context: one per (index m, modulus list); q ≡ 1 (mod m) or ALCH_E_NO_CRT (Lol: crtFuncs = Nothing)
 foreign import ccall safe   "alch_ring_create"         c_ringCreate      :: Word32 -> CInt -> Ptr Word64 -> Ptr (Ptr AlchRing) -> IO CInt
+foreign import ccall safe   "alch_ring_create_nocrt"   c_ringCreateNoCRT :: Word32 -> CInt -> Ptr Word64 -> Ptr (Ptr AlchRing) -> IO CInt
 foreign import ccall safe   "alch_ring_destroy"        c_ringDestroy     :: Ptr AlchRing -> IO CInt
 foreign import ccall unsafe "alch_host_root"           c_hostRoot        :: Word32 -> Word64 -> Ptr Word64 -> Ptr Word64 -> IO CInt
 foreign import ccall unsafe "alch_ring_n"              c_ringN           :: Ptr AlchRing -> Ptr Word32 -> Ptr CInt -> Ptr CInt -> IO CInt
@@ -45,13 +46,15 @@ foreign import ccall safe   "alch_add"                 c_add             :: Ptr 
 foreign import ccall safe   "alch_sub"                 c_sub             :: Ptr AlchRing -> Ptr Int64 -> Ptr Int64 -> IO CInt
 foreign import ccall safe   "alch_scale"               c_scale           :: Ptr AlchRing -> Ptr Int64 -> Ptr Word64 -> IO CInt
 
--- mulGPow/Dec/CRT, divGPow/Dec/CRT
-foreign import ccall unsafe "alch_mulg_pow"            c_mulGPow         :: Ptr AlchRing -> Ptr Int64 -> IO CInt
-foreign import ccall unsafe "alch_mulg_dec"            c_mulGDec         :: Ptr AlchRing -> Ptr Int64 -> IO CInt
-foreign import ccall unsafe "alch_mulg_crt"            c_mulGCRT         :: Ptr AlchRing -> Ptr Int64 -> IO CInt
-foreign import ccall unsafe "alch_divg_pow"            c_divGPow         :: Ptr AlchRing -> Ptr Int64 -> IO CInt
-foreign import ccall unsafe "alch_divg_dec"            c_divGDec         :: Ptr AlchRing -> Ptr Int64 -> IO CInt
-foreign import ccall unsafe "alch_divg_crt"            c_divGCRT         :: Ptr AlchRing -> Ptr Int64 -> IO CInt
+-- mulGPow/Dec/CRT, divGPow/Dec/CRT (divG: 1 = Nothing), l / lInv
+foreign import ccall safe   "alch_mulg_pow"            c_mulGPow         :: Ptr AlchRing -> Ptr Int64 -> IO CInt
+foreign import ccall safe   "alch_mulg_dec"            c_mulGDec         :: Ptr AlchRing -> Ptr Int64 -> IO CInt
+foreign import ccall safe   "alch_mulg_crt"            c_mulGCRT         :: Ptr AlchRing -> Ptr Int64 -> IO CInt
+foreign import ccall safe   "alch_divg_pow"            c_divGPow         :: Ptr AlchRing -> Ptr Int64 -> IO CInt
+foreign import ccall safe   "alch_divg_dec"            c_divGDec         :: Ptr AlchRing -> Ptr Int64 -> IO CInt
+foreign import ccall safe   "alch_divg_crt"            c_divGCRT         :: Ptr AlchRing -> Ptr Int64 -> IO CInt
+foreign import ccall safe   "alch_l"                   c_l               :: Ptr AlchRing -> Ptr Int64 -> IO CInt
+foreign import ccall safe   "alch_linv"                c_lInv            :: Ptr AlchRing -> Ptr Int64 -> IO CInt
 
 -- decompose + reduce (Gadget / Decompose instances of TrivGad and BaseBGad 2)
 foreign import ccall safe   "alch_decompose_triv"      c_decomposeTriv   :: Ptr AlchRing -> Ptr Int64 -> Ptr Int64 -> IO CInt
@@ -72,6 +75,12 @@ foreign import ccall safe   "alch_buf_add"             c_bufAdd          :: Ptr 
 foreign import ccall safe   "alch_buf_sub"             c_bufSub          :: Ptr AlchBuf -> Ptr AlchBuf -> Ptr AlchBuf -> CSize -> IO CInt
 foreign import ccall safe   "alch_buf_scale"           c_bufScale        :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> Ptr Word64 -> IO CInt
 foreign import ccall safe   "alch_buf_decompose_triv"  c_bufDecomposeTriv :: Ptr AlchBuf -> CSize -> Ptr AlchBuf -> CSize -> IO CInt
+foreign import ccall safe   "alch_buf_l"               c_bufL            :: Ptr AlchBuf -> CSize -> CSize -> IO CInt
+foreign import ccall safe   "alch_buf_linv"            c_bufLInv         :: Ptr AlchBuf -> CSize -> CSize -> IO CInt
+foreign import ccall safe   "alch_buf_mulg"            c_bufMulG         :: Ptr AlchBuf -> CSize -> CSize -> CInt -> IO CInt
+foreign import ccall safe   "alch_buf_divg"            c_bufDivG         :: Ptr AlchBuf -> CSize -> CSize -> CInt -> IO CInt
+foreign import ccall safe   "alch_buf_mul_public"      c_bufMulPublic    :: Ptr AlchBuf -> Ptr AlchBuf -> Ptr AlchBuf -> CSize -> CSize -> IO CInt
+foreign import ccall safe   "alch_buf_add_public"      c_bufAddPublic    :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> CSize -> IO CInt
 foreign import ccall safe   "alch_buf_checksum"        c_bufChecksum     :: Ptr AlchBuf -> CSize -> CSize -> Ptr Word64 -> IO CInt
 foreign import ccall safe   "alch_buf_rescale_drop0"   c_bufRescaleDrop0 :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> IO CInt
 foreign import ccall safe   "alch_buf_rescale_add0"    c_bufRescaleAdd0  :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> IO CInt

@@ -12,17 +12,24 @@
  * Conventions
  *   - plain C: no C++ types, no exceptions across the ABI.  Every function returns an int status
  *     (ALCH_OK == 0, negative == error); alch_last_error() gives a thread-local message.
- *   - ring R'_q = Z_q[X]/(X^n+1): cyclotomic index m = 2n a power of two, n >= 16; RNS limbs
- *     q_0..q_{L-1}, limb 0 = outermost component of Lol's nested pair
- *     (Crypto/Alchemy/Interpreter/PT2CT/Noise.hs:82-89,130).
+ *   - ring R'_q = Z_q[zeta_m], ANY cyclotomic index m whose odd prime factors are <= 13 (the reference's
+ *     ciphertext indices are H0' = F11648 .. H5' = F20475 = 2^a 3^b 5^c 7 13, examples/Common.hs:38-54) with
+ *     n = phi(m) <= 40960; for m = 2n a power of two that is Z_q[X]/(X^n+1).  RNS limbs q_0..q_{L-1}, limb 0 =
+ *     outermost component of Lol's nested pair (Crypto/Alchemy/Interpreter/PT2CT/Noise.hs:82-89,130).
  *   - HOST buffers use Lol's layout: int64_t, tuple-interleaved ("AoS"): coefficient k of limb j of
  *     one ring element at data[k*L + j], residues in [0, q_j)   (ZqBasic q Int64, examples/Common.hs:35).
  *     Host buffers are caller-owned, modified in place, never retained.
  *   - DEVICE buffers (alch_buf) are library-owned handles holding ring elements limb-major in HBM:
  *     element e, limb j, coefficient k at word (e*L + j)*n + k; 32-bit words when every q_j < 2^31
  *     (all of ALCHEMY's moduli, PT2CT.hs:137-139,283-285), 64-bit words otherwise (q < 2^62).
- *   - Pow basis = coefficient vector; Dec basis == Pow basis for a two-power index; CRT basis slot k
- *     holds a(psi^(2*brev(k)+1)), psi = g^((q-1)/m), g = smallest generator of Z_q^*.
+ *   - bases (toolkit / Lol definitions; m = prod_l p_l^e_l, primes ascending, m_l = p_l^e_l, m'_l = m_l/p_l):
+ *       Pow  p_j = prod_l zeta_{m_l}^{j_l}, j_l in [phi(m_l)], zeta_{m_l} = zeta_m^(m/m_l); linear index mixed radix,
+ *            first factor outermost (for a two-power index: the coefficient vector)
+ *       Dec  d^T = p^T L, L = kron_l (L_{p_l} (x) I_{m'_l}), L_p = lower-triangular all-ones; == Pow for a two-power index
+ *       CRT  slot (s_1..s_k) holds sigma_u(x), sigma_u: zeta_m -> omega_m^u, omega_m = gen^((q-1)/m), gen = smallest
+ *            generator of Z_q^*, u = i0 + p i1 (mod m_l) where s_l = (i0 - 1) m'_l + digitrev_p(i1);
+ *            for a two-power index: slot k holds a(psi^(2*brev(k)+1)), psi = omega_m.
+ *       g    = prod_{odd p | m} (1 - zeta_p)   (1 for a two-power index)
  *   - all work is queued on the ring's HIP stream; alch_sync() waits for it.  Entry points are
  *     re-entrant across rings; one ring must not be driven from two threads at once.  A ring is bound to the
  *     HIP device that was current when it was created; every entry point makes that device current for the
@@ -44,11 +51,16 @@ extern "C" {
 #define ALCH_E_INVALID (-1)        /* bad argument (null, size, basis) */
 #define ALCH_E_NOT_PRIME (-2)      /* a modulus is not prime */
 #define ALCH_E_NO_CRT (-3)         /* q != 1 mod m: Lol's crtFuncs returns Nothing */
-#define ALCH_E_UNSUPPORTED (-4)    /* index not a power of two, n < 16, q too large */
+#define ALCH_E_UNSUPPORTED (-4)    /* index with a prime factor > 13, ring too large for LDS, q too large */
 #define ALCH_E_NO_DEVICE (-5)      /* no gfx950 device / HIP runtime error at init */
 #define ALCH_E_HIP (-6)            /* HIP runtime error (message in alch_last_error) */
 #define ALCH_E_NOMEM (-7)
-#define ALCH_NOT_DIVISIBLE 1       /* divG family: Lol's Nothing (never happens for a two-power index) */
+#define ALCH_NOT_DIVISIBLE 1       /* divG family: Lol's Nothing */
+
+/* bases of alch_buf_mulg / alch_buf_divg */
+#define ALCH_BASIS_POW 0
+#define ALCH_BASIS_DEC 1
+#define ALCH_BASIS_CRT 2
 
 typedef struct alch_ring alch_ring;
 typedef struct alch_buf alch_buf;
@@ -71,11 +83,19 @@ uint32_t alch_version(void);
  * (index, modulus-list) type, i.e. once per `Cyc t m' zq` instance (PT2CT.hs:251-254).
  * m = cyclotomic index (2n).  Validates q prime and q == 1 mod m (else ALCH_E_NO_CRT, the CRTrans
  * failure of Lol's crtFuncs), builds device-resident twiddle tables with the root rule above.
- * Sizes: 32 <= m <= 2^17 (n <= 2^16) when every q < 2^31, m <= 2^16 (n <= 2^15) otherwise.  The largest size
+ * Two-power m: 32 <= m <= 2^17 (n <= 2^16) when every q < 2^31, m <= 2^16 (n <= 2^15) otherwise.  The largest size
  * of each word runs its transforms as two LDS-resident halves and the key switch unfused; the fused
  * kernels of alch_ct_mul_relin / alch_ct_mul_full cover n <= 2^15 (32-bit) / 2^14 (64-bit); at the largest size both
- * entry points run the same operations composed from element-wise kernels and batched transforms. */
+ * entry points run the same operations composed from element-wise kernels and batched transforms.
+ * Any other m (composite, or two-power below 32): the pass engine of kernel_gen.hpp -- every transform LDS-resident
+ * (phi(m) * word <= 160 KiB), the key switch composed from the element-wise tensor product (with mulG), batched
+ * crtInv, digit transforms with decompose + reduce in their loader, and the hint inner product. */
 int alch_ring_create(uint32_t m, int L, const uint64_t *q, alch_ring **out);
+/* A ring WITHOUT CRT basis: Lol's Tensor over a modulus whose crtFuncs is Nothing -- a plaintext ring Z_p (any
+ * 2 <= q < 2^31, e.g. the Z_{2^e} of examples/Common.hs:32) or, with q = 0, the integers (Tensor t m Int64: what
+ * Lol lifts to in decrypt, PT2CT.hs:91-99).  Serves the Pow / Dec operations: l, lInv, mulG, divG (Pow, Dec), add,
+ * sub, upload / download; everything that needs the CRT basis returns ALCH_E_NO_CRT. */
+int alch_ring_create_nocrt(uint32_t m, int L, const uint64_t *q, alch_ring **out);
 int alch_ring_destroy(alch_ring *ring);
 /* Host-only (no GPU needed): the root-rule constants of one modulus, for cross-checking against the
  * oracle: psi (primitive m-th root), and the smallest generator. */
@@ -106,14 +126,22 @@ int alch_sub(alch_ring *ring, int64_t *a, const int64_t *b);
 /* Multiply limb j by scalar s[j] (scalarPow/scalarCRT product: toLSD/toMSD of SymmSHE). */
 int alch_scale(alch_ring *ring, int64_t *a, const uint64_t *s);
 /* mulG and divG families (Tensor mulGPow/mulGDec/mulGCRT, divGPow/divGDec/divGCRT; used by (*) on CT, which
- * applies mulG to every product coefficient).  g_m = 1 for a two-power index: identity; divG returns
- * ALCH_OK (Lol's Just) and never ALCH_NOT_DIVISIBLE. */
+ * applies mulG to every product coefficient, Eval.hs:65-67, and by decrypt, PT2CT.hs:91-99).  g = prod over the odd
+ * primes p of m of (1 - zeta_p); identity for a two-power index.  divG returns ALCH_OK (Lol's Just) or
+ * ALCH_NOT_DIVISIBLE (Lol's Nothing; the data are left untouched): as in lol-cpp, a Z_q limb fails when the odd
+ * radical of m is not a unit mod q, an integer ring (alch_ring_create_nocrt with q = 0) when some coefficient of
+ * (rad/g) a is not divisible by the radical.  divGCRT never fails. */
 int alch_mulg_pow(alch_ring *ring, int64_t *a);
 int alch_mulg_dec(alch_ring *ring, int64_t *a);
 int alch_mulg_crt(alch_ring *ring, int64_t *a);
 int alch_divg_pow(alch_ring *ring, int64_t *a);
 int alch_divg_dec(alch_ring *ring, int64_t *a);
 int alch_divg_crt(alch_ring *ring, int64_t *a);
+/* Tensor l / lInv: decoding-basis coefficients -> powerful-basis coefficients and back (prefix sums / differences
+ * along every odd-prime axis); what Cyc's toPow / toDec run, e.g. under modSwitch's rescaleDec (Eval.hs:130) and
+ * decrypt's liftDec.  Identity for a two-power index. */
+int alch_l(alch_ring *ring, int64_t *a);
+int alch_linv(alch_ring *ring, int64_t *a);
 /* Lol `decompose` for TrivGad followed by `reduce` of every digit (the first half of `switch` in
  * keySwitchQuadCirc, Eval.hs:133): c in the Pow basis; digits = L consecutive ring elements (each
  * n*L int64, Pow basis), digit i = centred lift of limb i reduced into every limb. */
@@ -146,6 +174,19 @@ int alch_buf_add(alch_buf *dst, const alch_buf *a, const alch_buf *b, size_t cou
 int alch_buf_sub(alch_buf *dst, const alch_buf *a, const alch_buf *b, size_t count);
 /* dst = src * s_j per limb (toLSD / toMSD scalars of SymmSHE, any basis); dst may equal src. */
 int alch_buf_scale(alch_buf *dst, const alch_buf *src, size_t count, const uint64_t *s);
+/* Batched l / lInv / mulG / divG on elements [first, first+count); basis = ALCH_BASIS_*.  alch_buf_divg returns
+ * ALCH_NOT_DIVISIBLE when any element of the range is not divisible (the range is then unspecified). */
+int alch_buf_l(alch_buf *buf, size_t first, size_t count);
+int alch_buf_linv(alch_buf *buf, size_t first, size_t count);
+int alch_buf_mulg(alch_buf *buf, size_t first, size_t count, int basis);
+int alch_buf_divg(alch_buf *buf, size_t first, size_t count, int basis);
+/* SymmSHE mulPublic (Crypto/Alchemy/Interpreter/Eval.hs:132; the first op of homomRLWR, examples/HomomRLWR.hs:52-59):
+ * dst[e] = src[e] * pub[pub_index] for e < count, CRT basis (every component of every ciphertext times one public
+ * ring element, already embedded / reduced into this ring by the host). */
+int alch_buf_mul_public(alch_buf *dst, const alch_buf *src, const alch_buf *pub, size_t pub_index, size_t count);
+/* SymmSHE addPublic (Eval.hs:131; PT2CT.hs:114-118 uses it for constants): cts[2b] += pub[pub_index] for b < batch
+ * (c0 of every linear ciphertext; `pub` = the public element times l^-1 g^k, embedded, in the basis of cts). */
+int alch_buf_add_public(alch_buf *cts, const alch_buf *pub, size_t pub_index, size_t batch);
 /* Device-resident Lol `decompose` (TrivGad) + `reduce`: element `src_index` of src (Pow basis) -> L digit
  * elements written to dst[dst_first .. dst_first+L) (Pow basis). */
 int alch_buf_decompose_triv(const alch_buf *src, size_t src_index, alch_buf *dst, size_t dst_first);

@@ -92,3 +92,52 @@ def oracle_mul_relin_base2(oracle_lib, n, qs, hint_crt, a0, a1, b0, b1, s_pre=No
         c0 = o.add(c0, o.mul(dc, hint_crt[2 * i]))
         c1 = o.add(c1, o.mul(dc, hint_crt[2 * i + 1]))
     return (o.crtinv(c0), o.crtinv(c1)) if pow_out else (c0, c1)
+
+
+def primes_1_mod(m, count, lo=0):
+    """The first `count` primes q > lo with q = 1 (mod m)."""
+    from oracle.model import is_prime
+    out, q = [], (lo // m) * m + 1
+    while len(out) < count:
+        if q > max(lo, 2) and is_prime(q):
+            out.append(q)
+        q += m
+    return out
+
+
+def oracle_full_mul_general(oracle_lib, m, qs_h, l_in, l_out, hint_crt, a0, a1, b0, b1, s_pre=None, pow_out=False):
+    """PT2CT's whole mul_ on a GENERAL cyclotomic index, composed from the general C restatement's primitives:
+    (*) with mulG on every product coefficient (Eval.hs:65-67), modSwitch up, keySwitchQuadCirc (Eval.hs:133),
+    modSwitch down with rescaleDec on c0 and rescalePow on c1 (Eval.hs:130).  Same layout rules as oracle_full_mul."""
+    L = len(qs_h)
+    dup = L - l_in
+    o_in, o_h = oracle_lib.GenRing(m, qs_h[dup:]), oracle_lib.GenRing(m, qs_h)
+    n = o_h.n
+    s = list(s_pre) if s_pre is not None else [1] * l_in
+    c = [o_in.mul(a0, b0), o_in.add(o_in.mul(a0, b1), o_in.mul(a1, b0)), o_in.mul(a1, b1)]
+    c = [o_in.scale(o_in.mulg_crt(x), s) for x in c]
+    mult = 1
+    for q in qs_h[:dup]:
+        mult *= q
+    up = []
+    for x in c:
+        scaled = o_in.scale(x, [mult % q for q in qs_h[dup:]])
+        up.append(np.ascontiguousarray(np.concatenate([np.zeros((n, dup), dtype=np.int64), scaled], axis=1)))
+    digs = o_h.decompose_triv(o_h.crtinv(up[2]))
+    ks = [up[0], up[1]]
+    for i, d in enumerate(digs):
+        dc = o_h.crt(d)
+        ks[0] = o_h.add(ks[0], o_h.mul(dc, hint_crt[2 * i]))
+        ks[1] = o_h.add(ks[1], o_h.mul(dc, hint_crt[2 * i + 1]))
+    out = []
+    for comp, x in enumerate(ks):
+        cur = o_h.crtinv(x)
+        if comp == 0:
+            cur = o_h.linv(cur)                                   # c0: rescaleDec
+        for k in range(L, l_out, -1):
+            cur = oracle_lib.GenRing(m, qs_h[L - k:]).rescale_drop0(cur)
+        o_out = oracle_lib.GenRing(m, qs_h[L - l_out:])
+        if comp == 0:
+            cur = o_out.l(cur)
+        out.append(cur if pow_out else o_out.crt(cur))
+    return out[0], out[1]

@@ -82,8 +82,9 @@ def test_ring_create_fails_loudly_without_gpu():
 def test_ring_argument_validation_precedes_device_probe():
     for args, code in [((512, [268440579]), capi.ALCH_E_NOT_PRIME),          # composite
                        ((1 << 16, [ARITH_QS[1]]), capi.ALCH_E_NO_CRT),        # q != 1 mod m
-                       ((48, [ARITH_QS[0]]), capi.ALCH_E_UNSUPPORTED),        # index not a power of two
-                       ((16, [ARITH_QS[0]]), capi.ALCH_E_UNSUPPORTED),        # n < 16
+                       ((48, [ARITH_QS[1]]), capi.ALCH_E_NO_CRT),             # composite index, q != 1 mod 3
+                       ((4 * 17, [ARITH_QS[0]]), capi.ALCH_E_UNSUPPORTED),    # odd prime factor above 13
+                       ((3 * 5 * 7 * 11 * 13 * 64, [960961]), capi.ALCH_E_UNSUPPORTED),  # phi = 184320: a limb-polynomial exceeds the LDS
                        ((1 << 17, [CFG3_QS[3]]), capi.ALCH_E_NO_CRT),         # 2145976321 is 1 mod 2^16 only
                        ((1 << 18, [2146959361]), capi.ALCH_E_UNSUPPORTED),    # n = 2^17: beyond the split transform (32-bit words)
                        ((1 << 17, [1152921504606584833]), capi.ALCH_E_UNSUPPORTED),   # n = 2^16 with 64-bit words
