@@ -408,3 +408,164 @@ def rescale_down_basis(x, idx: Index, qs, drop: int, basis: str):
     dec = [linv_def(xl, idx, q) for xl, q in zip(x, qs)]
     y = rescale_down(dec, qs, drop)
     return [l_def(yl, idx, q) for yl, q in zip(y, qs[drop:])]
+
+
+# --------------------------------------------------------------------------------------
+# SymmSHE on a general index (Lol's CT with the g-power k live): the semantic pin of every convention above --
+# decrypt(modSwitch(keySwitchQuadCirc hint (modSwitch (a * b)))) must equal the product of the plaintexts.
+# Call sites: encrypt PT2CT.hs:84-87, (*) Eval.hs:65-67, modSwitch Eval.hs:130, keySwitchQuadCirc Eval.hs:133,
+# ksQuadCircHint KeysHints.hs:101-113, decrypt PT2CT.hs:91-99, addPublic / mulPublic Eval.hs:131-132,
+# modSwitchPT Eval.hs:129.
+# --------------------------------------------------------------------------------------
+import random
+from dataclasses import dataclass
+
+from .model import LSD, MSD, _crt_lift, _qprod, decompose_triv, gadget_triv, rescale_up
+
+
+@dataclass
+class GCT:
+    """CT enc k l c over R'_q, q = prod qs; c = list of RNS ring elements in the Pow basis of the index `big`."""
+    enc: str
+    k: int
+    l: int
+    c: list
+    p: int
+    qs: list
+    big: Index
+    small: Index
+
+
+def _small_dec(n: int, bound: int, rng: random.Random) -> List[int]:
+    return [rng.randint(-bound, bound) for _ in range(n)]
+
+
+def g_gen_sk(big: Index, rng: random.Random, bound: int = 2) -> List[int]:
+    """Secret key: short in the decoding basis (Lol: genSK = rounded tweaked Gaussian, a Dec-basis object); returned as
+    integer Pow coefficients."""
+    return l_def(_small_dec(big.n, bound, rng), big, None)
+
+
+def _rns_scale(x, s, qs):
+    return [[v * sj % q for v in xl] for xl, sj, q in zip(x, s, qs)]
+
+
+def g_to_lsd(ct: GCT) -> GCT:
+    if ct.enc == LSD:
+        return ct
+    Q = _qprod(ct.qs)
+    return GCT(LSD, ct.k, ct.l * pow((-Q) % ct.p, -1, ct.p) % ct.p, [_rns_scale(x, [ct.p % q for q in ct.qs], ct.qs) for x in ct.c],
+               ct.p, ct.qs, ct.big, ct.small)
+
+
+def g_to_msd(ct: GCT) -> GCT:
+    if ct.enc == MSD:
+        return ct
+    Q = _qprod(ct.qs)
+    return GCT(MSD, ct.k, ct.l * ((-Q) % ct.p) % ct.p, [_rns_scale(x, [pow(ct.p, -1, q) for q in ct.qs], ct.qs) for x in ct.c],
+               ct.p, ct.qs, ct.big, ct.small)
+
+
+def g_encrypt(sk, pt_pow, small: Index, big: Index, p: int, qs, rng: random.Random, bound: int = 2) -> GCT:
+    """LSD encryption: c0 + c1 s = e, e = embed(pt) (mod p R'), e short in the decoding basis (Lol: errorCoset)."""
+    emb = embed_pow([x % p for x in pt_pow], small, big)
+    ptdec = [centred(x, p) for x in linv_def(emb, big, p)]
+    e = l_def([v + p * t for v, t in zip(ptdec, _small_dec(big.n, bound, rng))], big, None)
+    c1 = [[rng.randrange(q) for _ in range(big.n)] for q in qs]
+    c0 = [[(ev - v) % q for ev, v in zip(e, ring_mul_def(c1l, sk, big, q))] for c1l, q in zip(c1, qs)]
+    return GCT(LSD, 0, 1, [c0, c1], p, list(qs), big, small)
+
+
+def g_ct_mul(a: GCT, b: GCT) -> GCT:
+    """(*): both to LSD, product of the polynomials in S, mulG on every coefficient, k = k1 + k2 + 1, l = l1 l2."""
+    a, b = g_to_lsd(a), g_to_lsd(b)
+    qs, big = a.qs, a.big
+    out = [[[0] * big.n for _ in qs] for _ in range(len(a.c) + len(b.c) - 1)]
+    for i, x in enumerate(a.c):
+        for j, y in enumerate(b.c):
+            pr = rns_ring_mul(x, y, big, qs)
+            out[i + j] = [[(u + v) % q for u, v in zip(ol, pl)] for ol, pl, q in zip(out[i + j], pr, qs)]
+    out = [[mulg_pow_def(cl, big, q) for cl, q in zip(c, qs)] for c in out]
+    return GCT(LSD, a.k + b.k + 1, a.l * b.l % a.p, out, a.p, qs, big, a.small)
+
+
+def g_ks_hint(sk, big: Index, qs, rng: random.Random, bound: int = 2):
+    """TrivGad KSQuadCircHint: h0_i + h1_i s = g_i s^2 + e_i."""
+    hint = []
+    for g in gadget_triv(qs):
+        e = l_def(_small_dec(big.n, bound, rng), big, None)
+        h1 = [[rng.randrange(q) for _ in range(big.n)] for q in qs]
+        h0 = []
+        for j, q in enumerate(qs):
+            s2 = ring_mul_def(sk, sk, big, q)
+            h1s = ring_mul_def(h1[j], sk, big, q)
+            h0.append([(g[j] * a + ev - b) % q for a, ev, b in zip(s2, e, h1s)])
+        hint.append([h0, h1])
+    return hint
+
+
+def g_key_switch(hint, ct: GCT) -> GCT:
+    ct = g_to_msd(ct)
+    assert len(ct.c) == 3
+    qs, big = ct.qs, ct.big
+    c0, c1 = ct.c[0], ct.c[1]
+    for d, (h0, h1) in zip(decompose_triv(ct.c[2], qs), hint):
+        dr = [[v % q for v in d] for q in qs]
+        c0 = [[(u + v) % q for u, v in zip(cl, pl)] for cl, pl, q in zip(c0, rns_ring_mul(dr, h0, big, qs), qs)]
+        c1 = [[(u + v) % q for u, v in zip(cl, pl)] for cl, pl, q in zip(c1, rns_ring_mul(dr, h1, big, qs), qs)]
+    return GCT(MSD, ct.k, ct.l, [c0, c1], ct.p, qs, big, ct.small)
+
+
+def g_mod_switch_up(ct: GCT, qs_front) -> GCT:
+    ct = g_to_msd(ct)
+    return GCT(MSD, ct.k, ct.l, [rescale_up(c, ct.qs, qs_front) for c in ct.c], ct.p, list(qs_front) + list(ct.qs), ct.big, ct.small)
+
+
+def g_mod_switch_down(ct: GCT, drop: int) -> GCT:
+    """modSwitch: rescaleDec on c0, rescalePow on the higher coefficients."""
+    ct = g_to_msd(ct)
+    c = [rescale_down_basis(x, ct.big, ct.qs, drop, "dec" if i == 0 else "pow") for i, x in enumerate(ct.c)]
+    return GCT(MSD, ct.k, ct.l, c, ct.p, ct.qs[drop:], ct.big, ct.small)
+
+
+def g_mod_switch_pt(ct: GCT, p_new: int) -> GCT:
+    """modSwitchPT (PT2CT's div2_): MSD form, plaintext modulus p -> p_new | p; the ring elements do not change."""
+    ct = g_to_msd(ct)
+    assert ct.p % p_new == 0
+    return GCT(MSD, ct.k, ct.l % p_new, ct.c, p_new, ct.qs, ct.big, ct.small)
+
+
+def g_mul_public(pub_pow, ct: GCT) -> GCT:
+    """mulPublic a ct: every coefficient times embed(reduce(liftPow a))."""
+    a = embed_pow([centred(x, ct.p) for x in pub_pow], ct.small, ct.big)
+    return GCT(ct.enc, ct.k, ct.l, [[ring_mul_def(cl, a, ct.big, q) for cl, q in zip(c, ct.qs)] for c in ct.c], ct.p, ct.qs,
+               ct.big, ct.small)
+
+
+def g_add_public(pub_pow, ct: GCT) -> GCT:
+    """addPublic b ct: LSD form, c0 += mulG^k (embed (reduce (liftPow (l^-1 b))))."""
+    ct = g_to_lsd(ct)
+    linv = pow(ct.l, -1, ct.p)
+    b = embed_pow([centred(x * linv % ct.p, ct.p) for x in pub_pow], ct.small, ct.big)
+    c0 = []
+    for cl, q in zip(ct.c[0], ct.qs):
+        t = [v % q for v in b]
+        for _ in range(ct.k):
+            t = mulg_pow_def(t, ct.big, q)
+        c0.append([(u + v) % q for u, v in zip(cl, t)])
+    return GCT(LSD, ct.k, ct.l, [c0] + ct.c[1:], ct.p, ct.qs, ct.big, ct.small)
+
+
+def g_decrypt(sk, ct: GCT) -> List[int]:
+    """Pow coefficients (mod p) of the plaintext: l * twace(g^-k * (liftDec(c(s)) mod p))."""
+    ct = g_to_lsd(ct)
+    big, qs = ct.big, ct.qs
+    acc = [[0] * big.n for _ in qs]
+    for comp in reversed(ct.c):                            # Horner in S
+        acc = [[(u + v) % q for u, v in zip(ring_mul_def(al, sk, big, q), cl)] for al, cl, q in zip(acc, comp, qs)]
+    e = [v % ct.p for v in lift_dec(acc, big, qs)]          # Dec coefficients mod p
+    for _ in range(ct.k):
+        e = divg_dec_def(e, big, ct.p)
+        assert e is not None
+    t = twace_pow_dec(e, ct.small, big)                     # Dec coefficients of the plaintext
+    return [ct.l * v % ct.p for v in l_def(t, ct.small, ct.p)]

@@ -173,3 +173,36 @@ def test_sixty_bit_moduli_general_index(oracle_lib):
     assert np.array_equal(buf.download(), x)
     assert np.array_equal(g.mulg_dec(x[0]), o.mulg_dec(x[0]))
     assert np.array_equal(g.divg_pow(x[1]), o.divg_pow(x[1]))
+
+
+def test_model_fixtures_on_the_gpu():
+    """The committed model-generated vectors (tests/golden/general_*.json) straight through the C ABI."""
+    from helpers import load_golden, to_aos
+    lm = lambda x: np.asarray(x).T.tolist()
+    for rec in load_golden("general_tensor_small.json"):
+        g = A.Ring(rec["m"], rec["qs"])
+        a = to_aos(rec["a"])
+        for name in ("crt", "l", "linv", "mulg_pow", "mulg_dec", "divg_pow", "divg_dec"):
+            assert lm(getattr(g, name)(a)) == rec[name], (rec["m"], name)
+        assert lm(g.mulg_crt(np.ones_like(a))) == rec["g_crt"]
+        z = A.Ring(rec["m"], [0], nocrt=True)
+        zz = np.array(rec["z"], dtype=np.int64).reshape(-1, 1)
+        assert z.mulg_pow(zz)[:, 0].tolist() == rec["z_mulg_pow"] and z.mulg_dec(zz)[:, 0].tolist() == rec["z_mulg_dec"]
+    for rec in load_golden("general_mul_small.json"):
+        mp, qs = rec["mp"], rec["qs"]
+        g = A.Ring(mp, qs)
+        hint = g.upload(np.stack([to_aos(h) for pair in rec["hint"] for h in pair]))
+        hint.crt()
+        gh = g.hint_from_buf(hint)
+        r = rec["relin"]
+        ga, gb, gout = g.upload(np.stack([to_aos(c) for c in r["a"]])), g.upload(np.stack([to_aos(c) for c in r["b"]])), g.alloc(2)
+        g.ct_mul_relin(gh, ga, gb, gout, 1, s_pre=r["s_pre"], flags=capi.ALCH_POW_IN | capi.ALCH_POW_OUT)
+        got = gout.download()
+        assert lm(got[0]) == r["out"][0] and lm(got[1]) == r["out"][1], mp
+        f = rec["full"]
+        rin, rout = A.Ring(mp, qs[1:]), A.Ring(mp, qs[2:])
+        ga, gb, gout = rin.upload(np.stack([to_aos(c) for c in f["a"]])), rin.upload(np.stack([to_aos(c) for c in f["b"]])), rout.alloc(2)
+        ga.crt(); gb.crt()
+        capi.ct_mul_full(gh, ga, gb, gout, 1, s_pre=f["s_pre"], flags=capi.ALCH_POW_OUT)
+        got = gout.download()
+        assert lm(got[0]) == f["out"][0] and lm(got[1]) == f["out"][1], mp
