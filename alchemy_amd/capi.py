@@ -28,7 +28,7 @@ SYMBOLS = [
     "alch_hint_free", "alch_ct_mul_relin", "alch_buf_rescale_drop0", "alch_buf_sub", "alch_buf_scale",
     "alch_buf_decompose_triv", "alch_buf_rescale_add0", "alch_decompose_base2", "alch_ct_mul_full", "alch_buf_device_ptr",
     "alch_ring_set_option", "alch_ring_create_nocrt", "alch_l", "alch_linv", "alch_buf_l", "alch_buf_linv", "alch_buf_mulg",
-    "alch_buf_divg", "alch_buf_mul_public", "alch_buf_add_public",
+    "alch_buf_divg", "alch_buf_mul_public", "alch_buf_add_public", "alch_select_limbs", "alch_modulus_units",
 ]
 
 
@@ -87,6 +87,8 @@ def load_library():
         "alch_ring_create": [C.c_uint32, C.c_int, PU64, C.POINTER(VP)],
         "alch_ring_create_nocrt": [C.c_uint32, C.c_int, PU64, C.POINTER(VP)],
         "alch_ring_destroy": [VP],
+        "alch_select_limbs": [PU64, C.c_int, C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4,
+        "alch_modulus_units": [C.c_uint64],
         "alch_l": [VP, P64], "alch_linv": [VP, P64],
         "alch_buf_l": [VP, C.c_size_t, C.c_size_t], "alch_buf_linv": [VP, C.c_size_t, C.c_size_t],
         "alch_buf_mulg": [VP, C.c_size_t, C.c_size_t, C.c_int], "alch_buf_divg": [VP, C.c_size_t, C.c_size_t, C.c_int],
@@ -151,6 +153,17 @@ def _p64(a: np.ndarray):
 def _pu64(vals):
     arr = (C.c_uint64 * len(vals))(*[int(v) for v in vals])
     return arr
+
+
+ALCH_OP_MUL, ALCH_OP_TUNNEL = 0, 1
+
+
+def select_limbs(moduli, p_noise_out: int, op: int = ALCH_OP_MUL, gadget: int = ALCH_GAD_TRIV):
+    """PT2CT's limb-count selection (host only): (L_in, L_hint, L_out, p_noise_in) of one mul_ / tunnel whose output has
+    pNoise p_noise_out, for the circuit's modulus list in `Zqs` order."""
+    v = [C.c_int() for _ in range(4)]
+    _check(load_library().alch_select_limbs(_pu64(moduli), len(moduli), op, gadget, p_noise_out, *[C.byref(x) for x in v]))
+    return tuple(int(x.value) for x in v)
 
 
 def host_root(m: int, q: int):

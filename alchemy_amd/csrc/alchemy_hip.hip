@@ -4,6 +4,7 @@
 // No CPU fallback lives here: every compute entry point needs a gfx950 device and reports
 // ALCH_E_NO_DEVICE / ALCH_E_HIP otherwise.  Nothing in this library includes or links oracle/.
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -555,6 +556,49 @@ static int validate_ring_args(uint32_t m, int L, const uint64_t* q, int* logn_ou
     if (logn > maxlog) return fail(ALCH_E_UNSUPPORTED, "ring dimension too large (n <= 2^16 for 32-bit, 2^15 for 64-bit residues)");
     *logn_out = logn;
     *word_out = word;
+    return ALCH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// limb-count selection (host only): PT2CT's type-level modulus arithmetic, restated
+// ------------------------------------------------------------------------------------------------------
+// Crypto/Alchemy/Interpreter/PT2CT/Noise.hs:107-170 (units of a modulus, shortest prefix with enough units) and
+// Crypto/Alchemy/Interpreter/PT2CT.hs:132-140 (KSPNoise), :160-177 (mul_), :207-229 (linearCyc_), :234-249
+// (CTPNoise2Units, KSPNoise2Units, Units2CTPNoise), :281-296 (the constants).
+extern "C" int alch_modulus_units(uint64_t q) {
+    if (q < 2) return 0;
+    return (int)std::floor(std::log2((double)q) / 6.1);          // mkModulus: floor (logBase 2 q / pNoiseUnit)
+}
+
+extern "C" int alch_select_limbs(const uint64_t* moduli, int n_moduli, int op, int gadget, int p_noise_out, int* L_in,
+                                 int* L_hint, int* L_out, int* p_noise_in) {
+    if (!moduli || n_moduli < 1 || p_noise_out < 0) return fail(ALCH_E_INVALID, "alch_select_limbs: bad argument");
+    if (op != ALCH_OP_MUL && op != ALCH_OP_TUNNEL) return fail(ALCH_E_INVALID, "alch_select_limbs: unknown op");
+    if (gadget != ALCH_GAD_TRIV && gadget != ALCH_GAD_BASE2) return fail(ALCH_E_INVALID, "unknown gadget");
+    const int MinUnits = (int)std::ceil(12 / 6.1), MulPNoise = (int)std::ceil(18 / 6.1), KSAccumPNoise = (int)std::ceil(12 / 6.1),
+              Max32BitUnits = (int)std::ceil(30.5 / 6.1), TunnelPNoise = (int)std::ceil(6 / 6.1);
+    // prefixLen: length of the shortest nonempty prefix whose units sum to >= h; total = that prefix's units
+    auto prefix = [&](int h, int* total) -> int {
+        int sum = 0;
+        for (int i = 0; i < n_moduli; ++i) {
+            sum += alch_modulus_units(moduli[i]);
+            if (sum >= h) { if (total) *total = sum; return i + 1; }
+        }
+        return -1;
+    };
+    const int p = p_noise_out;
+    const int lout = prefix(p + MinUnits, nullptr);                               // PNoise2Zq zqs p
+    int tot_in = 0;
+    const int lin = op == ALCH_OP_MUL ? prefix(p + MulPNoise + MinUnits, &tot_in)   // PreMul_: Units2CTPNoise (TotalUnits zqs (CTPNoise2Units (p :+ MulPNoise)))
+                                      : prefix(p + TunnelPNoise + MinUnits, &tot_in);
+    const int ks_units = p + KSAccumPNoise + (gadget == ALCH_GAD_TRIV ? Max32BitUnits : 0);   // KSPNoise, KSPNoise2Units
+    const int lh = prefix(ks_units, nullptr);
+    if (lout < 0 || lin < 0 || lh < 0)
+        return fail(ALCH_E_INVALID, "alch_select_limbs: the moduli do not hold enough noise units (PT2CT: \"You need more/bigger moduli!\")");
+    if (L_in) *L_in = lin;
+    if (L_hint) *L_hint = lh;
+    if (L_out) *L_out = lout;
+    if (p_noise_in) *p_noise_in = op == ALCH_OP_MUL ? tot_in - MinUnits : p + TunnelPNoise;
     return ALCH_OK;
 }
 

@@ -30,6 +30,8 @@ foreign import ccall unsafe "alch_version"             c_version         :: IO W
 foreign import ccall safe   "alch_ring_create"         c_ringCreate      :: Word32 -> CInt -> Ptr Word64 -> Ptr (Ptr AlchRing) -> IO CInt
 foreign import ccall safe   "alch_ring_create_nocrt"   c_ringCreateNoCRT :: Word32 -> CInt -> Ptr Word64 -> Ptr (Ptr AlchRing) -> IO CInt
 foreign import ccall safe   "alch_ring_destroy"        c_ringDestroy     :: Ptr AlchRing -> IO CInt
+foreign import ccall unsafe "alch_select_limbs"        c_selectLimbs     :: Ptr Word64 -> CInt -> CInt -> CInt -> CInt -> Ptr CInt -> Ptr CInt -> Ptr CInt -> Ptr CInt -> IO CInt
+foreign import ccall unsafe "alch_modulus_units"       c_modulusUnits    :: Word64 -> IO CInt
 foreign import ccall unsafe "alch_host_root"           c_hostRoot        :: Word32 -> Word64 -> Ptr Word64 -> Ptr Word64 -> IO CInt
 foreign import ccall unsafe "alch_ring_n"              c_ringN           :: Ptr AlchRing -> Ptr Word32 -> Ptr CInt -> Ptr CInt -> IO CInt
 foreign import ccall unsafe "alch_ring_set_stream"     c_ringSetStream   :: Ptr AlchRing -> Ptr () -> IO CInt

@@ -97,6 +97,21 @@ int alch_ring_create(uint32_t m, int L, const uint64_t *q, alch_ring **out);
  * sub, upload / download; everything that needs the CRT basis returns ALCH_E_NO_CRT. */
 int alch_ring_create_nocrt(uint32_t m, int L, const uint64_t *q, alch_ring **out);
 int alch_ring_destroy(alch_ring *ring);
+/* Host-only: PT2CT's limb-count selection (the type-level rules of Crypto/Alchemy/Interpreter/PT2CT/Noise.hs:107-170 and
+ * PT2CT.hs:132-140,234-249,281-296).  `moduli` is the circuit's modulus list in the order of the `Zqs` type list
+ * (examples/Arithmetic.hs:29-34, examples/HomomRLWR.hs:37-43); a ring uses the shortest PREFIX of it with enough 6.1-bit
+ * noise units, nested last-taken-outermost, i.e. the alch_ring of L limbs is created on moduli[L-1], ..., moduli[0].
+ * Given the pNoise of an operation's OUTPUT, returns how many moduli its input, its key-switch hint and its output use,
+ * and the pNoise its input must have (feed that to the operation before it: PT2CT resolves a circuit backwards).
+ *   op ALCH_OP_MUL     mul_        (PT2CT.hs:160-177):  modSwitch . keySwitchQuad hint . modSwitch $ x * y
+ *   op ALCH_OP_TUNNEL  linearCyc_  (PT2CT.hs:207-229):  modSwitch . tunnel hint . modSwitch
+ * ALCH_E_INVALID when the list does not hold enough units (PT2CT's type error "You need more/bigger moduli!"). */
+#define ALCH_OP_MUL 0
+#define ALCH_OP_TUNNEL 1
+int alch_select_limbs(const uint64_t *moduli, int n_moduli, int op, int gadget, int p_noise_out, int *L_in, int *L_hint,
+                      int *L_out, int *p_noise_in);
+/* Noise units a modulus holds: floor(log2 q / 6.1)  (mkModulus, Noise.hs:154-170). */
+int alch_modulus_units(uint64_t q);
 /* Host-only (no GPU needed): the root-rule constants of one modulus, for cross-checking against the
  * oracle: psi (primitive m-th root), and the smallest generator. */
 int alch_host_root(uint32_t m, uint64_t q, uint64_t *psi, uint64_t *generator);

@@ -113,3 +113,27 @@ def test_graft_entry_build_is_idempotent():
     import __graft_entry__ as g
     g.build()
     assert os.path.exists(A.lib_path())
+
+
+def test_select_limbs_reproduces_pt2ct_type_level_choices():
+    """alch_select_limbs against the hand simulation of SURVEY 3.3 / 3.1 (Noise.hs:107-170, PT2CT.hs:132-140,234-249,281-296):
+    HomomRLWR resolved backwards from the output pNoise 0 (PNZ, examples/HomomRLWR.hs:47): three tree levels, x(1+x), then
+    the five tunnels; Arithmetic's single multiplication."""
+    rlwr = [1543651201, 689270401, 718099201, 720720001, 1556755201, 1567238401]      # examples/HomomRLWR.hs:37-43
+    assert [capi.load_library().alch_modulus_units(q) for q in rlwr] == [5, 4, 4, 4, 5, 5]
+    p, got = 0, []
+    for _ in range(4):                                   # tree level 3, 2, 1, then x * (1 + x); div2_ keeps the pNoise
+        lin, lh, lout, p = capi.select_limbs(rlwr, p, capi.ALCH_OP_MUL)
+        got.append((lin, lh, lout))
+    assert got == [(1, 2, 1), (2, 3, 1), (3, 4, 2), (4, 5, 3)]
+    tunnels = []
+    for _ in range(5):                                   # switch5 .. switch1
+        lin, lh, lout, p = capi.select_limbs(rlwr, p, capi.ALCH_OP_TUNNEL)
+        tunnels.append((lin, lh, lout))
+    assert tunnels == [(5, 5, 4), (5, 6, 5), (5, 6, 5), (5, 6, 5), (5, 6, 5)]
+    arith = [268440577, 8392193, 1073750017]                                           # examples/Arithmetic.hs:31-34
+    assert capi.select_limbs(arith, 0)[:3] == (2, 2, 1)
+    # BaseBGad 2 hints need no Max32BitUnits head-room (PT2CT.hs:140)
+    assert capi.select_limbs(rlwr, 11, capi.ALCH_OP_MUL, capi.ALCH_GAD_BASE2)[:3] == (4, 3, 3)
+    with pytest.raises(A.AlchemyError):
+        capi.select_limbs(arith, 9)                      # "You need more/bigger moduli!"
