@@ -714,6 +714,7 @@ extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) 
     else if (k == "ks_grid") { if (value < 1) return fail(ALCH_E_INVALID, "ks_grid must be >= 1"); r->opts.ks_grid = (unsigned)value; }
     else if (k == "ti_grid") r->opts.ti_grid = (int)value;
     else if (k == "ti_split") { if (value < 0) return fail(ALCH_E_INVALID, "ti_split must be >= 0"); r->opts.ti_split = (int)value; }
+    else if (k == "rs_lin") r->opts.rs_lin = value != 0;
     else if (k == "rs_slots") { if (value < 1) return fail(ALCH_E_INVALID, "rs_slots must be >= 1"); r->rs_slots = (unsigned)value; }
     else return fail(ALCH_E_INVALID, "unknown option '" + k + "'");
     return ALCH_OK;
@@ -1580,6 +1581,15 @@ static int do_mul_full(alch_ring* rh, alch_ring* rin, alch_ring* rout, const alc
             if ((qu - 1) / 2 >= qt) c.drop.balanced = 0;
             const u64 inv = h_powmod(qu % qt, qt - 2, qt);
             c.drop.qinv_m[u][t] = (W)h_mulmod(inv, h_powmod(2, (u64)bits, qt), qt);
+        }
+    for (int u = 0; u < MAXDROP; ++u)
+        for (int t = 0; t < MAXL; ++t) c.drop.comb_m[u][t] = 0;
+    for (int u = 0; u < ddn; ++u)
+        for (int t = ddn; t < rh->L; ++t) {
+            const u64 qt = rh->q[t];
+            u64 v = 1;
+            for (int w = u; w < ddn; ++w) v = h_mulmod(v, h_powmod(rh->q[w] % qt, qt - 2, qt), qt);
+            c.drop.comb_m[u][t] = (W)h_mulmod(v, h_powmod(2, (u64)bits, qt), qt);
         }
     c.stash_slots = slots;
     c.pow_out = pow_out;

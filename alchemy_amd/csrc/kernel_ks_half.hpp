@@ -116,6 +116,7 @@ __device__ __forceinline__ u32 __attribute__((ext_vector_type(4))) buf_ld16(Rsrc
 template <typename Rsrc>
 __device__ __forceinline__ void buf_st16(Rsrc r, u32 voff, u32 soff, u32 __attribute__((ext_vector_type(4))) v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)), v), r, voff, soff, 0);
+    ALCH_STORE_GUARD(v);
 }
 
 // EPT = coefficients (and accumulator pairs) per thread: 32 -> n/64 threads, <= 128 VGPRs, 4 waves per SIMD.

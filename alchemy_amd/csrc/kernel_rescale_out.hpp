@@ -16,6 +16,7 @@
 // slower here, twice: with the forward transform in the same kernel the 32 extra registers spill.)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "ntt_engine.hpp"
 
 namespace alch {
@@ -112,8 +113,124 @@ k_rescale_out(DevRing<W> R, const W* __restrict__ src, W* __restrict__ out, type
                     __builtin_amdgcn_raw_buffer_store_b128(
                         __builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(rout, 0, 0, 0)), v), rout, lane16,
                         ot + (u32)(G::T * r) * 16u, 0);
+                    ALCH_STORE_GUARD(v);
                 }
             }
+        }
+    }
+}
+
+// k_rescale_out_lin: the same modSwitch with the kept limbs never leaving the CRT basis.
+//
+// Rescale is affine in the kept limb: with r_u = lift of the u-th dropped residue (after the drops before it),
+//     z_t = (..((x_t - r_0) q_0^-1 - r_1) q_1^-1 ..)  =  x_t C_t - sum_u r_u c_{u,t}     (mod q_t),
+//     c_{u,t} = prod_{v >= u} q_v^-1,  C_t = c_{0,t},
+// and crt is linear, so  crt(z_t) = crt(x_t) C_t - crt(sum_u reduce(r_u) c_{u,t}):  the same residues bit for bit
+// (both sides are the canonical representative of the same element of Z_{q_t}), with ddn inverse transforms (the dropped
+// limbs) + (L - ddn) forward transforms per component instead of L inverse + (L - ddn) forward: 5 instead of 8 for the
+// 5 -> 3 limb switch of PT2CT's mul_, 10 instead of 16 per ciphertext.
+// One workgroup owns one (ciphertext, component): the lifted residues r_u live in registers (32 per lane and dropped
+// limb, DDN <= 2), the combination sum_u reduce(r_u) c_{u,t} is formed lane-locally and written to LDS in the layout
+// the first forward pass reads, and the closing pass's epilogue reads crt(x_t) straight from HBM, 16 consecutive slots
+// per lane, and stores the result.  Serves CRT-basis output with one or two dropped limbs; k_rescale_out keeps the
+// Pow-basis output and three-limb drops.
+template <int LOGN, typename W, int DDN, bool BALANCED>
+__global__ void __launch_bounds__(Geo<LOGN>::T)
+k_rescale_out_lin(DevRing<W> R, const W* __restrict__ src, W* __restrict__ out, unsigned nitems, DropTab<W> D) {
+    typedef Geo<LOGN> G;
+    typedef typename Vec4<W>::type V;
+    typedef typename Signed<W>::type SW;
+    constexpr int VL = Vec4<W>::LANES;
+    constexpr int RR = 1 << G::NS0;                 // coefficients per group of the last inverse pass
+    constexpr int STRIDE = G::N / RR;
+    constexpr int NG = G::E / RR;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W* lds = reinterpret_cast<W*>(smem);
+    const int L = R.L, Lo = L - DDN;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<W*>(src), 0, (u32)((size_t)nitems * L * G::N * sizeof(W)), 0x00020000);
+    const auto rout = __builtin_amdgcn_make_buffer_rsrc(out, 0, (u32)((size_t)nitems * Lo * G::N * sizeof(W)), 0x00020000);
+    constexpr u32 ROW = (u32)G::N * (u32)sizeof(W);
+    const u32 lane16 = threadIdx.x * 16u;
+
+    for (unsigned item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const u32 x = item * (u32)L * ROW;                           // item = 2*ct + component; byte offsets
+        const u32 o = item * (u32)Lo * ROW;
+        SW rr0[G::E], rr1[DDN > 1 ? G::E : 1];                        // lifted residues of the dropped limbs, per lane (registers)
+        // ---- phase 1: the dropped limbs, outermost first (spelled out per limb: every index into rr0 / rr1 is static)
+        auto drop_limb = [&](auto UC) {
+            constexpr int u = decltype(UC)::value;
+            const ModP<W> m = R.mod[u];
+            const W q = m.q, qni = m.qni, half = (q - 1) >> 1;
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            lds_barrier();
+#pragma unroll
+            for (int r = 0; r < G::E / VL; ++r)
+                *reinterpret_cast<V*>(&lds[swz<LOGN>((tid + G::T * r) * VL)]) =
+                    __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, x + (u32)u * ROW + (u32)(G::T * r) * 16u, 0));
+            lds_barrier();
+            auto epi = [&](int g, int, W* v) {
+#pragma unroll
+                for (int k = 0; k < RR; ++k) {
+                    W c = csub(v[k], q);
+                    if constexpr (u == 1) {                          // the drop of limb 0 comes first
+                        const SW z = rr0[g * RR + k];
+                        W r;
+                        if constexpr (BALANCED) r = z < 0 ? (W)z + q : (W)z;
+                        else { SW t2 = z % (SW)q; r = t2 < 0 ? (W)(t2 + (SW)q) : (W)t2; }
+                        c = csub(mont_mul_lazy((W)(c - r + q), D.qinv_m[0][1], q, qni), q);
+                    }
+                    const SW lifted = c > half ? (SW)c - (SW)q : (SW)c;
+                    if constexpr (u == 0) rr0[g * RR + k] = lifted; else rr1[g * RR + k] = lifted;
+                }
+            };
+            ntt_inverse<LOGN, W, true, (u > 0)>(lds, R.twi[u], q, qni, R.ninv_m[u], R.w1ninv_m[u], tid, epi);
+        };
+        drop_limb(std::integral_constant<int, 0>());
+        if constexpr (DDN > 1) drop_limb(std::integral_constant<int, 1>());
+        // ---- phase 2: the kept limbs stay in the CRT basis
+        for (int t = DDN; t < L; ++t) {
+            const ModP<W> m = R.mod[t];
+            const W q = m.q, qni = m.qni;
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            lds_barrier();                      // the previous transform has finished reading LDS
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int base = tid + G::T * g;
+#pragma unroll
+                for (int k = 0; k < RR; ++k) {
+                    auto red = [&](SW z) -> W {
+                        if constexpr (BALANCED) return z < 0 ? (W)z + q : (W)z;
+                        else { SW t2 = z % (SW)q; return t2 < 0 ? (W)(t2 + (SW)q) : (W)t2; }
+                    };
+                    W acc = csub(mont_mul_lazy(red(rr0[g * RR + k]), D.comb_m[0][t], q, qni), q);
+                    if constexpr (DDN > 1) acc = csub(acc + csub(mont_mul_lazy(red(rr1[g * RR + k]), D.comb_m[1][t], q, qni), q), q);
+                    lds[swz<LOGN>(base + k * STRIDE)] = acc;
+                }
+            }
+            lds_barrier();
+            const u32 xt = x + (u32)t * ROW, ot = o + (u32)(t - DDN) * ROW;
+            const W Ct = D.comb_m[0][t];
+            auto twf = fwd_tw(R, t);
+            const W* twm = R.twf[t];
+            ntt_forward<LOGN, W, true, true>(lds, twf, twm, q, qni, tid, [&](int, int base, W* v) {
+#pragma unroll
+                for (int k = 0; k < 16; k += VL) {
+                    const V xin = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, (u32)(base + k) * (u32)sizeof(W), xt, 0));
+                    V res;
+#pragma unroll
+                    for (int e = 0; e < VL; ++e) {
+                        const W a = csub(mont_mul_lazy(xin[e], Ct, q, qni), q);
+                        res[e] = csub((W)(a + (q - csub(v[k + e], q))), q);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        __builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(rout, 0, 0, 0)), res), rout,
+                        (u32)(base + k) * (u32)sizeof(W), ot, 0);
+                    // see ALCH_STORE_GUARD (ntt_engine.hpp): this is the store the hazard was found on
+                    asm volatile("s_nop 1" ::"v"(res));
+                }
+            });
         }
     }
 }

@@ -106,7 +106,9 @@ k_tensor_intt_split(DevRing<u32> R, const u32* __restrict__ a, const u32* __rest
                     }
                     const u32 so = drow + SLICE * (u32)r;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(rd, 0, 0, 0)), z0), rd, lane16, so, 0);
+                    ALCH_STORE_GUARD(z0);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(rd, 0, 0, 0)), z1), rd, lane16, so + HALF, 0);
+                    ALCH_STORE_GUARD(z1);
                 }
             }
             lds_barrier();                      // LDS is refilled next

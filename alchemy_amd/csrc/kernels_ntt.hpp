@@ -66,12 +66,14 @@ struct DropTab {
     int ddn;                       // limbs dropped (outermost first), 1..MAXDROP
     int balanced;                  // every centred residue of a dropped limb is smaller than every kept modulus
     W qinv_m[MAXDROP][MAXL];       // q_u^-1 mod q_t in Montgomery form (t > u)
+    W comb_m[MAXDROP][MAXL];       // prod_{v >= u} q_v^-1 mod q_t in Montgomery form (t >= ddn): k_rescale_out_lin
 };
 
 // Launch-structure options of the fused kernels (alch_ring_set_option; defaults are the measured optima).
 struct LaunchOpts {
     int ti_split = 1;        // n = 2^15 tensor kernel: 1 = split form, one workgroup per item; 0 = whole-polynomial kernel; > 1 = that many persistent workgroups
     int ti_grid = -1;        // whole-polynomial tensor kernel: -1 = one resident set of persistent workgroups, 0 = one workgroup per item, n > 0 = n workgroups
+    int rs_lin = 1;          // closing modSwitch: 1 = kept limbs stay in the CRT basis (k_rescale_out_lin), 0 = every limb through the Pow basis
     unsigned ks_grid = 4096; // persistent workgroups of k_ks_accum_half (measured, 1024-ciphertext chunks: 2048 -> 511k, 4096 -> 517k, 8192 -> 513k op/s)
 };
 
@@ -604,6 +606,21 @@ inline hipError_t run_call(const NttCall<W>& c) {
         break;
     }
     case OP_RESCALE_OUT: {
+        if (!c.pow_out && c.opts.rs_lin && (c.drop.ddn == 1 || (c.drop.ddn == 2 && c.drop.balanced))) {   // (unbalanced two-limb drops would spill)
+            // kept limbs stay in the CRT basis: ddn inverse + (L - ddn) forward transforms per component (kernel_rescale_out.hpp)
+            const unsigned nitems = (unsigned)(c.nct * 2);
+            const unsigned grid = nitems < c.stash_slots ? nitems : c.stash_slots;
+            auto go = [&](auto k) -> hipError_t {
+                hipError_t e2 = set_lds(k, lds_bytes);
+                if (e2 != hipSuccess) return e2;
+                hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), lds_bytes, c.stream, R, c.a, c.out, nitems, c.drop);
+                return hipSuccess;
+            };
+            if (c.drop.ddn == 1) e = c.drop.balanced ? go(k_rescale_out_lin<LOGN, W, 1, true>) : go(k_rescale_out_lin<LOGN, W, 1, false>);
+            else e = go(k_rescale_out_lin<LOGN, W, 2, true>);
+            if (e != hipSuccess) return e;
+            break;
+        }
         auto k = k_rescale_out<LOGN, W>;
         if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
         const unsigned nitems = (unsigned)(c.nct * 2);

@@ -76,6 +76,14 @@ template <typename W> struct Vec4;
 template <> struct Vec4<u32> { typedef u32 type __attribute__((ext_vector_type(4))); static constexpr int LANES = 4; };
 template <> struct Vec4<u64> { typedef u64 type __attribute__((ext_vector_type(2))); static constexpr int LANES = 2; };
 
+// Store-data guard for 16-byte buffer stores.  A buffer_store_dwordx4 reads its four data VGPRs over several cycles.
+// hipcc (ROCm 7.2, gfx950) inserts no wait state behind such a store when it carries an SGPR offset, and a VALU
+// instruction issued right behind it that writes the first data register was observed to win the race: k_rescale_out_lin
+// lost element 12 of lanes 12-15 / 28-31 / 44-47 / 60-63 of one wave in ~0.5 % of its polynomials until its store data
+// were kept live across one s_nop (found by the whole-batch checksum of tests/test_gpu_bench_shape.py).  Every 16-byte
+// buffer store in this library is followed by this guard; it costs one issue slot.
+#define ALCH_STORE_GUARD(v) asm volatile("s_nop 0" ::"v"(v))
+
 // Workgroup barrier for LDS hand-offs only.  __syncthreads() is also a fence for global memory, so hipcc puts
 // `s_waitcnt vmcnt(0)` in front of it whenever vector-memory operations are outstanding -- which drains every
 // prefetch (register loads for the next work item, LDS-DMA touches) at the next pass boundary.  The transforms
