@@ -86,6 +86,15 @@ def cpu_baseline_all_cores(ops_per_thread: int):
             "sample": f"{ops_per_thread} ops on each of {threads} threads, slowest thread {max(secs):.1f} s"}
 
 
+RING_OPTS = []
+
+
+def apply_opts(*rings):
+    for r in rings:
+        for k, v in RING_OPTS:
+            r.set_option(k, v)
+
+
 def general_index_line():
     """Extra line: the same op on the ring the reference's HomomRLWR example multiplies in -- H5' = F20475 =
     3^2 5^2 7 13 (examples/Common.hs:54), phi = 8640, the first four HomomRLWR moduli (examples/HomomRLWR.hs:37-43),
@@ -93,6 +102,7 @@ def general_index_line():
     from alchemy_amd import Ring
     m, qs = 20475, [1543651201, 689270401, 718099201, 720720001]
     ring = Ring(m, qs)
+    apply_opts(ring)
     n, Bg = ring.n, 4096
     a, b, out, hs = ring.alloc(2 * Bg), ring.alloc(2 * Bg), ring.alloc(2 * Bg), ring.alloc(2 * ring.L)
     a.fill_uniform(11); b.fill_uniform(12); hs.fill_uniform(13)
@@ -131,7 +141,12 @@ def main():
                     help="skip PT2CT's whole mul_ (modSwitch . keySwitchQuad . modSwitch . (*)), 4 -> 5 -> 3 limbs (extra field)")
     ap.add_argument("--no-general", dest="general", action="store_false",
                     help="skip the general-index line (keySwitchQuadCirc(a*b) on the reference's H5' = F20475 ring)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="launch-structure option for every ring (alch_ring_set_option), e.g. one_stream=1 for kernel traces "
+                         "whose durations add up to the step time")
     args = ap.parse_args()
+    global RING_OPTS
+    RING_OPTS = [(kv.split("=")[0], int(kv.split("=")[1])) for kv in args.opt]
 
     import torch
     from alchemy_amd import Ring, shard
@@ -153,6 +168,7 @@ def main():
     red_dev = None if os.environ.get("ALCH_DIST_BACKEND") == "gloo" else dev
 
     ring = Ring(2 << LOGN, CFG3_QS)
+    apply_opts(ring)
     B = args.batch
     a, b, out = ring.alloc(2 * B), ring.alloc(2 * B), ring.alloc(2 * B)
     hint_src = ring.alloc(2 * ring.L)
@@ -270,6 +286,7 @@ def main():
         from alchemy_amd import capi
         qs_h = [FULL_EXTRA_Q] + CFG3_QS
         rh, rout = Ring(2 << LOGN, qs_h), Ring(2 << LOGN, CFG3_QS[1:])
+        apply_opts(rh, rout)
         Bf = min(B, 4096)
         hsrc = rh.alloc(2 * rh.L)
         hsrc.fill_uniform(0xA1C4E5)

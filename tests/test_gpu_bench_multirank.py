@@ -1,0 +1,48 @@
+"""GPU: bench.py's multi-rank path rehearsed on the one-GPU box -- two ranks over gloo sharing cuda:0
+(ALCH_DIST_BACKEND=gloo, ALCH_FORCE_DEVICE=0; the driver's real runs use nccl = RCCL with one rank per GPU):
+hint broadcast, sharded steps, max-over-ranks timing, per-rank event times, result all-gather with the own slice checked.
+A broken collective must END the run with a non-zero exit code instead of printing a healthy-looking line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(extra_env):
+    env = dict(os.environ, ALCH_DIST_BACKEND="gloo", ALCH_FORCE_DEVICE="0", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "64", "--cpu-ops", "0", "--no-full", "--no-pow", "--no-general"]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+
+
+def test_two_rank_rehearsal_prints_one_line():
+    out = _run({})
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["scaling"] == "weak"
+    assert d["config"]["hint"].startswith("gloo broadcast")
+    assert len(d["hip_event_ms_per_step_by_rank"]) == 2 and all(t > 0 for t in d["hip_event_ms_per_step_by_rank"])
+    assert d["result_gather"]["own_slice_intact"] is True
+    assert d["cpu_baseline"] is None
+
+
+def test_failed_broadcast_is_fatal():
+    out = _run({"ALCH_TEST_FAIL_BROADCAST": "1"})
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")], "no result line may be printed"

@@ -58,3 +58,45 @@ def test_blocking_calls_are_safe_imports():
     for name in ("alch_ct_mul_relin", "alch_ct_mul_full", "alch_sync", "alch_buf_upload", "alch_buf_download",
                  "alch_crt", "alch_crtinv", "alch_hint_load"):
         assert imps[name][0] == "safe", name
+
+
+TENSOR_METHODS = ["scalarPow", "l", "lInv", "mulGPow", "mulGDec", "divGPow", "divGDec", "crtFuncs", "tGaussianDec",
+                  "gSqNormDec", "twacePowDec", "embedPow", "embedDec", "crtExtFuncs", "coeffs", "powBasisPow", "crtSetDec",
+                  "fmapT", "zipWithT", "unzipT", "entailIndexT", "entailEqT", "entailZTT", "entailNFDataT",
+                  "entailRandomT", "entailShowT", "entailModuleT"]        # Lol 0.7's class Tensor
+
+
+def _gt_source():
+    return open(os.path.join(ROOT, "haskell", "Crypto", "Lol", "Cyclotomic", "Tensor", "GT.hs")).read()
+
+
+def test_tensor_instance_defines_every_method_and_none_is_a_stub():
+    text = _gt_source()
+    inst = text[text.index("instance Tensor GT where"):text.index("-- | The CRTrans-monad tuple")]
+    for name in TENSOR_METHODS:
+        assert re.search(r"^  %s\b[^\n]*=" % re.escape(name), inst, flags=re.M), f"instance Tensor GT lacks {name}"
+    code = "\n".join(l.split("--")[0] for l in text.splitlines())            # comments stripped
+    assert not re.search(r"=\s*error\b", code) and "undefined" not in code, "stub bodies are not allowed"
+    assert not re.search(r"\berror\s+\"(coerce|see|as )", code)
+
+
+def test_every_foreign_symbol_used_by_the_instance_is_imported_by_the_backend():
+    text, imps = _gt_source(), haskell_imports()
+    hs_names = set(re.findall(r'^foreign import ccall (?:safe|unsafe)\s+"\w+"\s+(\w+)\s*::', open(os.path.join(
+        ROOT, "haskell", "Crypto", "Lol", "Cyclotomic", "Tensor", "GT", "Backend.hs")).read(), flags=re.M))
+    used = set(re.findall(r"\bc_[A-Za-z0-9]+\b", text))
+    assert used and used <= hs_names, sorted(used - hs_names)
+    # the hot Tensor methods of SURVEY 8b all cross the FFI
+    for sym in ("c_crt", "c_crtInv", "c_mulGPow", "c_mulGDec", "c_mulGCRT", "c_divGPow", "c_divGDec", "c_divGCRT", "c_l", "c_lInv",
+                "c_mul", "c_add", "c_ctMulRelin", "c_ctMulFull"):
+        assert sym in used, sym
+    assert len(imps) >= 55
+
+
+def test_example_variant_patch_touches_only_the_tensor_type():
+    patch = open(os.path.join(ROOT, "haskell", "examples", "Arithmetic-GT.patch")).read()
+    minus = [l for l in patch.splitlines() if l.startswith("-") and not l.startswith("---")]
+    plus = [l for l in patch.splitlines() if l.startswith("+") and not l.startswith("+++")]
+    assert len(minus) == len(plus) == 2
+    assert "Tensor.CPP" in minus[0] and "Tensor.GT" in plus[0]
+    assert minus[1].replace(" CT ", " GT ") == "-" + plus[1][1:]
