@@ -7,4 +7,4 @@ the C++ header ``alchemy_amd/host/symmshe.hpp`` (the reference's host code is co
 compiled code too).  There is no CPU fallback: importing works anywhere, but every compute
 call raises unless the HIP library is built and a gfx950 device is present.
 """
-from .capi import AlchemyError, Buf, Hint, Ring, lib_path, load_library  # noqa: F401
+from .capi import AlchemyError, Buf, Hint, Ring, Tunnel, lib_path, load_library  # noqa: F401

@@ -29,6 +29,7 @@ SYMBOLS = [
     "alch_buf_decompose_triv", "alch_buf_rescale_add0", "alch_decompose_base2", "alch_ct_mul_full", "alch_buf_device_ptr",
     "alch_ring_set_option", "alch_ring_create_nocrt", "alch_l", "alch_linv", "alch_buf_l", "alch_buf_linv", "alch_buf_mulg",
     "alch_buf_divg", "alch_buf_mul_public", "alch_buf_add_public", "alch_select_limbs", "alch_modulus_units",
+    "alch_tunnel_info", "alch_tunnel_create", "alch_tunnel_free", "alch_ct_tunnel",
 ]
 
 
@@ -89,6 +90,10 @@ def load_library():
         "alch_ring_destroy": [VP],
         "alch_select_limbs": [PU64, C.c_int, C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4,
         "alch_modulus_units": [C.c_uint64],
+        "alch_tunnel_info": [VP, VP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
+        "alch_tunnel_create": [VP, VP, VP, VP, C.POINTER(VP)],
+        "alch_tunnel_free": [VP],
+        "alch_ct_tunnel": [VP, VP, VP, C.c_size_t, PU64, C.c_uint],
         "alch_l": [VP, P64], "alch_linv": [VP, P64],
         "alch_buf_l": [VP, C.c_size_t, C.c_size_t], "alch_buf_linv": [VP, C.c_size_t, C.c_size_t],
         "alch_buf_mulg": [VP, C.c_size_t, C.c_size_t, C.c_int], "alch_buf_divg": [VP, C.c_size_t, C.c_size_t, C.c_int],
@@ -312,6 +317,38 @@ def ct_mul_full(hint: "Hint", a: "Buf", b: "Buf", out: "Buf", batch: int, s_pre=
     """PT2CT's whole mul_: modSwitch . keySwitchQuadCirc hint . modSwitch $ a * b (rings come from the handles)."""
     sp = _pu64(s_pre) if s_pre is not None else None
     _check(load_library().alch_ct_mul_full(hint._h, a._h, b._h, out._h, batch, sp, flags))
+
+
+class Tunnel:
+    """alch_tunnel: SymmSHE `tunnel hint` from ring_r = R'_q to ring_s = S'_q (device-resident linear function + hints)."""
+
+    def __init__(self, ring_r: "Ring", ring_s: "Ring", lin_crt: "Buf", ks_crt: "Buf"):
+        self.ring_r, self.ring_s = ring_r, ring_s
+        h = C.c_void_p()
+        _check(ring_s._l.alch_tunnel_create(ring_r._h, ring_s._h, lin_crt._h, ks_crt._h, C.byref(h)))
+        self._h = h
+
+    @staticmethod
+    def info(ring_r: "Ring", ring_s: "Ring"):
+        """(index of E' = R' cap S', d_rel = dim R'/E')."""
+        e, d = C.c_uint32(), C.c_uint32()
+        _check(ring_r._l.alch_tunnel_info(ring_r._h, ring_s._h, C.byref(e), C.byref(d)))
+        return int(e.value), int(d.value)
+
+    def apply(self, src: "Buf", dst: "Buf", batch: int, s_pre=None, flags: int = 0):
+        sp = _pu64(s_pre) if s_pre is not None else None
+        _check(self.ring_s._l.alch_ct_tunnel(self._h, src._h, dst._h, batch, sp, flags))
+
+    def free(self):
+        if getattr(self, "_h", None):
+            self.ring_s._l.alch_tunnel_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Buf:

@@ -68,6 +68,16 @@ struct alch_buf {
     void* dptr;
 };
 
+struct alch_tunnel {
+    alch_ring* rr;                             // R'_q (input ciphertexts)
+    alch_ring* rs;                             // S'_q (hint, output ciphertexts)
+    u32 d_rel;                                 // dim of R'/E' = number of E'-coefficients per ring element
+    u32 linv_skip_mask;
+    int32_t* table;                            // device: [d_rel][n_s] source positions in R', -1 = zero
+    void* lin;                                 // device: f' values y_i, [d_rel][L][n_s], CRT basis, Montgomery form
+    void* ks;                                  // device: [d_rel * L][2][L][n_s], CRT basis, Montgomery form
+};
+
 struct alch_hint {
     alch_ring* ring;
     int gadget;
@@ -380,6 +390,39 @@ __global__ void k_add_bcast(DevRing<W> R, W* dst, const W* pub, size_t cts) {
         const size_t ct = w / Ln, rem = w % Ln;
         W* p = dst + 2 * ct * Ln + rem;
         *p = add_mod(*p, pub[rem], R.mod[rem / n].q);
+    }
+}
+
+// Tunnel, step 1: the E'-coefficients of (c0, c1) embedded into S' (coeffs + embedPow as one index gather; toMSD's
+// per-limb scalar folded in).  in: [ct][2][L][n_r]; x0 / x1: [ct][d_rel][L][n_s].
+template <typename W>
+__global__ void k_tunnel_gather(DevRing<W> Rs, const W* in, W* x0, W* x1, const int32_t* table, u32 d_rel, u32 n_r, size_t nct, Scal<W> s_m, int scale) {
+    const size_t n = (size_t)Rs.n, L = (size_t)Rs.L;
+    const size_t per_ct = (size_t)d_rel * L * n;
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < nct * 2 * per_ct; w += (size_t)gridDim.x * blockDim.x) {
+        const size_t ct = w / (2 * per_ct), rem = w % (2 * per_ct), comp = rem / per_ct, r2 = rem % per_ct;
+        const size_t i = r2 / (L * n), limb = (r2 / n) % L, k = r2 % n;
+        const int32_t src = table[i * n + k];
+        W v = 0;
+        if (src >= 0) {
+            v = in[((2 * ct + comp) * L + limb) * (size_t)n_r + (size_t)src];
+            if (scale) v = mont_mul(v, s_m.v[limb], Rs.mod[limb]);
+        }
+        (comp ? x1 : x0)[ct * per_ct + r2] = v;
+    }
+}
+
+// Tunnel, step 2: c0' = sum_i crt(x0_i) * y_i (evalLin on the constant term), c1' = 0.  out: [ct][2][L][n].
+template <typename W>
+__global__ void k_tunnel_lin(DevRing<W> Rs, W* out, const W* x0crt, const W* lin, u32 d_rel, size_t nct) {
+    const size_t n = (size_t)Rs.n, Ln = (size_t)Rs.L * n;
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < nct * Ln; w += (size_t)gridDim.x * blockDim.x) {
+        const size_t ct = w / Ln, rem = w % Ln;
+        const ModP<W> m = Rs.mod[rem / n];
+        W acc = 0;
+        for (u32 i = 0; i < d_rel; ++i) acc = add_mod(acc, mont_mul(x0crt[(ct * d_rel + i) * Ln + rem], lin[(size_t)i * Ln + rem], m), m.q);
+        out[2 * ct * Ln + rem] = acc;
+        out[(2 * ct + 1) * Ln + rem] = 0;
     }
 }
 
@@ -1792,6 +1835,163 @@ extern "C" int alch_ct_mul_full(const alch_hint* hint, const alch_buf* a, const 
     HIP_TRY(hipEventRecord(rh->ev_x, rh->stream));
     if (rin->stream != rh->stream) HIP_TRY(hipStreamWaitEvent(rin->stream, rh->ev_x, 0));
     if (rout->stream != rh->stream) HIP_TRY(hipStreamWaitEvent(rout->stream, rh->ev_x, 0));
+    return ALCH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// ring tunnelling: tunnel_ hint between two modSwitch_ (PT2CT.hs:224-229, Eval.hs:134)
+// ------------------------------------------------------------------------------------------------------
+extern "C" int alch_tunnel_info(const alch_ring* rr, const alch_ring* rs, uint32_t* e_prime, uint32_t* d_rel) {
+    if (!rr || !rs) return fail(ALCH_E_INVALID, "null ring");
+    u32 a = rr->m, b = rs->m;
+    while (b) { const u32 t = a % b; a = b; b = t; }
+    GenHost ge, gr, gs;
+    if (!gen_plan(a, ge) || !gen_plan(rr->m, gr) || !gen_plan(rs->m, gs)) return fail(ALCH_E_UNSUPPORTED, "index not served");
+    u32 d = 0, mask = 0;
+    std::vector<int32_t> tab;
+    if (!gen_tunnel_table(ge, gr, gs, d, tab, mask)) return fail(ALCH_E_INVALID, "indices do not form a tunnel");
+    if (e_prime) *e_prime = a;
+    if (d_rel) *d_rel = d;
+    return ALCH_OK;
+}
+
+template <typename W>
+static int tunnel_to_mont(alch_ring* rs, void* dst, const void* src, size_t elems) {
+    Scal<W> sm;
+    scal_to_mont<W>(rs, nullptr, 2, sm);
+    const size_t words = elems * elem_words(rs);
+    hipLaunchKernelGGL((k_scale<W>), dim3(ew_grid(words)), dim3(256), 0, rs->stream, dev_ring<W>(rs), (W*)dst, (const W*)src, words, sm);
+    HIP_TRY(hipGetLastError());
+    return ALCH_OK;
+}
+
+extern "C" int alch_tunnel_create(alch_ring* rr, alch_ring* rs, const alch_buf* lin_crt, const alch_buf* ks_crt, alch_tunnel** out) {
+    if (!rr || !rs || !lin_crt || !ks_crt || !out) return fail(ALCH_E_INVALID, "null argument");
+    *out = nullptr;
+    if (!rr->gen || !rs->gen || !rr->has_crt || !rs->has_crt) return fail(ALCH_E_UNSUPPORTED, "tunnelling runs on general-index rings with a CRT basis");
+    if (rr->L != rs->L || rr->word != rs->word) return fail(ALCH_E_INVALID, "both rings must have the same moduli");
+    for (int j = 0; j < rr->L; ++j) if (rr->q[j] != rs->q[j]) return fail(ALCH_E_INVALID, "both rings must have the same moduli");
+    if (lin_crt->ring != rs || ks_crt->ring != rs) return fail(ALCH_E_INVALID, "the linear function and the hints live in the target ring");
+    u32 ep = 0, d_rel = 0;
+    int rc = alch_tunnel_info(rr, rs, &ep, &d_rel);
+    if (rc != ALCH_OK) return rc;
+    GenHost ge;
+    gen_plan(ep, ge);
+    std::vector<int32_t> tab;
+    u32 mask = 0;
+    if (!gen_tunnel_table(ge, rr->gh, rs->gh, d_rel, tab, mask)) return fail(ALCH_E_INVALID, "indices do not form a tunnel");
+    const size_t nlin = d_rel, nks = (size_t)d_rel * rs->L * 2;
+    if (lin_crt->n_elems < nlin || ks_crt->n_elems < nks)
+        return fail(ALCH_E_INVALID, "need d_rel linear-function values and 2 * d_rel * L hint elements");
+    BIND(rs);
+    alch_tunnel* t = new alch_tunnel{rr, rs, d_rel, mask, nullptr, nullptr, nullptr};
+    if (hipMalloc((void**)&t->table, tab.size() * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc(&t->lin, nlin * elem_bytes(rs)) != hipSuccess || hipMalloc(&t->ks, nks * elem_bytes(rs)) != hipSuccess) {
+        alch_tunnel_free(t);
+        return fail(ALCH_E_NOMEM, "hipMalloc(tunnel) failed");
+    }
+    if (hipMemcpy(t->table, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { alch_tunnel_free(t); return fail(ALCH_E_HIP, "tunnel table upload failed"); }
+    rc = rs->word == 4 ? tunnel_to_mont<u32>(rs, t->lin, lin_crt->dptr, nlin) : tunnel_to_mont<u64>(rs, t->lin, lin_crt->dptr, nlin);
+    if (rc == ALCH_OK) rc = rs->word == 4 ? tunnel_to_mont<u32>(rs, t->ks, ks_crt->dptr, nks) : tunnel_to_mont<u64>(rs, t->ks, ks_crt->dptr, nks);
+    if (rc != ALCH_OK) { alch_tunnel_free(t); return rc; }
+    if (hipStreamSynchronize(rs->stream) != hipSuccess) { alch_tunnel_free(t); return fail(ALCH_E_HIP, "tunnel setup failed"); }
+    *out = t;
+    return ALCH_OK;
+}
+
+extern "C" int alch_tunnel_free(alch_tunnel* t) {
+    if (!t) return ALCH_OK;
+    (void)hipSetDevice(t->rs->device);
+    (void)hipStreamSynchronize(t->rs->stream);
+    if (t->table) (void)hipFree(t->table);
+    if (t->lin) (void)hipFree(t->lin);
+    if (t->ks) (void)hipFree(t->ks);
+    delete t;
+    return ALCH_OK;
+}
+
+// SymmSHE.tunnel on a batch of linear ciphertexts (k = 0):  out = (f'(c0), 0) + sum_i switch(hint_i, embed(c1_i)).
+template <typename W>
+static int do_tunnel(const alch_tunnel* t, const void* in, void* out, size_t batch, const uint64_t* s_pre, unsigned flags) {
+    alch_ring* rr = t->rr;
+    alch_ring* rs = t->rs;
+    const int L = rs->L;
+    const u32 D = t->d_rel;
+    const size_t ebr = elem_bytes(rr), ebs = elem_bytes(rs);
+    // scratch per ciphertext: Pow copy of the input (2 R'-elements), x0, x1 (D S'-elements each), digits (D * L S'-elements)
+    const size_t per_ct = 2 * ebr + (size_t)(2 * D + D * L) * ebs;
+    size_t chunk = std::max<size_t>(1, ((size_t)1 << 30) / per_ct);
+    chunk = std::min(chunk, batch);
+    int rc = ensure_ws(&rs->ws_full, &rs->ws_full_bytes, chunk * per_ct);
+    if (rc != ALCH_OK) return rc;
+    char* win = reinterpret_cast<char*>(rs->ws_full);
+    char* x0 = win + chunk * 2 * ebr;
+    char* x1 = x0 + chunk * D * ebs;
+    char* dig = x1 + chunk * D * ebs;
+    Scal<W> sm;
+    scal_to_mont<W>(rs, s_pre, 1, sm);
+    const bool dec_c0 = rr->gh.rad > 1 && t->linv_skip_mask != ((1u << rr->gh.nfact) - 1);
+    for (size_t done = 0; done < batch; done += chunk) {
+        const size_t now = std::min(chunk, batch - done);
+        const char* src = reinterpret_cast<const char*>(in) + done * 2 * ebr;
+        // Pow basis of R' (a copy: the caller's ciphertexts are left alone); c0 onto relative-Dec (x) Pow(E')
+        if (flags & ALCH_POW_IN) HIP_TRY(hipMemcpyAsync(win, src, now * 2 * ebr, hipMemcpyDeviceToDevice, rs->stream));
+        else if ((rc = do_crt<W>(rr, win, 0, 2 * now, true, src, rs->stream)) != ALCH_OK) return rc;
+        if (dec_c0) {
+            GenCall<W> g{};
+            g.op = GEN_LINV; g.ring = &dev_ring<W>(rr); g.gen = &gen_dev<W>(rr); g.stream = rs->stream;
+            g.data = reinterpret_cast<W*>(win); g.elem_stride = 2; g.first_poly = 0; g.npoly = now * (size_t)L;
+            g.skip_mask = t->linv_skip_mask; g.fail_flag = rr->d_flag;
+            hipError_t e = gen_dispatch(g);
+            if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("tunnel lInv launch: ") + hipGetErrorString(e));
+        }
+        const size_t gw = now * 2 * (size_t)D * elem_words(rs);
+        hipLaunchKernelGGL((k_tunnel_gather<W>), dim3(ew_grid(gw)), dim3(256), 0, rs->stream, dev_ring<W>(rs), (const W*)win, (W*)x0, (W*)x1,
+                           t->table, D, rr->n, now, sm, s_pre ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+        // constant term: evalLin
+        if ((rc = do_crt<W>(rs, x0, 0, now * D, false)) != ALCH_OK) return rc;
+        W* po = reinterpret_cast<W*>(reinterpret_cast<char*>(out) + done * 2 * ebs);
+        hipLaunchKernelGGL((k_tunnel_lin<W>), dim3(ew_grid(now * elem_words(rs))), dim3(256), 0, rs->stream, dev_ring<W>(rs), po, (const W*)x0,
+                           (const W*)t->lin, D, now);
+        HIP_TRY(hipGetLastError());
+        // linear term: decompose + reduce + crt of every embedded coefficient, inner product with the hints
+        {
+            GenCall<W> g{};
+            g.op = GEN_CRT_DIGITS; g.ring = &dev_ring<W>(rs); g.gen = &gen_dev<W>(rs); g.stream = rs->stream;
+            g.src = reinterpret_cast<const W*>(x1); g.data = reinterpret_cast<W*>(dig);
+            g.npoly = now * (size_t)D * (size_t)L * (size_t)L; g.balanced = rs->balanced; g.with_diag = true;
+            hipError_t e = gen_dispatch(g);
+            if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("tunnel crt_digits launch: ") + hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL((k_hint_mac<W>), dim3(ew_grid(now * elem_words(rs))), dim3(256), 0, rs->stream, dev_ring<W>(rs), po, (const W*)dig,
+                           (const W*)t->ks, now, D * (u32)L, (const W*)nullptr);
+        HIP_TRY(hipGetLastError());
+    }
+    return ALCH_OK;
+}
+
+extern "C" int alch_ct_tunnel(const alch_tunnel* t, const alch_buf* in, alch_buf* out, size_t batch, const uint64_t* s_pre, unsigned flags) {
+    if (!t || !in || !out) return fail(ALCH_E_INVALID, "null argument");
+    if (in->ring != t->rr || out->ring != t->rs) return fail(ALCH_E_INVALID, "input / output buffers must belong to the tunnel's rings");
+    if (flags & ~(unsigned)(ALCH_POW_IN | ALCH_POW_OUT)) return fail(ALCH_E_INVALID, "unknown flag");
+    if (batch == 0) return ALCH_OK;
+    if (in->n_elems < 2 * batch || out->n_elems < 2 * batch) return fail(ALCH_E_INVALID, "buffers must hold 2*batch ring elements");
+    alch_ring* rs = t->rs;
+    alch_ring* rr = t->rr;
+    BIND(rs);
+    if (!rs->ev_x) HIP_TRY(hipEventCreateWithFlags(&rs->ev_x, hipEventDisableTiming));
+    if (rr->stream != rs->stream) {                       // everything runs on the target ring's stream
+        HIP_TRY(hipEventRecord(rs->ev_x, rr->stream));
+        HIP_TRY(hipStreamWaitEvent(rs->stream, rs->ev_x, 0));
+    }
+    int rc = rs->word == 4 ? do_tunnel<u32>(t, in->dptr, out->dptr, batch, s_pre, flags) : do_tunnel<u64>(t, in->dptr, out->dptr, batch, s_pre, flags);
+    if (rc != ALCH_OK) return rc;
+    if (flags & ALCH_POW_OUT) if ((rc = buf_crt(out, 0, 2 * batch, true)) != ALCH_OK) return rc;
+    if (rr->stream != rs->stream) {
+        HIP_TRY(hipEventRecord(rs->ev_x, rs->stream));
+        HIP_TRY(hipStreamWaitEvent(rr->stream, rs->ev_x, 0));
+    }
     return ALCH_OK;
 }
 

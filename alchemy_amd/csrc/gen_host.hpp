@@ -208,4 +208,50 @@ inline bool gen_tables(const GenHost& g, u64 q, std::vector<u64>& fwd, std::vect
     return true;
 }
 
+// Tunnel index table (SymmSHE.tunnel): for the relative index i of R'/E' and every Pow/Dec position k of S',
+// table[i * n_s + k] = the position in R' whose coefficient lands there -- coeffs (R' -> E', relative index i) followed by
+// embedPow (E' -> S') -- or -1 where embedPow leaves a zero.  ep = gcd(r', s'); relative indices in mixed radix, first
+// prime outermost (the order of oracle/model_gen.py coeffs_indices).
+inline bool gen_tunnel_table(const GenHost& ep, const GenHost& rp, const GenHost& sp, u32& d_rel, std::vector<int32_t>& table,
+                             u32& linv_skip_mask) {
+    if (rp.m % ep.m || sp.m % ep.m) return false;
+    auto expo = [](const GenHost& g, int p) { for (int l = 0; l < g.nfact; ++l) if (g.fact[l].p == p) return g.fact[l].e; return 0; };
+    auto ipow = [](u32 b, int e) { u32 r = 1; while (e-- > 0) r *= b; return r; };
+    // relative dimensions per factor of r'
+    u32 rel_dim[GEN_MAXFACT];
+    d_rel = 1;
+    linv_skip_mask = 0;
+    for (int l = 0; l < rp.nfact; ++l) {
+        const int p = rp.fact[l].p, er = rp.fact[l].e, ee = expo(ep, p);
+        rel_dim[l] = ee ? ipow((u32)p, er - ee) : rp.fact[l].dim;
+        d_rel *= rel_dim[l];
+        // lInv on R' followed by l on every E'-coefficient = lInv over the primes that do NOT divide e' only
+        if (ee) linv_skip_mask |= 1u << l;
+    }
+    if ((u64)d_rel * ep.n != rp.n) return false;
+    table.assign((size_t)d_rel * sp.n, -1);
+    for (u32 i = 0; i < d_rel; ++i) {
+        u32 rel[GEN_MAXFACT], t = i;
+        for (int l = rp.nfact - 1; l >= 0; --l) { rel[l] = t % rel_dim[l]; t /= rel_dim[l]; }
+        for (u32 j = 0; j < ep.n; ++j) {
+            u32 posr = 0, poss = 0;
+            for (int l = 0; l < rp.nfact; ++l) {
+                const int p = rp.fact[l].p, er = rp.fact[l].e, ee = expo(ep, p);
+                u32 jp = 0;
+                if (ee) for (int le = 0; le < ep.nfact; ++le) if (ep.fact[le].p == p) jp = (j / ep.fact[le].rts) % ep.fact[le].dim;
+                posr += (ee ? rel[l] + ipow((u32)p, er - ee) * jp : rel[l]) * rp.fact[l].rts;
+            }
+            for (int l = 0; l < sp.nfact; ++l) {
+                const int p = sp.fact[l].p, es = sp.fact[l].e, ee = expo(ep, p);
+                if (!ee) continue;
+                u32 jp = 0;
+                for (int le = 0; le < ep.nfact; ++le) if (ep.fact[le].p == p) jp = (j / ep.fact[le].rts) % ep.fact[le].dim;
+                poss += jp * ipow((u32)p, es - ee) * sp.fact[l].rts;
+            }
+            table[(size_t)i * sp.n + poss] = (int32_t)posr;
+        }
+    }
+    return true;
+}
+
 }  // namespace alch

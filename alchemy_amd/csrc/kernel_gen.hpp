@@ -77,6 +77,8 @@ struct GenCall {
     size_t first_poly, npoly;
     size_t elem_stride;        // GEN_L .. GEN_DIVG_*: process every elem_stride-th ring element (1 = all; 2 = the c0 of ciphertexts)
     bool balanced;
+    bool with_diag;            // GEN_CRT_DIGITS: also transform the digits i == j (tunnel: no CRT copy of the source exists)
+    u32 skip_mask;             // GEN_L .. GEN_DIVG_*: bit l set = leave prime-power factor l alone (tunnel: partial lInv)
     bool zdom;                 // the ring's "modulus" is 0: signed 64-bit integers (Pow / Dec operations only)
     int* fail_flag;            // device int, set when a divG is not possible (Lol's Nothing)
 };
@@ -198,14 +200,14 @@ __global__ void __launch_bounds__(GEN_T) k_gen_crt(DevRing<W> R, GenDev<W> G, W*
 // workgroup = (ciphertext, source limb i, target limb j); the diagonal i == j is skipped (that digit is c2's own
 // limb j, which the caller kept in the CRT basis).
 template <typename W>
-__global__ void __launch_bounds__(GEN_T) k_gen_crt_digits(DevRing<W> R, GenDev<W> G, const W* __restrict__ c2pow, W* __restrict__ digits, int balanced) {
+__global__ void __launch_bounds__(GEN_T) k_gen_crt_digits(DevRing<W> R, GenDev<W> G, const W* __restrict__ c2pow, W* __restrict__ digits, int balanced, int with_diag) {
     typedef typename Signed<W>::type SW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W* lds = reinterpret_cast<W*>(smem);
     const int L = R.L;
     const size_t p = blockIdx.x;
     const int j = (int)(p % (size_t)L), i = (int)((p / (size_t)L) % (size_t)L);
-    if (i == j) return;
+    if (i == j && !with_diag) return;      // key switch: that digit is c2's own limb j, kept in the CRT basis by the caller
     const size_t ct = p / ((size_t)L * L);
     const u32 n = G.n;
     const W* src = c2pow + (ct * (size_t)L + i) * (size_t)n;
@@ -278,7 +280,7 @@ __device__ __forceinline__ void gen_column(W* __restrict__ x, u32 b, u32 s, int 
 }
 
 template <typename W, bool ZDOM, int OP>
-__global__ void __launch_bounds__(GEN_T) k_gen_columns(DevRing<W> R, GenDev<W> G, W* data, size_t first_elem, size_t elem_stride, int* fail_flag) {
+__global__ void __launch_bounds__(GEN_T) k_gen_columns(DevRing<W> R, GenDev<W> G, W* data, size_t first_elem, size_t elem_stride, int* fail_flag, u32 skip_mask) {
     typedef typename Signed<W>::type SW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W* lds = reinterpret_cast<W*>(smem);
@@ -292,7 +294,7 @@ __global__ void __launch_bounds__(GEN_T) k_gen_columns(DevRing<W> R, GenDev<W> G
     lds_barrier();
     for (int l = 0; l < G.nfact; ++l) {
         const GenFact f = G.fact[l];
-        if (f.p == 2) continue;
+        if (f.p == 2 || ((skip_mask >> l) & 1u)) continue;
         const u32 step = f.mp * f.rts, span = f.dim * f.rts, ncol = n / (u32)(f.p - 1);
         for (u32 c = threadIdx.x; c < ncol; c += GEN_T) {
             const u32 o = c / step, in = c % step;
@@ -329,7 +331,7 @@ inline hipError_t gen_launch_columns(const GenCall<W>& c, size_t lds_bytes) {
     hipError_t e = set_lds(k, lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(GEN_T), lds_bytes, c.stream, *c.ring, *c.gen, c.data, c.first_poly,
-                       c.elem_stride ? c.elem_stride : (size_t)1, c.fail_flag);
+                       c.elem_stride ? c.elem_stride : (size_t)1, c.fail_flag, c.skip_mask);
     return hipGetLastError();
 }
 
@@ -353,7 +355,7 @@ inline hipError_t gen_run(const GenCall<W>& c) {
     case GEN_CRT_DIGITS: {
         auto k = k_gen_crt_digits<W>;
         if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(GEN_T), lds_bytes, c.stream, *c.ring, *c.gen, c.src, c.data, c.balanced ? 1 : 0);
+        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(GEN_T), lds_bytes, c.stream, *c.ring, *c.gen, c.src, c.data, c.balanced ? 1 : 0, c.with_diag ? 1 : 0);
         break;
     }
     // npoly = number of (element, limb) workgroups; first_poly = first ELEMENT here

@@ -22,6 +22,7 @@ import Foreign.Ptr
 data AlchRing
 data AlchBuf
 data AlchHint
+data AlchTunnel
 
 foreign import ccall unsafe "alch_last_error"          c_lastError       :: IO CString
 foreign import ccall unsafe "alch_version"             c_version         :: IO Word32
@@ -91,6 +92,12 @@ foreign import ccall safe   "alch_buf_rescale_add0"    c_bufRescaleAdd0  :: Ptr 
 foreign import ccall safe   "alch_hint_load"           c_hintLoad        :: Ptr AlchRing -> CInt -> Ptr Int64 -> Ptr (Ptr AlchHint) -> IO CInt
 foreign import ccall safe   "alch_hint_from_buf"       c_hintFromBuf     :: Ptr AlchRing -> CInt -> Ptr AlchBuf -> Ptr (Ptr AlchHint) -> IO CInt
 foreign import ccall safe   "alch_hint_free"           c_hintFree        :: Ptr AlchHint -> IO CInt
+
+-- ring tunnelling (SymmSHE tunnel between PT2CT's two modSwitch_)
+foreign import ccall unsafe "alch_tunnel_info"         c_tunnelInfo      :: Ptr AlchRing -> Ptr AlchRing -> Ptr Word32 -> Ptr Word32 -> IO CInt
+foreign import ccall safe   "alch_tunnel_create"       c_tunnelCreate    :: Ptr AlchRing -> Ptr AlchRing -> Ptr AlchBuf -> Ptr AlchBuf -> Ptr (Ptr AlchTunnel) -> IO CInt
+foreign import ccall safe   "alch_tunnel_free"         c_tunnelFree      :: Ptr AlchTunnel -> IO CInt
+foreign import ccall safe   "alch_ct_tunnel"           c_ctTunnel        :: Ptr AlchTunnel -> Ptr AlchBuf -> Ptr AlchBuf -> CSize -> Ptr Word64 -> CUInt -> IO CInt
 
 -- the hot path: keySwitchQuadCirc hint (a * b), and PT2CT's whole mul_
 foreign import ccall safe   "alch_ct_mul_relin"        c_ctMulRelin      :: Ptr AlchRing -> Ptr AlchHint -> Ptr AlchBuf -> Ptr AlchBuf -> Ptr AlchBuf -> CSize -> Ptr Word64 -> CUInt -> IO CInt

@@ -65,6 +65,7 @@ extern "C" {
 typedef struct alch_ring alch_ring;
 typedef struct alch_buf alch_buf;
 typedef struct alch_hint alch_hint;
+typedef struct alch_tunnel alch_tunnel;
 
 /* flags of alch_ct_mul_relin */
 #define ALCH_POW_IN 1u             /* inputs are in the Pow basis (crt applied first)          */
@@ -246,6 +247,24 @@ int alch_ct_mul_relin(alch_ring *ring, const alch_hint *hint, const alch_buf *a,
  * flags: ALCH_POW_OUT leaves the result in the Pow basis (what Lol's rescale produces); operands are CRT basis. */
 int alch_ct_mul_full(const alch_hint *hint, const alch_buf *a, const alch_buf *b, alch_buf *out, size_t batch,
                      const uint64_t *s_pre, unsigned flags);
+
+/* ---- ring tunnelling ----------------------------------------------------------------
+ * SymmSHE `tunnel hint` as E runs it (Eval.hs:134) between PT2CT's two modSwitch_ (PT2CT.hs:224-229), with the hint of
+ * `tunnelHint f skout skin` (Crypto/Alchemy/Interpreter/KeysHints.hs:120-129); the linear functions of the reference are
+ * `linearDec` lists (examples/Common.hs:65-75), the hops switch1..5 (examples/Common.hs:78-95).
+ * ring_r = R'_q (input ciphertexts), ring_s = S'_q (hint and output), same moduli; E' = R' cap S' (index gcd), which must
+ * satisfy Lol's tunnel conditions (alch_tunnel_info reports E' and d_rel = dim R'/E', or ALCH_E_INVALID).
+ *   lin_crt : d_rel elements of ring_s, CRT basis: the values f'(d_i) of the E'-linear function on the relative decoding
+ *             basis of R'/E' (Lol: `extendLin (lift f)` reduced mod q), i in the order of Tensor `coeffs`
+ *   ks_crt  : 2 * d_rel * L elements of ring_s, CRT basis: for relative index i and TrivGad digit t the linear hint
+ *             (b, a) with b + a s_out = g_t f'(s_in p_i) + e   (p_i = relative powerful basis of R'/E'); order i, t, (b, a)
+ * alch_ct_tunnel: out[b] = (f'(c0), 0) + sum_i switch(hint_i, embed(coeffsPow(c1)_i)) for linear ciphertexts with k = 0
+ * (elements (2b, 2b+1)); s_pre = toMSD's per-limb scalar (NULL = 1).  CRT basis in and out unless ALCH_POW_IN /
+ * ALCH_POW_OUT.  Runs on ring_s's stream; the input is not modified. */
+int alch_tunnel_info(const alch_ring *ring_r, const alch_ring *ring_s, uint32_t *e_prime, uint32_t *d_rel);
+int alch_tunnel_create(alch_ring *ring_r, alch_ring *ring_s, const alch_buf *lin_crt, const alch_buf *ks_crt, alch_tunnel **out);
+int alch_tunnel_free(alch_tunnel *t);
+int alch_ct_tunnel(const alch_tunnel *t, const alch_buf *in, alch_buf *out, size_t batch, const uint64_t *s_pre, unsigned flags);
 
 /* ---- modSwitch building block (Eval.hs:130) ---------------------------------------
  * Rescale (a,b) -> b on Pow-basis elements: src lives in ring_src (L limbs), dst in ring_dst whose

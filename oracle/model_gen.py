@@ -569,3 +569,129 @@ def g_decrypt(sk, ct: GCT) -> List[int]:
         assert e is not None
     t = twace_pow_dec(e, ct.small, big)                     # Dec coefficients of the plaintext
     return [ct.l * v % ct.p for v in l_def(t, ct.small, ct.p)]
+
+
+# --------------------------------------------------------------------------------------
+# Ring tunnelling (SURVEY 8f N4): tunnel_ hint between two modSwitch_ (PT2CT.hs:224-229, Eval.hs:134), tunnelHint
+# (KeysHints.hs:120-129), linearDec / the five hops of examples/Common.hs:65-95.  Published algorithm: Crockett-Peikert
+# CCS'16 section 4.4 ("ring switching") / Lol's SymmSHE.tunnel:
+#   E = R cap S, E' = R' cap S'; f: R -> S is E-linear, given by its values y_i on the relative decoding basis of R/E
+#   (linearDec); it extends E'-linearly to f': R' -> S' with the same values (embedded).  For ct = (c0, c1) over R'_q (MSD,
+#   k = 0):      c0' = f'(c0) = sum_i y_i embed(coeffsDec(c0)_i)
+#                c1  = sum_i c1_i p_i   (c1_i in E': coefficients on the relative powerful basis of R'/E')
+#                result = (c0', 0) + sum_i switch(hint_i, embed(c1_i)),   hint_i encrypting f'(s_in p_i) under s_out.
+# The relative bases: for p^e | p^e', index j' of the big ring's axis = j1 + p^(e'-e) j with j the small ring's index and
+# j1 in [p^(e'-e)] the relative index (the same split for the Pow and the Dec basis -- both factor as relative (x) base,
+# which is why Lol's Tensor has ONE `coeffs`); a prime that does not divide the small index contributes its whole axis.
+# --------------------------------------------------------------------------------------
+
+def coeffs_indices(small: Index, big: Index) -> List[List[int]]:
+    """[relative index i][small index j] -> index into the big ring (Pow or Dec alike).  Relative indices are ordered as the
+    mixed radix of the per-prime relative indices, first prime outermost."""
+    assert big.m % small.m == 0
+    sp = dict(small.pps)
+    rel_dims = []
+    for p, eb in big.pps:
+        es = sp.get(p, 0)
+        rel_dims.append(p ** (eb - es) if es else (p - 1) * p ** (eb - 1))
+    nrel = 1
+    for d in rel_dims:
+        nrel *= d
+    assert nrel * small.n == big.n
+    out = []
+    for i in range(nrel):
+        rel, t = [], i
+        for d in reversed(rel_dims):
+            rel.append(t % d)
+            t //= d
+        rel.reverse()
+        row = []
+        for j in range(small.n):
+            js = dict(zip([p for p, _ in small.pps], small.unravel(j)))
+            idxb = []
+            for (p, eb), j1 in zip(big.pps, rel):
+                es = sp.get(p, 0)
+                idxb.append(j1 + p ** (eb - es) * js[p] if es else j1)
+            row.append(big.ravel(idxb))
+        out.append(row)
+    return out
+
+
+def coeffs(a: Sequence[int], small: Index, big: Index) -> List[List[int]]:
+    """Tensor `coeffs`: the small-ring coefficient vectors of a big-ring element w.r.t. the relative Pow (or Dec) basis."""
+    return [[a[pos] for pos in row] for row in coeffs_indices(small, big)]
+
+
+def eval_lin_dec(ys_pow, x_dec, e: Index, r: Index, s: Index, q: Optional[int]) -> List[int]:
+    """evalLin (linearDec ys) x: sum_i y_i * embed(coeffsDec(x)_i), x given by its Dec coefficients over R, ys (and the
+    result) as Pow coefficients over S.  embed of a Dec-basis element = embedPow of its Pow form."""
+    acc = [0] * s.n
+    for y, c in zip(ys_pow, coeffs(x_dec, e, r)):
+        emb = embed_pow(l_def(c, e, q), e, s)
+        pr = ring_mul_def(y, emb, s, q)
+        acc = [(u + v) % q if q else u + v for u, v in zip(acc, pr)]
+    return acc
+
+
+@dataclass
+class TunnelInfo:
+    e: Index
+    r: Index
+    s: Index
+    ep: Index
+    rp: Index
+    sp: Index
+
+
+def tunnel_indices(r: int, s: int, rp: int, sp: int) -> TunnelInfo:
+    """E = R cap S, E' = R' cap S' (index gcds), with Lol's side conditions: e = gcd(r, e') and lcm(r, e') = r', so that the
+    relative decoding basis of R/E is also one of R'/E' (extendLin)."""
+    import math
+    e, ep = math.gcd(r, s), math.gcd(rp, sp)
+    assert rp % r == 0 and sp % s == 0 and math.gcd(r, ep) == e and r * ep // e == rp, "indices do not form a tunnel"
+    return TunnelInfo(Index(e), Index(r), Index(s), Index(ep), Index(rp), Index(sp))
+
+
+def g_tunnel_hint(ys_pow_p, T: TunnelInfo, p: int, sk_in, sk_out, qs, rng: random.Random, bound: int = 2):
+    """tunnelHint f skout skin: (f' mod q as S'-elements, [hint_i]) with hint_i a TrivGad KSLinearHint for f'(s_in p_i),
+    p_i the relative powerful basis of R'/E'."""
+    ysz = [embed_pow([centred(v, p) for v in y], T.s, T.sp) for y in ys_pow_p]           # lift f, extend to S'
+    rows = coeffs_indices(T.ep, T.rp)
+    hints = []
+    for row in rows:
+        pi = [0] * T.rp.n
+        pi[row[0]] = 1                                                                   # relative Pow basis element
+        x = ring_mul_def(sk_in, pi, T.rp, None)                                          # s_in * p_i  over Z
+        val = eval_lin_dec(ysz, linv_def(x, T.rp, None), T.ep, T.rp, T.sp, None)         # f'(s_in p_i) over Z
+        hint_i = []
+        for g in gadget_triv(qs):
+            err = l_def(_small_dec(T.sp.n, bound, rng), T.sp, None)
+            a = [[rng.randrange(q) for _ in range(T.sp.n)] for q in qs]
+            b = []
+            for j, q in enumerate(qs):
+                as_ = ring_mul_def(a[j], sk_out, T.sp, q)
+                b.append([(g[j] * v + ev - w) % q for v, ev, w in zip(val, err, as_)])
+            hint_i.append([b, a])
+        hints.append(hint_i)
+    lin_q = [[[v % q for v in y] for q in qs] for y in ysz]
+    return lin_q, hints
+
+
+def g_tunnel(lin_q, hints, ct: GCT, T: TunnelInfo) -> GCT:
+    """SymmSHE.tunnel on a linear ciphertext with k = 0 (the state every ALCHEMY tunnel sees: PT2CT tunnels before it
+    multiplies, examples/HomomRLWR.hs:45-50)."""
+    ct = g_to_msd(ct)
+    assert ct.k == 0 and len(ct.c) == 2 and ct.big.m == T.rp.m
+    qs = ct.qs
+    c0 = []
+    for j, q in enumerate(qs):
+        c0.append(eval_lin_dec([y[j] for y in lin_q], linv_def(ct.c[0][j], T.rp, q), T.ep, T.rp, T.sp, q))
+    c1 = [[0] * T.sp.n for _ in qs]
+    c1parts = [coeffs(ct.c[1][j], T.ep, T.rp) for j in range(len(qs))]                  # [limb][i] -> E'-element (Pow)
+    for i, hint_i in enumerate(hints):
+        emb = [embed_pow(c1parts[j][i], T.ep, T.sp) for j in range(len(qs))]            # RNS element of S' (Pow)
+        for d, (b, a) in zip(decompose_triv(emb, qs), hint_i):
+            dr = [[v % q for v in d] for q in qs]
+            c0 = [[(u + v) % q for u, v in zip(cl, pl)] for cl, pl, q in zip(c0, rns_ring_mul(dr, b, T.sp, qs), qs)]
+            c1 = [[(u + v) % q for u, v in zip(cl, pl)] for cl, pl, q in zip(c1, rns_ring_mul(dr, a, T.sp, qs), qs)]
+    return GCT(MSD, 0, ct.l, [c0, c1], ct.p, qs, T.sp, T.s)

@@ -3,6 +3,8 @@
     python tests/golden/make_golden_general.py
 Outputs (all values are Python ints; ring elements limb-major [L][n], Pow basis unless the key says otherwise):
   general_tensor_small.json   per index m: one RNS element and the model's crt, l, lInv, mulGPow/Dec, divGPow/Dec, g_crt
+  tunnel_small.json           per tower (r, s, r', s'): linear function, tunnel hint, MSD input ciphertext over R'_q, SymmSHE.tunnel's
+                              output over S'_q, and f(pt)
   general_mul_small.json      per (m, m'): a valid SymmSHE instance -- secret key, two LSD encryptions, a TrivGad hint,
                               keySwitchQuadCirc(hint, a*b) on one ring and PT2CT's whole mul_ (2 -> 3 -> 1 limbs), with
                               the decryptions the model obtained
@@ -68,8 +70,33 @@ def mul_vectors():
     return out
 
 
+def tunnel_vectors():
+    """A valid tunnel instance per index tower: E-linear f given on the relative decoding basis, tunnelHint, an LSD
+    encryption, modSwitch up -> tunnel -> modSwitch down, and the decryption (= f(pt)) the model obtained."""
+    import math
+    rng = random.Random(20260403)
+    out = []
+    for r, s, rp, sp, p in ((8, 12, 40, 60, 4), (4, 6, 28, 42, 8)):
+        T = G.tunnel_indices(r, s, rp, sp)
+        qs = primes_1_mod(rp * sp // math.gcd(rp, sp), 3, 1 << 29)
+        sk_in, sk_out = G.g_gen_sk(T.rp, rng), G.g_gen_sk(T.sp, rng)
+        ys = [[rng.randrange(p) for _ in range(T.s.n)] for _ in range(T.r.n // T.e.n)]
+        pt = [rng.randrange(p) for _ in range(T.r.n)]
+        ct = G.g_to_msd(G.g_mod_switch_up(G.g_encrypt(sk_in, pt, T.r, T.rp, p, qs[1:], rng), qs[:1]))
+        lin_q, hints = G.g_tunnel_hint(ys, T, p, sk_in, sk_out, qs, rng)
+        tun = G.g_tunnel(lin_q, hints, ct, T)
+        down = G.g_mod_switch_down(tun, 1)
+        want = G.eval_lin_dec(ys, G.linv_def(pt, T.r, p), T.e, T.r, T.s, p)
+        assert G.g_decrypt(sk_out, down) == want
+        out.append({"r": r, "s": s, "rp": rp, "sp": sp, "ep": T.ep.m, "p": p, "qs": qs, "ys": ys, "pt": pt, "f_of_pt": want,
+                    "sk_in": sk_in, "sk_out": sk_out, "lin": lin_q, "hints": hints, "ct_in": ct.c, "ct_out": tun.c,
+                    "ct_out_l": tun.l})
+    return out
+
+
 if __name__ == "__main__":
-    for name, data in (("general_tensor_small.json", tensor_vectors()), ("general_mul_small.json", mul_vectors())):
+    for name, data in (("general_tensor_small.json", tensor_vectors()), ("general_mul_small.json", mul_vectors()),
+                       ("tunnel_small.json", tunnel_vectors())):
         with open(os.path.join(HERE, name), "w") as f:
             json.dump(data, f, separators=(",", ":"))
         print(name, os.path.getsize(os.path.join(HERE, name)), "bytes")

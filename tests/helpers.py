@@ -141,3 +141,32 @@ def oracle_full_mul_general(oracle_lib, m, qs_h, l_in, l_out, hint_crt, a0, a1, 
             cur = o_out.l(cur)
         out.append(cur if pow_out else o_out.crt(cur))
     return out[0], out[1]
+
+
+def oracle_tunnel(oracle_lib, r_p, s_p, qs, lin_crt, ks_crt, c0, c1, s_pre=None, pow_out=False):
+    """SymmSHE.tunnel (Eval.hs:134) on one linear ciphertext (k = 0), composed from the general C restatement's primitives and
+    the model's index maps -- following the definition literally: full lInv on R', Tensor `coeffs`, l on every E'-coefficient,
+    embedPow into S', crt, times f'(d_i); for c1: `coeffs` on the Pow basis, embedPow, TrivGad decompose, crt, hint products.
+    c0, c1: CRT basis over R' ((n_r, L)); lin_crt: d_rel CRT elements of S'; ks_crt: [(i * L + t) * 2 + {0: b, 1: a}]."""
+    import math
+    from oracle import model_gen as G
+    e_p = math.gcd(r_p, s_p)
+    ie, ir, isx = G.Index(e_p), G.Index(r_p), G.Index(s_p)
+    Or, Os, Oe = oracle_lib.GenRing(r_p, qs), oracle_lib.GenRing(s_p, qs), oracle_lib.GenRing(e_p, qs)
+    L = len(qs)
+    s = list(s_pre) if s_pre is not None else [1] * L
+    c0p, c1p = Or.scale(Or.crtinv(c0), s), Or.scale(Or.crtinv(c1), s)
+    c0d = Or.linv(c0p)
+    rows, emb = np.array(G.coeffs_indices(ie, ir)), np.array(G.embed_indices(ie, isx))
+    acc0, acc1 = np.zeros((isx.n, L), dtype=np.int64), np.zeros((isx.n, L), dtype=np.int64)
+    for i, row in enumerate(rows):
+        x = np.zeros((isx.n, L), dtype=np.int64)
+        x[emb] = Oe.l(np.ascontiguousarray(c0d[row]))
+        acc0 = Os.add(acc0, Os.mul(Os.crt(x), lin_crt[i]))
+        x1 = np.zeros((isx.n, L), dtype=np.int64)
+        x1[emb] = c1p[row]
+        for t, d in enumerate(Os.decompose_triv(x1)):
+            dc = Os.crt(d)
+            acc0 = Os.add(acc0, Os.mul(dc, ks_crt[(i * L + t) * 2]))
+            acc1 = Os.add(acc1, Os.mul(dc, ks_crt[(i * L + t) * 2 + 1]))
+    return (Os.crtinv(acc0), Os.crtinv(acc1)) if pow_out else (acc0, acc1)

@@ -1,0 +1,72 @@
+"""GPU: ring tunnelling through the C ABI (alch_tunnel_create / alch_ct_tunnel): the model-generated fixture
+(valid hints, the output decrypts to f(pt)) bit for bit, and the reference's first hop switch1 = H0' -> H1'
+(F11648 -> F29120, examples/Common.hs:49-50,78-80) at full size against the C restatement's composition."""
+import math
+
+import numpy as np
+import pytest
+
+import alchemy_amd as A
+from alchemy_amd import capi
+from helpers import load_golden, oracle_tunnel, primes_1_mod, to_aos
+
+pytestmark = pytest.mark.gpu
+
+RLWR_QS = [1543651201, 689270401, 718099201, 720720001, 1556755201, 1567238401]
+
+
+def rand_elems(rng, count, n, qs):
+    return np.stack([np.stack([rng.integers(0, q, size=n, dtype=np.int64) for q in qs], axis=1) for _ in range(count)])
+
+
+def test_tunnel_fixture():
+    lm = lambda a: np.asarray(a).T.tolist()
+    for rec in load_golden("tunnel_small.json"):
+        qs = rec["qs"]
+        gr, gs = A.Ring(rec["rp"], qs), A.Ring(rec["sp"], qs)
+        assert A.Tunnel.info(gr, gs) == (rec["ep"], len(rec["lin"]))
+        lin = gs.upload(np.stack([to_aos(y) for y in rec["lin"]]))
+        ks = gs.upload(np.stack([to_aos(x) for hint_i in rec["hints"] for pair in hint_i for x in pair]))
+        lin.crt(); ks.crt()
+        tun = A.Tunnel(gr, gs, lin, ks)
+        cin = gr.upload(np.stack([to_aos(c) for c in rec["ct_in"]]))
+        cout = gs.alloc(2)
+        tun.apply(cin, cout, 1, flags=capi.ALCH_POW_IN | capi.ALCH_POW_OUT)
+        got = cout.download()
+        assert lm(got[0]) == rec["ct_out"][0] and lm(got[1]) == rec["ct_out"][1], (rec["rp"], rec["sp"])
+        assert np.array_equal(cin.download(), np.stack([to_aos(c) for c in rec["ct_in"]]))      # input untouched
+
+
+@pytest.mark.parametrize("rp,sp,L,batch", [(40, 60, 2, 3), (63, 105, 3, 2), (11648, 29120, 6, 3), (27300, 20475, 5, 2)])
+def test_tunnel_hop_matches_the_oracle(oracle_lib, rp, sp, L, batch):
+    """switch1 (H0' -> H1', six limbs: SURVEY 3.3 'tunnels switch1-4: hint on 6') and switch5 (H4' -> H5', five limbs) at
+    full size, random linear function / hints / ciphertexts (parity does not need them valid)."""
+    qs = RLWR_QS[:L] if rp > 1000 else primes_1_mod(rp * sp // math.gcd(rp, sp), L, 1 << 29)
+    gr, gs = A.Ring(rp, qs), A.Ring(sp, qs)
+    ep, d_rel = A.Tunnel.info(gr, gs)
+    assert ep == math.gcd(rp, sp) and d_rel * (gs.n * 0 + 1) >= 1
+    rng = np.random.default_rng(rp)
+    lin, ks = rand_elems(rng, d_rel, gs.n, qs), rand_elems(rng, 2 * d_rel * L, gs.n, qs)
+    cts = rand_elems(rng, 2 * batch, gr.n, qs)
+    s_pre = [int(rng.integers(1, q)) for q in qs]
+    tun = A.Tunnel(gr, gs, gs.upload(lin), gs.upload(ks))
+    gin, gout = gr.upload(cts), gs.alloc(2 * batch)
+    tun.apply(gin, gout, batch, s_pre=s_pre)
+    got = gout.download()
+    for ct in range(batch):
+        w0, w1 = oracle_tunnel(oracle_lib, rp, sp, qs, list(lin), list(ks), cts[2 * ct], cts[2 * ct + 1], s_pre)
+        assert np.array_equal(got[2 * ct], w0) and np.array_equal(got[2 * ct + 1], w1), ct
+
+
+def test_tunnel_argument_checks():
+    qs = primes_1_mod(40 * 60, 3, 1 << 29)
+    gr, gs, gs2 = A.Ring(40, qs[:2]), A.Ring(60, qs[:2]), A.Ring(60, qs[1:])
+    assert A.Tunnel.info(gr, gs) == (20, 2)
+    lin, ks = gs.alloc(2), gs.alloc(8)
+    with pytest.raises(A.AlchemyError):
+        A.Tunnel(gr, gs2, gs2.alloc(2), gs2.alloc(8))         # different moduli
+    with pytest.raises(A.AlchemyError):
+        A.Tunnel(gr, gs, lin, gs.alloc(7))                    # too few hint elements
+    t = A.Tunnel(gr, gs, lin, ks)
+    with pytest.raises(A.AlchemyError):
+        t.apply(gs.alloc(2), gs.alloc(2), 1)                  # input must live in R'

@@ -12,6 +12,7 @@ CTYPE = {  # C parameter type (qualifiers stripped) -> Haskell FFI type
     "uint64_t*": "Ptr Word64", "uint32_t*": "Ptr Word32", "int*": "Ptr CInt", "size_t*": "Ptr CSize",
     "float*": "Ptr CFloat", "int64_t*": "Ptr Int64", "void*": "Ptr ()", "void**": "Ptr (Ptr ())",
     "alch_ring*": "Ptr AlchRing", "alch_buf*": "Ptr AlchBuf", "alch_hint*": "Ptr AlchHint",
+    "alch_tunnel*": "Ptr AlchTunnel", "alch_tunnel**": "Ptr (Ptr AlchTunnel)",
     "alch_ring**": "Ptr (Ptr AlchRing)", "alch_buf**": "Ptr (Ptr AlchBuf)", "alch_hint**": "Ptr (Ptr AlchHint)",
 }
 RET = {"int": "IO CInt", "uint32_t": "IO Word32", "const char*": "IO CString"}
