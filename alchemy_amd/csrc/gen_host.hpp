@@ -2,6 +2,7 @@
 // Lol computes the corresponding twiddles in Haskell and hands lol-cpp raw pointers on every call; here they are
 // built once per ring from the documented root rule and stay device-resident.
 #pragma once
+#include <algorithm>
 #include <string>
 #include <vector>
 #include "kernel_gen.hpp"
@@ -52,28 +53,41 @@ inline bool gen_plan(u32 m, GenHost& g) {
         f.dim = (u32)(f.p - 1) * f.mp;
         n *= f.dim;
     }
-    if (n > (1u << 20)) { g.error = "ring dimension too large"; return false; }
+    if (n > 65535) { g.error = "ring dimension too large (the pass engine indexes with 16-bit quantities)"; return false; }
     g.n = (u32)n;
     u32 s = g.n;
     for (int l = 0; l < g.nfact; ++l) { s /= g.fact[l].dim; g.fact[l].rts = s; }
     u32 off = 0;
-    auto push = [&](int kind, int r, u32 stride, const GenFact& f, bool mat, bool tw) {
+    auto rcp = [](u32 d) { return d <= 1 ? 0u : (u32)(((u64)1 << 32) / d) + 1u; };
+    // mat_words: size of the pass's own table; tw_off: 0xffffffff = no twiddles, 0xfffffffe = allocate f.dim words, else shared
+    auto push = [&](int kind, int r, int aux, u32 stride, const GenFact& f, u32 mat_words, u32 tw_off) {
         if (g.npass == GEN_MAXPASS) { g.error = "too many passes"; return false; }
         GenPass& P = g.pass[g.npass++];
-        P.kind = kind; P.r = r; P.stride = stride; P.axis_stride = f.rts; P.axis_len = f.dim;
-        P.mat_off = off; if (mat) off += (u32)(r * r);
-        P.tw_off = tw ? off : 0xffffffffu; if (tw) off += f.dim;
+        P.kind = kind; P.r = r; P.aux = aux; P.stride = stride; P.axis_stride = f.rts; P.axis_len = f.dim;
+        P.mat_off = off; off += mat_words;
+        if (tw_off == 0xfffffffeu) { P.tw_off = off; off += f.dim; } else P.tw_off = tw_off;
+        P.rcp_stride = rcp(P.stride); P.rcp_axis_stride = rcp(P.axis_stride); P.rcp_axis_len = rcp(P.axis_len);
         return true;
     };
     for (int l = 0; l < g.nfact; ++l) {
         const GenFact& f = g.fact[l];
         if (f.p == 2) {
-            for (u32 t = f.dim / 2; t >= 1; t /= 2)
-                if (!push(GK_RADIX2, 2, t * f.rts, f, false, true)) return false;
+            int a = 0;
+            while ((1u << a) < f.dim) ++a;                       // dim = 2^a stages
+            if (a == 0) continue;
+            const u32 tw = off;                                  // one table tw[k] = psi^brev(k), k < dim, for every block
+            off += f.dim;
+            for (int s0 = 0; s0 < a;) {
+                const int K = std::min(3, a - s0);
+                const u32 t_last = f.dim >> (s0 + K);
+                if (!push(GK_R2BLOCK, 1 << K, s0, t_last * f.rts, f, 0, tw)) return false;
+                s0 += K;
+            }
         } else {
-            if (!push(GK_DENSE, f.p - 1, f.mp * f.rts, f, true, false)) return false;
+            const u32 h = (u32)(f.p - 1) / 2, sym_words = 2 * h * h + (u32)f.p;
+            if (!push(GK_SYM_CRT, f.p - 1, 0, f.mp * f.rts, f, sym_words, 0xffffffffu)) return false;
             for (u32 B = f.mp; B > 1; B /= (u32)f.p)
-                if (!push(GK_DENSE, f.p, (B / (u32)f.p) * f.rts, f, true, true)) return false;
+                if (!push(GK_SYM_DFT, f.p, 0, (B / (u32)f.p) * f.rts, f, sym_words, 0xfffffffeu)) return false;
         }
     }
     g.block_words = off ? off : 1;
@@ -118,43 +132,49 @@ inline bool gen_tables(const GenHost& g, u64 q, std::vector<u64>& fwd, std::vect
         std::vector<u64> pw(pe), pwi(pe);
         { u64 a = 1, b = 1; for (u32 t = 0; t < pe; ++t) { pw[t] = a; pwi[t] = b; a = h_mulmod(a, w, q); b = h_mulmod(b, wi, q); } }
         if (p == 2) {
-            // merged-twiddle Cooley-Tukey: stage s (t = dim / 2^(s+1)), group gidx = pos / (2t): the upper element
-            // (pos / t odd) is multiplied by psi^brev(2^s + gidx), psi = omega_{2^e}, brev on log2(dim) bits
+            // tw[k] = psi^brev(k) on log2(dim) bits, psi = omega_{2^e}: stage s, group gidx uses tw[2^s + gidx]
             int lg = 0;
             while ((1u << lg) < f.dim) ++lg;
-            int s = 0;
-            for (u32 t = f.dim / 2; t >= 1; t /= 2, ++s, ++ps) {
-                const GenPass& P = g.pass[ps];
-                for (u32 pos = 0; pos < f.dim; ++pos) {
-                    const u32 gidx = pos / (2 * t);
-                    const u32 e = h_brev((1u << s) + gidx, lg);
-                    fwd[P.tw_off + pos] = pw[e % pe];
-                    inv[P.tw_off + pos] = pwi[e % pe];
-                }
-                iscale = h_mulmod(iscale, h_invmod(2, q), q);
+            if (lg == 0) continue;
+            const u32 tw_off = g.pass[ps].tw_off;
+            for (u32 k = 0; k < f.dim; ++k) {
+                const u32 e = h_brev(k, lg);
+                fwd[tw_off + k] = pw[e % pe];
+                inv[tw_off + k] = pwi[e % pe];
             }
+            for (int st = 0; st < lg; ++st) iscale = h_mulmod(iscale, h_invmod(2, q), q);
+            while (ps < g.npass && g.pass[ps].kind == GK_R2BLOCK && g.pass[ps].tw_off == tw_off) ++ps;
             continue;
         }
-        {   // CRT_p[i0-1][j0] = omega_p^(i0 j0), omega_p = omega_{p^e}^(m')
-            const GenPass& P = g.pass[ps++];
-            const int d = (int)p - 1;
-            std::vector<u64> M((size_t)d * d);
-            for (int i0 = 1; i0 < (int)p; ++i0)
-                for (int j0 = 0; j0 < d; ++j0) M[(size_t)(i0 - 1) * d + j0] = pw[(size_t)(((u64)i0 * j0) % p) * f.mp];
-            for (size_t k = 0; k < M.size(); ++k) fwd[P.mat_off + k] = M[k];
-            if (!h_mat_inv(M, d, q)) return false;
-            for (size_t k = 0; k < M.size(); ++k) inv[P.mat_off + k] = M[k];
-        }
+        // symmetric tables of omega_p = omega_{p^e}^(m'):  a_ij = (w^ij + w^-ij)/2, b_ij = (w^ij - w^-ij)/2  (i, j = 1..h)
+        const u32 h = (p - 1) / 2;
+        const u64 half = h_invmod(2, q), pinv = h_invmod(p, q);
+        auto wp = [&](u64 e) { return pw[(size_t)(e % p) * f.mp]; };
+        auto wpi = [&](u64 e) { return pwi[(size_t)(e % p) * f.mp]; };
+        auto fill_sym = [&](const GenPass& P) {
+            for (u32 i = 1; i <= h; ++i)
+                for (u32 j = 1; j <= h; ++j) {
+                    const u64 c = h_mulmod((wp((u64)i * j) + wpi((u64)i * j)) % q, half, q);
+                    const u64 sn = h_mulmod((wp((u64)i * j) + q - wpi((u64)i * j)) % q, half, q);
+                    fwd[P.mat_off + (i - 1) * h + (j - 1)] = c;
+                    fwd[P.mat_off + h * h + (i - 1) * h + (j - 1)] = sn;
+                    // inverse: w -> w^-1 (the cosine part is even, the sine part changes sign) and 1/p
+                    inv[P.mat_off + (i - 1) * h + (j - 1)] = h_mulmod(c, pinv, q);
+                    inv[P.mat_off + h * h + (i - 1) * h + (j - 1)] = h_mulmod((q - sn) % q, pinv, q);
+                }
+            for (u32 i = 1; i < p; ++i) {                       // inverse CRT_p: y_0 = sum_i y_i (-w^i)
+                fwd[P.mat_off + 2 * h * h + (i - 1)] = 0;
+                inv[P.mat_off + 2 * h * h + (i - 1)] = (q - wp(i)) % q;
+            }
+            fwd[P.mat_off + 2 * h * h + (p - 1)] = 1;
+            inv[P.mat_off + 2 * h * h + (p - 1)] = pinv;
+        };
+        fill_sym(g.pass[ps++]);                                  // CRT_p
         bool first = true;
         u32 Bprev = 0;
         for (u32 B = f.mp; B > 1; B /= p, ++ps) {
             const GenPass& P = g.pass[ps];
-            const u64 pinv = h_invmod(p, q);
-            for (u32 a = 0; a < p; ++a)
-                for (u32 b = 0; b < p; ++b) {
-                    fwd[P.mat_off + a * p + b] = pw[(size_t)((a * b) % p) * f.mp];
-                    inv[P.mat_off + a * p + b] = h_mulmod(pwi[(size_t)((a * b) % p) * f.mp], pinv, q);
-                }
+            fill_sym(P);
             // twiddles in front of this stage, by axis position a = (i0 - 1) m' + j1:
             //   first stage: T = omega_{p^e}^(i0 j1);  later stages: the previous stage's omega_{Bprev}^(fq off)
             for (u32 i0 = 1; i0 < p; ++i0)

@@ -7,10 +7,11 @@
 //   ascending, first factor outermost; every operator is a Kronecker product of per-factor operators, so it runs as a
 //   sequence of PASSES, each applying one small operator along one strided sub-axis of the whole array:
 //     CRT_{p^e} = (DFT_{m'} (x) I_{p-1}) . T . (I_{m'} (x) CRT_p)        m' = p^(e-1)
-//       pass "dense p-1":  CRT_p[i0-1][j0] = w_p^(i0 j0) along j0                         (odd p only)
-//       passes "dense p":  DFT_{m'} as e-1 radix-p decimation-in-frequency stages; T and the stage twiddles are
-//                          per-axis-position tables multiplied in front of the stage that follows them
-//       p = 2:             the merged-twiddle Cooley-Tukey stages of the two-power engine (one product per butterfly)
+//       pass "CRT_p":  CRT_p[i0-1][j0] = w_p^(i0 j0) along j0, computed through the +/- symmetry of the roots (odd p only)
+//       passes "DFT_p": DFT_{m'} as e-1 radix-p decimation-in-frequency stages; T and the stage twiddles are
+//                       per-axis-position tables multiplied in front of the stage that follows them
+//       p = 2:          the merged-twiddle Cooley-Tukey stages of the two-power engine, up to three per pass on
+//                       register-resident groups of eight (one product per butterfly)
 //     L_{p^e} = L_p (x) I_{m'}, G_{p^e} = G_p (x) I_{m'}: column recurrences of length p-1 (prefix sums / differences)
 //
 // Mapping to CDNA4.  phi(m) <= 11520 for every index of the reference, so one limb-polynomial (46 KiB of 32-bit
@@ -29,17 +30,27 @@ constexpr int GEN_MAXPASS = 24;
 constexpr int GEN_MAXFACT = 8;
 constexpr int GEN_T = 256;                  // threads per workgroup of every kernel in this file
 
-enum GenKind : int { GK_DENSE = 0, GK_RADIX2 = 1 };
+enum GenKind : int {
+    GK_R2BLOCK = 1,    // K <= 3 merged-twiddle Cooley-Tukey stages of a two-power axis on register-resident groups of 2^K
+    GK_SYM_CRT = 2,    // CRT_p (p odd, r = p - 1) through the +/- symmetry of the roots: half the products of a dense matrix
+    GK_SYM_DFT = 3     // DFT_p (r = p) the same way, behind a per-axis-position twiddle table
+};
 
 struct GenPass {
-    int kind;          // GK_DENSE: r x r matrix along the sub-axis; GK_RADIX2: one merged-twiddle butterfly stage
+    int kind;
     int r;             // group size
+    int aux;           // GK_R2BLOCK: index s0 of the block's first stage
     u32 stride;        // distance between consecutive elements of a group
     u32 axis_stride;   // stride of the prime-power axis the pass belongs to (its rts)
     u32 axis_len;      // phi(p^e): twiddle tables are indexed by the position along that axis
     u32 mat_off;       // offset of the r*r matrix inside a limb's table block (forward and inverse blocks alike)
     u32 tw_off;        // offset of the axis_len twiddles, or 0xffffffff
+    u32 rcp_stride, rcp_axis_stride, rcp_axis_len;   // floor(2^32 / d) + 1: w / d == mulhi(w, rcp) for w, d < 2^16
 };
+
+// Exact w / d for w * d < 2^32 (every index here is below phi(m) <= 40960 < 2^16): one v_mul_hi instead of a runtime
+// division (~30 VALU instructions on gfx950), four of which a pass would otherwise pay per group.
+__device__ __forceinline__ u32 fdiv(u32 w, u32 d, u32 rcp) { return d == 1 ? w : __umulhi(w, rcp); }
 
 struct GenFact { int p, e; u32 mp, dim, rts; };
 
@@ -89,76 +100,197 @@ hipError_t gen_dispatch(const GenCall<u64>& c);
 // ------------------------------------------------------------------------------------------------------
 // passes
 // ------------------------------------------------------------------------------------------------------
-// y = M (tw . x) along one sub-axis (forward) or y = twinv . (Minv x) (inverse).  Values canonical in [0, q).
-template <typename W, int R, bool INV>
-__device__ __forceinline__ void gen_dense_pass(W* __restrict__ lds, const GenPass& P, const W* __restrict__ tab, u32 n, W q, W qni) {
-    const W* __restrict__ M = tab + P.mat_off;
-    const bool has_tw = P.tw_off != 0xffffffffu;
-    const W* __restrict__ tw = tab + (has_tw ? P.tw_off : 0u);
-    const u32 step = P.stride / P.axis_stride;
-    for (u32 w = threadIdx.x; w < n / (u32)R; w += GEN_T) {
-        const u32 lo = w % P.stride, hi = w / P.stride;
-        const u32 base = hi * (u32)R * P.stride + lo;
-        const u32 pos0 = (base / P.axis_stride) % P.axis_len;
-        W x[R], y[R];
+// sum_t x[t] * M[t] (Montgomery: M holds M R) for canonical x, M < q < 2^31.
+// 32-bit words: four products are summed in 64 bits before one reduction -- 4 q^2 < 2^64, the sum's high word is < 2q, one
+// conditional subtraction brings the sum below q 2^32, then a single Montgomery reduction: 10 instructions per four terms
+// instead of 20.  64-bit words: one product at a time.
+template <int R>
+__device__ __forceinline__ u32 dense_row(const u32* x, const u32* __restrict__ M, u32 q, u32 qni) {
+    u32 acc = 0;
 #pragma unroll
-        for (int t = 0; t < R; ++t) x[t] = lds[base + (u32)t * P.stride];
-        if (!INV && has_tw) {
+    for (int t0 = 0; t0 < R; t0 += 4) {
+        u64 p = (u64)x[t0] * M[t0];
 #pragma unroll
-            for (int t = 0; t < R; ++t) x[t] = csub(mont_mul_lazy(x[t], tw[pos0 + (u32)t * step], q, qni), q);
-        }
+        for (int t = t0 + 1; t < t0 + 4 && t < R; ++t) p += (u64)x[t] * M[t];
+        const u64 pr = ((u64)csub((u32)(p >> 32), q) << 32) | (u32)p;          // high word < 2q -> < q
+        const u32 m = (u32)pr * qni;
+        const u32 v = csub((u32)((pr + (u64)m * q) >> 32), q);
+        acc = t0 ? csub(acc + v, q) : v;
+    }
+    return acc;
+}
+template <int R>
+__device__ __forceinline__ u64 dense_row(const u64* x, const u64* __restrict__ M, u64 q, u64 qni) {
+    u64 acc = csub(mont_mul_lazy(x[0], M[0], q, qni), q);
 #pragma unroll
-        for (int s = 0; s < R; ++s) {
-            W acc = csub(mont_mul_lazy(x[0], M[s * R], q, qni), q);
+    for (int t = 1; t < R; ++t) acc = csub(acc + csub(mont_mul_lazy(x[t], M[t], q, qni), q), q);
+    return acc;
+}
+template <typename W> __device__ __forceinline__ W gadd(W a, W b, W q) { return csub((W)(a + b), q); }
+template <typename W> __device__ __forceinline__ W gsub(W a, W b, W q) { return csub((W)(a + (q - b)), q); }
+template <typename W> __device__ __forceinline__ W gmul(W a, W b, W q, W qni) { return csub(mont_mul_lazy(a, b, q, qni), q); }
+
+// CRT_p and DFT_p through the symmetry  w^(i (p-j)) = w^(-i j):  with u_j = x_j + x_{p-j}, v_j = x_j - x_{p-j} (j = 1..h,
+// h = (p-1)/2), a_ij = (w^ij + w^-ij)/2, b_ij = (w^ij - w^-ij)/2:
+//     y_i = A_i + B_i,  y_{p-i} = A_i - B_i,   A_i = x_0 + sum_j a_ij u_j,   B_i = sum_j b_ij v_j        (i = 1..h)
+// i.e. 2 h^2 products for p - 1 outputs instead of (p-1)^2.  Table of a pass (same layout in the forward and inverse block):
+//     a[h*h], b[h*h], negw[p-1], pinv      (negw, pinv: inverse CRT_p only / inverse passes only)
+//   forward CRT_p : inputs x_0..x_{p-2} (x_{p-1} = 0), outputs y_1..y_{p-1} at slots 0..p-2
+//   inverse CRT_p : y_0 = -sum_i y_i w^i (the condition x_{p-1} = 0), then the inverse DFT_p (w -> w^-1, a, b, carry 1/p)
+//   forward DFT_p : y_0 = sum_j x_j as well;  inverse DFT_p : the same with w^-1 and 1/p
+template <typename W, int P, bool IS_DFT, bool INV>
+__device__ __forceinline__ void sym_apply(W* x /* in/out: R = IS_DFT ? P : P-1 values */, const W* __restrict__ T, W q, W qni) {
+    constexpr int H = (P - 1) / 2, R = IS_DFT ? P : P - 1;
+    const W* __restrict__ a = T;
+    const W* __restrict__ b = T + H * H;
+    W in[P];                                   // the full length-p input of the DFT_p behind the pass
+    if (!IS_DFT && !INV) {
 #pragma unroll
-            for (int t = 1; t < R; ++t) acc = csub(acc + csub(mont_mul_lazy(x[t], M[s * R + t], q, qni), q), q);
-            y[s] = acc;
-        }
-        if (INV && has_tw) {
+        for (int t = 0; t < P - 1; ++t) in[t] = x[t];
+        in[P - 1] = 0;
+    } else if (!IS_DFT && INV) {
+        in[0] = dense_row<P - 1>(x, T + 2 * H * H, q, qni);                       // y_0 = sum_i y_i (-w^i)
 #pragma unroll
-            for (int s = 0; s < R; ++s) y[s] = csub(mont_mul_lazy(y[s], tw[pos0 + (u32)s * step], q, qni), q);
-        }
+        for (int t = 1; t < P; ++t) in[t] = x[t - 1];
+    } else {
 #pragma unroll
-        for (int s = 0; s < R; ++s) lds[base + (u32)s * P.stride] = y[s];
+        for (int t = 0; t < P; ++t) in[t] = x[t];
+    }
+    W u[H], v[H];
+#pragma unroll
+    for (int j = 1; j <= H; ++j) { u[j - 1] = gadd(in[j], in[P - j], q); v[j - 1] = gsub(in[j], in[P - j], q); }
+    W u0 = in[0], sum = in[0];
+#pragma unroll
+    for (int j = 0; j < H; ++j) sum = gadd(sum, u[j], q);
+    if (INV) {                                 // 1/p rides on a, b; the constant terms take it explicitly
+        const W pinv = T[2 * H * H + (P - 1)];
+        u0 = gmul(u0, pinv, q, qni);
+        sum = gmul(sum, pinv, q, qni);
+    }
+    W out[P];
+    out[0] = sum;
+#pragma unroll
+    for (int i = 1; i <= H; ++i) {
+        const W A = gadd(u0, dense_row<H>(u, a + (i - 1) * H, q, qni), q);
+        const W B = dense_row<H>(v, b + (i - 1) * H, q, qni);
+        out[i] = gadd(A, B, q);
+        out[P - i] = gsub(A, B, q);
+    }
+    if (!IS_DFT && !INV) {
+#pragma unroll
+        for (int t = 0; t < P - 1; ++t) x[t] = out[t + 1];                    // rows 1..p-1
+    } else {
+#pragma unroll
+        for (int t = 0; t < R; ++t) x[t] = out[t];                            // inverse CRT_p: x_{p-1} = 0 is dropped
     }
 }
 
-// one Cooley-Tukey stage on a two-power axis: (x, y) -> (x + w y, x - w y), w = tw[axis position of y];
-// inverse: (x, y) -> (x + y, (x - y) w^-1), the factor 1/2 is collected in GenDev::iscale_m.
-template <typename W, bool INV>
-__device__ __forceinline__ void gen_radix2_pass(W* __restrict__ lds, const GenPass& P, const W* __restrict__ tab, u32 n, W q, W qni) {
-    const W* __restrict__ tw = tab + P.tw_off;
-    for (u32 w = threadIdx.x; w < n / 2u; w += GEN_T) {
-        const u32 lo = w % P.stride, hi = w / P.stride;
-        const u32 ix = hi * 2u * P.stride + lo, iy = ix + P.stride;
-        const W tv = tw[(iy / P.axis_stride) % P.axis_len];
-        const W x = lds[ix], y = lds[iy];
-        if (!INV) {
-            const W t = csub(mont_mul_lazy(y, tv, q, qni), q);
-            lds[ix] = csub(x + t, q);
-            lds[iy] = csub(x + (q - t), q);
-        } else {
-            lds[ix] = csub(x + y, q);
-            lds[iy] = csub(mont_mul_lazy((W)(x + (q - y)), tv, q, qni), q);
+template <typename W, int P, bool IS_DFT, bool INV>
+__device__ __forceinline__ void gen_sym_pass(W* __restrict__ lds, const GenPass& Ps, const W* __restrict__ tab, u32 n, W q, W qni) {
+    constexpr int R = IS_DFT ? P : P - 1;
+    const W* __restrict__ T = tab + Ps.mat_off;
+    const bool has_tw = Ps.tw_off != 0xffffffffu;
+    const W* __restrict__ tw = tab + (has_tw ? Ps.tw_off : 0u);
+    const u32 step = fdiv(Ps.stride, Ps.axis_stride, Ps.rcp_axis_stride);
+    for (u32 w = threadIdx.x; w < n / (u32)R; w += GEN_T) {
+        const u32 hi = fdiv(w, Ps.stride, Ps.rcp_stride), lo = w - hi * Ps.stride;
+        const u32 base = hi * (u32)R * Ps.stride + lo;
+        W x[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) x[t] = lds[base + (u32)t * Ps.stride];
+        u32 pos0 = 0;
+        if (has_tw) {
+            const u32 a = fdiv(base, Ps.axis_stride, Ps.rcp_axis_stride);
+            pos0 = a - fdiv(a, Ps.axis_len, Ps.rcp_axis_len) * Ps.axis_len;
         }
+        if (!INV && has_tw) {
+#pragma unroll
+            for (int t = 0; t < R; ++t) x[t] = gmul(x[t], tw[pos0 + (u32)t * step], q, qni);
+        }
+        sym_apply<W, P, IS_DFT, INV>(x, T, q, qni);
+        if (INV && has_tw) {
+#pragma unroll
+            for (int t = 0; t < R; ++t) x[t] = gmul(x[t], tw[pos0 + (u32)t * step], q, qni);
+        }
+#pragma unroll
+        for (int t = 0; t < R; ++t) lds[base + (u32)t * Ps.stride] = x[t];
+    }
+}
+
+// K merged-twiddle Cooley-Tukey stages (s0 .. s0+K-1) of a two-power axis on register-resident groups of 2^K points
+// (element k of a group at base + k stride).  Stage s0 + r uses the 2^r table entries tw[(gm << r) + c], gm = 2^s0 + group
+// index -- the table is tw[k] = psi^brev(k), exactly the two-power engine's.  Inverse: Gentleman-Sande, the stages backwards with
+// tw^-1; the factor 2^-K is collected in GenDev::iscale_m.
+template <typename W, int K, bool INV>
+__device__ __forceinline__ void gen_r2block_pass(W* __restrict__ lds, const GenPass& P, const W* __restrict__ tab, u32 n, W q, W qni) {
+    constexpr int R = 1 << K;
+    const W* __restrict__ tw = tab + P.tw_off;
+    const u32 smask = (1u << P.aux) - 1u;
+    for (u32 w = threadIdx.x; w < n / (u32)R; w += GEN_T) {
+        const u32 hi = fdiv(w, P.stride, P.rcp_stride), lo = w - hi * P.stride;
+        const u32 base = hi * (u32)R * P.stride + lo;
+        const u32 gm = (1u << P.aux) + (hi & smask);
+        W x[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) x[k] = lds[base + (u32)k * P.stride];
+        if (!INV) {
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+                const int half = R >> (r + 1);
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    if (k & half) continue;
+                    const W t = gmul(x[k + half], tw[(gm << r) + (u32)(k >> (K - r))], q, qni);
+                    const W a = x[k];
+                    x[k] = gadd(a, t, q);
+                    x[k + half] = gsub(a, t, q);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = K - 1; r >= 0; --r) {
+                const int half = R >> (r + 1);
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    if (k & half) continue;
+                    const W a = x[k], b = x[k + half];
+                    x[k] = gadd(a, b, q);
+                    x[k + half] = gmul(gsub(a, b, q), tw[(gm << r) + (u32)(k >> (K - r))], q, qni);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) lds[base + (u32)k * P.stride] = x[k];
     }
 }
 
 template <typename W, bool INV>
 __device__ __forceinline__ void gen_run_pass(W* lds, const GenPass& P, const W* tab, u32 n, W q, W qni) {
-    if (P.kind == GK_RADIX2) { gen_radix2_pass<W, INV>(lds, P, tab, n, q, qni); return; }
-    switch (P.r) {                                 // wave-uniform
-    case 2: gen_dense_pass<W, 2, INV>(lds, P, tab, n, q, qni); break;
-    case 3: gen_dense_pass<W, 3, INV>(lds, P, tab, n, q, qni); break;
-    case 4: gen_dense_pass<W, 4, INV>(lds, P, tab, n, q, qni); break;
-    case 5: gen_dense_pass<W, 5, INV>(lds, P, tab, n, q, qni); break;
-    case 6: gen_dense_pass<W, 6, INV>(lds, P, tab, n, q, qni); break;
-    case 7: gen_dense_pass<W, 7, INV>(lds, P, tab, n, q, qni); break;
-    case 10: gen_dense_pass<W, 10, INV>(lds, P, tab, n, q, qni); break;
-    case 11: gen_dense_pass<W, 11, INV>(lds, P, tab, n, q, qni); break;
-    case 12: gen_dense_pass<W, 12, INV>(lds, P, tab, n, q, qni); break;
-    case 13: gen_dense_pass<W, 13, INV>(lds, P, tab, n, q, qni); break;
-    default: break;                                // the host refuses indices with other odd primes
+    if (P.kind == GK_R2BLOCK) {                    // every branch here is wave-uniform
+        if (P.r == 8) gen_r2block_pass<W, 3, INV>(lds, P, tab, n, q, qni);
+        else if (P.r == 4) gen_r2block_pass<W, 2, INV>(lds, P, tab, n, q, qni);
+        else gen_r2block_pass<W, 1, INV>(lds, P, tab, n, q, qni);
+        return;
+    }
+    const int p = P.kind == GK_SYM_DFT ? P.r : P.r + 1;
+    if (P.kind == GK_SYM_CRT) {
+        switch (p) {
+        case 3: gen_sym_pass<W, 3, false, INV>(lds, P, tab, n, q, qni); break;
+        case 5: gen_sym_pass<W, 5, false, INV>(lds, P, tab, n, q, qni); break;
+        case 7: gen_sym_pass<W, 7, false, INV>(lds, P, tab, n, q, qni); break;
+        case 11: gen_sym_pass<W, 11, false, INV>(lds, P, tab, n, q, qni); break;
+        case 13: gen_sym_pass<W, 13, false, INV>(lds, P, tab, n, q, qni); break;
+        default: break;                            // the host refuses indices with other odd primes
+        }
+    } else {
+        switch (p) {
+        case 3: gen_sym_pass<W, 3, true, INV>(lds, P, tab, n, q, qni); break;
+        case 5: gen_sym_pass<W, 5, true, INV>(lds, P, tab, n, q, qni); break;
+        case 7: gen_sym_pass<W, 7, true, INV>(lds, P, tab, n, q, qni); break;
+        case 11: gen_sym_pass<W, 11, true, INV>(lds, P, tab, n, q, qni); break;
+        case 13: gen_sym_pass<W, 13, true, INV>(lds, P, tab, n, q, qni); break;
+        default: break;
+        }
     }
 }
 
@@ -185,11 +317,24 @@ __global__ void __launch_bounds__(GEN_T) k_gen_crt(DevRing<W> R, GenDev<W> G, W*
     W* poly = data + p * (size_t)n;
     const W* in = src ? src + p * (size_t)n : poly;
     const W q = R.mod[j].q, qni = R.mod[j].qni;
-    for (u32 i = threadIdx.x; i < n; i += GEN_T) lds[i] = in[i];
+    typedef typename Vec4<W>::type V;
+    constexpr u32 VL = Vec4<W>::LANES;
+    const bool vec = n % VL == 0;                 // then every limb-polynomial starts 16-byte aligned
+    if (vec) for (u32 i = threadIdx.x * VL; i < n; i += GEN_T * VL) *reinterpret_cast<V*>(lds + i) = *reinterpret_cast<const V*>(in + i);
+    else for (u32 i = threadIdx.x; i < n; i += GEN_T) lds[i] = in[i];
     lds_barrier();
     gen_transform<W, INV>(lds, G, j, q, qni);
-    if (INV) {
-        const W sc = G.iscale_m[j];
+    const W sc = G.iscale_m[j];
+    if (vec) {
+        for (u32 i = threadIdx.x * VL; i < n; i += GEN_T * VL) {
+            V v = *reinterpret_cast<const V*>(lds + i);
+            if (INV) {
+#pragma unroll
+                for (u32 e = 0; e < VL; ++e) v[e] = csub(mont_mul_lazy(v[e], sc, q, qni), q);
+            }
+            *reinterpret_cast<V*>(poly + i) = v;
+        }
+    } else if (INV) {
         for (u32 i = threadIdx.x; i < n; i += GEN_T) poly[i] = csub(mont_mul_lazy(lds[i], sc, q, qni), q);
     } else {
         for (u32 i = threadIdx.x; i < n; i += GEN_T) poly[i] = lds[i];
@@ -223,7 +368,10 @@ __global__ void __launch_bounds__(GEN_T) k_gen_crt_digits(DevRing<W> R, GenDev<W
     }
     lds_barrier();
     gen_transform<W, false>(lds, G, j, q, qni);
-    for (u32 k = threadIdx.x; k < n; k += GEN_T) dst[k] = lds[k];
+    typedef typename Vec4<W>::type V;
+    constexpr u32 VL = Vec4<W>::LANES;
+    if (n % VL == 0) for (u32 k = threadIdx.x * VL; k < n; k += GEN_T * VL) *reinterpret_cast<V*>(dst + k) = *reinterpret_cast<const V*>(lds + k);
+    else for (u32 k = threadIdx.x; k < n; k += GEN_T) dst[k] = lds[k];
 }
 
 // ------------------------------------------------------------------------------------------------------
