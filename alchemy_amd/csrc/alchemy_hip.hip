@@ -50,6 +50,7 @@ struct alch_ring {
     LaunchOpts opts;                           // launch-structure options (alch_ring_set_option)
     bool one_stream = false;
     unsigned rs_slots = 512;                   // resident workgroups of k_rescale_out (each owns a stash slot)
+    size_t scratch_mib = 1024;                 // scratch of the composed (unfused) paths: digits + intermediates of one chunk
     alch_buf* scratch = nullptr;               // staging elements of the host-buffer Tensor methods
     // general cyclotomic index (kernel_gen.hpp); two-power rings with n >= 16 keep the radix-16 engine
     bool gen = false;
@@ -758,6 +759,8 @@ extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) 
     else if (k == "ti_grid") r->opts.ti_grid = (int)value;
     else if (k == "ti_split") { if (value < 0) return fail(ALCH_E_INVALID, "ti_split must be >= 0"); r->opts.ti_split = (int)value; }
     else if (k == "rs_lin") r->opts.rs_lin = value != 0;
+    else if (k == "gen_fused") r->opts.gen_fused = value != 0;
+    else if (k == "scratch_mib") { if (value < 1 || value > 65536) return fail(ALCH_E_INVALID, "scratch_mib must be 1 .. 65536"); r->scratch_mib = (size_t)value; }
     else if (k == "rs_slots") { if (value < 1) return fail(ALCH_E_INVALID, "rs_slots must be >= 1"); r->rs_slots = (unsigned)value; }
     else return fail(ALCH_E_INVALID, "unknown option '" + k + "'");
     return ALCH_OK;
@@ -1390,6 +1393,23 @@ static bool split_ring(const alch_ring* r) { return r->logn > (r->word == 4 ? 15
 //     two orders of magnitude heavier by construction;
 //   * TrivGad on rings too large for one LDS-resident transform (n = 2^16 / 2^15), where the fused kernels do
 //     not exist and crt runs as k_crt_split.
+// The fused general-index key switch (k_gen_tensor_inv + k_gen_ks, kernel_gen.hpp): TrivGad, 32-bit words, n <= 12288.
+static bool gen_ks_fused(const alch_ring* r, const alch_hint* hint) {
+    return r->gen && r->word == 4 && hint->gadget == ALCH_GAD_TRIV && r->n <= (u32)(GEN_KS_T * GEN_KS_NPT) && r->opts.gen_fused;
+}
+
+// keySwitchQuadCirc hint (a * b) for `now` ciphertexts through the two fused general-index kernels; a, b live on the last
+// L - dup limbs of r's moduli (Ls limbs, ring_in), ks receives [now][2][L][n].
+static int launch_gen_ks(alch_ring* r, const alch_hint* hint, const u32* a, const u32* b, u32* ks, u32* c2pow, size_t now, int dup,
+                         const Scal<u32>& sr2, hipStream_t stream) {
+    GenKsArgs<u32> A{};
+    A.a = a; A.b = b; A.c2pow = c2pow; A.hint = reinterpret_cast<const u32*>(hint->dptr); A.out = ks;
+    A.sr2 = sr2; A.dup = dup; A.balanced = r->balanced ? 1 : 0; A.use_g = r->gh.rad > 1 ? 1 : 0;
+    hipError_t e = gen_ks_dispatch(r->d32, r->g32, A, now, stream);
+    if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("general-index fused key switch launch: ") + hipGetErrorString(e));
+    return ALCH_OK;
+}
+
 template <typename W>
 static int do_mul_relin_unfused(alch_ring* r, const alch_hint* hint, const void* a, const void* b, void* out, size_t batch,
                                 const uint64_t* s_pre) {
@@ -1398,7 +1418,7 @@ static int do_mul_relin_unfused(alch_ring* r, const alch_hint* hint, const void*
     const u32 D = base2 ? (u32)base2_layout(r, first, kd) : (u32)r->L;
     const size_t eb = elem_bytes(r);
     // scratch: c2 (1 element) + digits (D elements) per ciphertext of a chunk, at most ~1 GiB
-    size_t chunk = std::max<size_t>(1, ((size_t)1 << 30) / ((D + 2) * eb));
+    size_t chunk = std::max<size_t>(1, (r->scratch_mib << 20) / ((D + 2) * eb));
     chunk = std::min(chunk, batch);
     int rc = ensure_ws(&r->ws_digits, &r->ws_digits_bytes, chunk * (D + 2) * eb);
     if (rc != ALCH_OK) return rc;
@@ -1417,6 +1437,12 @@ static int do_mul_relin_unfused(alch_ring* r, const alch_hint* hint, const void*
         const W* pb = reinterpret_cast<const W*>(reinterpret_cast<const char*>(b) + done * ct_bytes);
         W* po = reinterpret_cast<W*>(reinterpret_cast<char*>(out) + done * ct_bytes);
         const size_t words = now * elem_words(r);
+        if constexpr (sizeof(W) == 4) {
+            if (gen_ks_fused(r, hint)) {                          // two fused launches: tensor + crtInv, digit transforms + hint products
+                if ((rc = launch_gen_ks(r, hint, pa, pb, po, reinterpret_cast<u32*>(c2), now, 0, sr2, r->stream)) != ALCH_OK) return rc;
+                continue;
+            }
+        }
         hipLaunchKernelGGL((k_tensor_ew<W>), dim3(ew_grid(words)), dim3(256), 0, r->stream, dev_ring<W>(r), pa, pb, po,
                            (W*)c2, now, sr2, 0, fused_digits ? (W*)c2crt : (W*)nullptr, gt);
         HIP_TRY(hipGetLastError());
@@ -1689,7 +1715,7 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
     const size_t eb = elem_bytes(rh);
     // scratch per ciphertext: key-switched pair (2) + c2 in both bases (2) + digits (L) + rescale ping-pong (2 + 2), in ring_h elements
     const size_t per_ct = (size_t)(2 + 2 + L + 4) * eb;
-    size_t chunk = std::max<size_t>(1, ((size_t)1 << 30) / per_ct);
+    size_t chunk = std::max<size_t>(1, (rh->scratch_mib << 20) / per_ct);
     chunk = std::min(chunk, batch);
     int rc = ensure_ws(&rh->ws_full, &rh->ws_full_bytes, chunk * per_ct);
     if (rc != ALCH_OK) return rc;
@@ -1727,6 +1753,14 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
         const W* pb = reinterpret_cast<const W*>(reinterpret_cast<const char*>(b) + done * in_bytes);
         const size_t words = now * elem_words(rh);
         // (*) and modSwitch up
+        bool fused_ks = false;
+        if constexpr (sizeof(W) == 4) {
+            if (gen_ks_fused(rh, hint)) {
+                if ((rc = launch_gen_ks(rh, hint, pa, pb, reinterpret_cast<u32*>(ks), reinterpret_cast<u32*>(c2), now, dup, sr2, rh->stream)) != ALCH_OK) return rc;
+                fused_ks = true;
+            }
+        }
+        if (!fused_ks) {
         hipLaunchKernelGGL((k_tensor_ew<W>), dim3(ew_grid(words)), dim3(256), 0, rh->stream, dev_ring<W>(rh), pa, pb, (W*)ks,
                            (W*)c2, now, sr2, dup, (W*)c2crt, gt);
         HIP_TRY(hipGetLastError());
@@ -1759,6 +1793,7 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
         hipLaunchKernelGGL((k_hint_mac<W>), dim3(ew_grid(words)), dim3(256), 0, rh->stream, dev_ring<W>(rh), (W*)ks, (const W*)dig,
                            (const W*)hint->dptr, now, (u32)L, (const W*)c2crt);
         HIP_TRY(hipGetLastError());
+        }
         // modSwitch down: Pow basis (c0: Dec basis for a general index), one limb at a time, then back to the CRT basis on ring_out
         if ((rc = do_crt<W>(rh, ks, 0, 2 * now, true)) != ALCH_OK) return rc;
         if (dec_c0 && (rc = do_columns<W>(rh, GEN_LINV, ks, 0, now, 2)) != ALCH_OK) return rc;
@@ -1920,7 +1955,7 @@ static int do_tunnel(const alch_tunnel* t, const void* in, void* out, size_t bat
     const size_t ebr = elem_bytes(rr), ebs = elem_bytes(rs);
     // scratch per ciphertext: Pow copy of the input (2 R'-elements), x0, x1 (D S'-elements each), digits (D * L S'-elements)
     const size_t per_ct = 2 * ebr + (size_t)(2 * D + D * L) * ebs;
-    size_t chunk = std::max<size_t>(1, ((size_t)1 << 30) / per_ct);
+    size_t chunk = std::max<size_t>(1, (rs->scratch_mib << 20) / per_ct);
     chunk = std::min(chunk, batch);
     int rc = ensure_ws(&rs->ws_full, &rs->ws_full_bytes, chunk * per_ct);
     if (rc != ALCH_OK) return rc;

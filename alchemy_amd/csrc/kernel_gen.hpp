@@ -96,6 +96,9 @@ struct GenCall {
 
 hipError_t gen_dispatch(const GenCall<u32>& c);
 hipError_t gen_dispatch(const GenCall<u64>& c);
+template <typename W> struct GenKsArgs;
+hipError_t gen_ks_dispatch(const DevRing<u32>& R, const GenDev<u32>& G, const GenKsArgs<u32>& A, size_t nct, hipStream_t stream);
+hipError_t gen_ks_dispatch(const DevRing<u64>& R, const GenDev<u64>& G, const GenKsArgs<u64>& A, size_t nct, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------------
 // passes
@@ -138,82 +141,67 @@ template <typename W> __device__ __forceinline__ W gmul(W a, W b, W q, W qni) { 
 //   forward CRT_p : inputs x_0..x_{p-2} (x_{p-1} = 0), outputs y_1..y_{p-1} at slots 0..p-2
 //   inverse CRT_p : y_0 = -sum_i y_i w^i (the condition x_{p-1} = 0), then the inverse DFT_p (w -> w^-1, a, b, carry 1/p)
 //   forward DFT_p : y_0 = sum_j x_j as well;  inverse DFT_p : the same with w^-1 and 1/p
-template <typename W, int P, bool IS_DFT, bool INV>
-__device__ __forceinline__ void sym_apply(W* x /* in/out: R = IS_DFT ? P : P-1 values */, const W* __restrict__ T, W q, W qni) {
+template <typename W, int NT, int P, bool IS_DFT, bool INV>
+__device__ __forceinline__ void gen_sym_pass(W* __restrict__ lds, const GenPass& Ps, const W* __restrict__ tab, u32 n, W q, W qni) {
     constexpr int H = (P - 1) / 2, R = IS_DFT ? P : P - 1;
+    const W* __restrict__ T = tab + Ps.mat_off;
     const W* __restrict__ a = T;
     const W* __restrict__ b = T + H * H;
-    W in[P];                                   // the full length-p input of the DFT_p behind the pass
-    if (!IS_DFT && !INV) {
-#pragma unroll
-        for (int t = 0; t < P - 1; ++t) in[t] = x[t];
-        in[P - 1] = 0;
-    } else if (!IS_DFT && INV) {
-        in[0] = dense_row<P - 1>(x, T + 2 * H * H, q, qni);                       // y_0 = sum_i y_i (-w^i)
-#pragma unroll
-        for (int t = 1; t < P; ++t) in[t] = x[t - 1];
-    } else {
-#pragma unroll
-        for (int t = 0; t < P; ++t) in[t] = x[t];
-    }
-    W u[H], v[H];
-#pragma unroll
-    for (int j = 1; j <= H; ++j) { u[j - 1] = gadd(in[j], in[P - j], q); v[j - 1] = gsub(in[j], in[P - j], q); }
-    W u0 = in[0], sum = in[0];
-#pragma unroll
-    for (int j = 0; j < H; ++j) sum = gadd(sum, u[j], q);
-    if (INV) {                                 // 1/p rides on a, b; the constant terms take it explicitly
-        const W pinv = T[2 * H * H + (P - 1)];
-        u0 = gmul(u0, pinv, q, qni);
-        sum = gmul(sum, pinv, q, qni);
-    }
-    W out[P];
-    out[0] = sum;
-#pragma unroll
-    for (int i = 1; i <= H; ++i) {
-        const W A = gadd(u0, dense_row<H>(u, a + (i - 1) * H, q, qni), q);
-        const W B = dense_row<H>(v, b + (i - 1) * H, q, qni);
-        out[i] = gadd(A, B, q);
-        out[P - i] = gsub(A, B, q);
-    }
-    if (!IS_DFT && !INV) {
-#pragma unroll
-        for (int t = 0; t < P - 1; ++t) x[t] = out[t + 1];                    // rows 1..p-1
-    } else {
-#pragma unroll
-        for (int t = 0; t < R; ++t) x[t] = out[t];                            // inverse CRT_p: x_{p-1} = 0 is dropped
-    }
-}
-
-template <typename W, int P, bool IS_DFT, bool INV>
-__device__ __forceinline__ void gen_sym_pass(W* __restrict__ lds, const GenPass& Ps, const W* __restrict__ tab, u32 n, W q, W qni) {
-    constexpr int R = IS_DFT ? P : P - 1;
-    const W* __restrict__ T = tab + Ps.mat_off;
     const bool has_tw = Ps.tw_off != 0xffffffffu;
     const W* __restrict__ tw = tab + (has_tw ? Ps.tw_off : 0u);
     const u32 step = fdiv(Ps.stride, Ps.axis_stride, Ps.rcp_axis_stride);
-    for (u32 w = threadIdx.x; w < n / (u32)R; w += GEN_T) {
+    for (u32 w = threadIdx.x; w < n / (u32)R; w += NT) {
         const u32 hi = fdiv(w, Ps.stride, Ps.rcp_stride), lo = w - hi * Ps.stride;
         const u32 base = hi * (u32)R * Ps.stride + lo;
-        W x[R];
-#pragma unroll
-        for (int t = 0; t < R; ++t) x[t] = lds[base + (u32)t * Ps.stride];
         u32 pos0 = 0;
         if (has_tw) {
-            const u32 a = fdiv(base, Ps.axis_stride, Ps.rcp_axis_stride);
-            pos0 = a - fdiv(a, Ps.axis_len, Ps.rcp_axis_len) * Ps.axis_len;
+            const u32 ap = fdiv(base, Ps.axis_stride, Ps.rcp_axis_stride);
+            pos0 = ap - fdiv(ap, Ps.axis_len, Ps.rcp_axis_len) * Ps.axis_len;
         }
-        if (!INV && has_tw) {
+        // the length-p input of the DFT_p behind the pass: in_t = element t - OFF of the group
+        //   forward CRT_p: in_0..in_{p-2} = x, in_{p-1} = 0;  inverse CRT_p: in_0 = y_0 (below), in_1.. = x;  DFT_p: in = x
+        constexpr int OFF = (!IS_DFT && INV) ? 1 : 0;
+        W x[R];
 #pragma unroll
-            for (int t = 0; t < R; ++t) x[t] = gmul(x[t], tw[pos0 + (u32)t * step], q, qni);
+        for (int t = 0; t < R; ++t) {
+            x[t] = lds[base + (u32)t * Ps.stride];
+            if (!INV && has_tw) x[t] = gmul(x[t], tw[pos0 + (u32)t * step], q, qni);
         }
-        sym_apply<W, P, IS_DFT, INV>(x, T, q, qni);
-        if (INV && has_tw) {
+        W in0;
+        if (!IS_DFT && INV) in0 = dense_row<P - 1>(x, T + 2 * H * H, q, qni);          // y_0 = sum_i y_i (-w^i)
+        else in0 = x[0];
+        auto in = [&](int t) -> W { return t == 0 ? in0 : (t - OFF < R ? x[t - OFF] : (W)0); };
+        W u[H], v[H];
+        W sum = in0;
 #pragma unroll
-            for (int t = 0; t < R; ++t) x[t] = gmul(x[t], tw[pos0 + (u32)t * step], q, qni);
+        for (int j = 1; j <= H; ++j) {
+            const W xa = in(j), xb = in(P - j);
+            u[j - 1] = gadd(xa, xb, q);
+            v[j - 1] = gsub(xa, xb, q);
+            sum = gadd(sum, u[j - 1], q);
         }
+        W u0 = in0;
+        if (INV) {                                 // 1/p rides on a, b; the constant terms take it explicitly
+            const W pinv = T[2 * H * H + (P - 1)];
+            u0 = gmul(u0, pinv, q, qni);
+            sum = gmul(sum, pinv, q, qni);
+        }
+        // results go straight back to LDS (every input of the group is in registers by now): row r of the DFT_p lands at
+        // element r (DFT_p, inverse CRT_p) or r - 1 (forward CRT_p, which has no row 0); inverse CRT_p drops row p - 1 (= 0)
+        auto put = [&](int row, W val) {
+            const int t = (!IS_DFT && !INV) ? row - 1 : row;
+            if (t < 0 || t >= R) return;
+            if (INV && has_tw) val = gmul(val, tw[pos0 + (u32)t * step], q, qni);
+            lds[base + (u32)t * Ps.stride] = val;
+        };
+        put(0, sum);
 #pragma unroll
-        for (int t = 0; t < R; ++t) lds[base + (u32)t * Ps.stride] = x[t];
+        for (int i = 1; i <= H; ++i) {
+            const W A = gadd(u0, dense_row<H>(u, a + (i - 1) * H, q, qni), q);
+            const W B = dense_row<H>(v, b + (i - 1) * H, q, qni);
+            put(i, gadd(A, B, q));
+            put(P - i, gsub(A, B, q));
+        }
     }
 }
 
@@ -221,12 +209,12 @@ __device__ __forceinline__ void gen_sym_pass(W* __restrict__ lds, const GenPass&
 // (element k of a group at base + k stride).  Stage s0 + r uses the 2^r table entries tw[(gm << r) + c], gm = 2^s0 + group
 // index -- the table is tw[k] = psi^brev(k), exactly the two-power engine's.  Inverse: Gentleman-Sande, the stages backwards with
 // tw^-1; the factor 2^-K is collected in GenDev::iscale_m.
-template <typename W, int K, bool INV>
+template <typename W, int NT, int K, bool INV>
 __device__ __forceinline__ void gen_r2block_pass(W* __restrict__ lds, const GenPass& P, const W* __restrict__ tab, u32 n, W q, W qni) {
     constexpr int R = 1 << K;
     const W* __restrict__ tw = tab + P.tw_off;
     const u32 smask = (1u << P.aux) - 1u;
-    for (u32 w = threadIdx.x; w < n / (u32)R; w += GEN_T) {
+    for (u32 w = threadIdx.x; w < n / (u32)R; w += NT) {
         const u32 hi = fdiv(w, P.stride, P.rcp_stride), lo = w - hi * P.stride;
         const u32 base = hi * (u32)R * P.stride + lo;
         const u32 gm = (1u << P.aux) + (hi & smask);
@@ -264,43 +252,43 @@ __device__ __forceinline__ void gen_r2block_pass(W* __restrict__ lds, const GenP
     }
 }
 
-template <typename W, bool INV>
+template <typename W, int NT, bool INV>
 __device__ __forceinline__ void gen_run_pass(W* lds, const GenPass& P, const W* tab, u32 n, W q, W qni) {
     if (P.kind == GK_R2BLOCK) {                    // every branch here is wave-uniform
-        if (P.r == 8) gen_r2block_pass<W, 3, INV>(lds, P, tab, n, q, qni);
-        else if (P.r == 4) gen_r2block_pass<W, 2, INV>(lds, P, tab, n, q, qni);
-        else gen_r2block_pass<W, 1, INV>(lds, P, tab, n, q, qni);
+        if (P.r == 8) gen_r2block_pass<W, NT, 3, INV>(lds, P, tab, n, q, qni);
+        else if (P.r == 4) gen_r2block_pass<W, NT, 2, INV>(lds, P, tab, n, q, qni);
+        else gen_r2block_pass<W, NT, 1, INV>(lds, P, tab, n, q, qni);
         return;
     }
     const int p = P.kind == GK_SYM_DFT ? P.r : P.r + 1;
     if (P.kind == GK_SYM_CRT) {
         switch (p) {
-        case 3: gen_sym_pass<W, 3, false, INV>(lds, P, tab, n, q, qni); break;
-        case 5: gen_sym_pass<W, 5, false, INV>(lds, P, tab, n, q, qni); break;
-        case 7: gen_sym_pass<W, 7, false, INV>(lds, P, tab, n, q, qni); break;
-        case 11: gen_sym_pass<W, 11, false, INV>(lds, P, tab, n, q, qni); break;
-        case 13: gen_sym_pass<W, 13, false, INV>(lds, P, tab, n, q, qni); break;
+        case 3: gen_sym_pass<W, NT, 3, false, INV>(lds, P, tab, n, q, qni); break;
+        case 5: gen_sym_pass<W, NT, 5, false, INV>(lds, P, tab, n, q, qni); break;
+        case 7: gen_sym_pass<W, NT, 7, false, INV>(lds, P, tab, n, q, qni); break;
+        case 11: gen_sym_pass<W, NT, 11, false, INV>(lds, P, tab, n, q, qni); break;
+        case 13: gen_sym_pass<W, NT, 13, false, INV>(lds, P, tab, n, q, qni); break;
         default: break;                            // the host refuses indices with other odd primes
         }
     } else {
         switch (p) {
-        case 3: gen_sym_pass<W, 3, true, INV>(lds, P, tab, n, q, qni); break;
-        case 5: gen_sym_pass<W, 5, true, INV>(lds, P, tab, n, q, qni); break;
-        case 7: gen_sym_pass<W, 7, true, INV>(lds, P, tab, n, q, qni); break;
-        case 11: gen_sym_pass<W, 11, true, INV>(lds, P, tab, n, q, qni); break;
-        case 13: gen_sym_pass<W, 13, true, INV>(lds, P, tab, n, q, qni); break;
+        case 3: gen_sym_pass<W, NT, 3, true, INV>(lds, P, tab, n, q, qni); break;
+        case 5: gen_sym_pass<W, NT, 5, true, INV>(lds, P, tab, n, q, qni); break;
+        case 7: gen_sym_pass<W, NT, 7, true, INV>(lds, P, tab, n, q, qni); break;
+        case 11: gen_sym_pass<W, NT, 11, true, INV>(lds, P, tab, n, q, qni); break;
+        case 13: gen_sym_pass<W, NT, 13, true, INV>(lds, P, tab, n, q, qni); break;
         default: break;
         }
     }
 }
 
 // whole transform on an LDS-resident polynomial (canonical values in, canonical values out)
-template <typename W, bool INV>
+template <typename W, bool INV, int NT = GEN_T>
 __device__ __forceinline__ void gen_transform(W* lds, const GenDev<W>& G, int j, W q, W qni) {
     if (!INV) {
-        for (int ps = 0; ps < G.npass; ++ps) { gen_run_pass<W, false>(lds, G.pass[ps], G.tabf[j], G.n, q, qni); lds_barrier(); }
+        for (int ps = 0; ps < G.npass; ++ps) { gen_run_pass<W, NT, false>(lds, G.pass[ps], G.tabf[j], G.n, q, qni); lds_barrier(); }
     } else {
-        for (int ps = G.npass - 1; ps >= 0; --ps) { gen_run_pass<W, true>(lds, G.pass[ps], G.tabi[j], G.n, q, qni); lds_barrier(); }
+        for (int ps = G.npass - 1; ps >= 0; --ps) { gen_run_pass<W, NT, true>(lds, G.pass[ps], G.tabi[j], G.n, q, qni); lds_barrier(); }
     }
 }
 
@@ -372,6 +360,150 @@ __global__ void __launch_bounds__(GEN_T) k_gen_crt_digits(DevRing<W> R, GenDev<W
     constexpr u32 VL = Vec4<W>::LANES;
     if (n % VL == 0) for (u32 k = threadIdx.x * VL; k < n; k += GEN_T * VL) *reinterpret_cast<V*>(dst + k) = *reinterpret_cast<const V*>(lds + k);
     else for (u32 k = threadIdx.x; k < n; k += GEN_T) dst[k] = lds[k];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// fused key switch for a general index (SymmSHE (*) + keySwitchQuadCirc, Eval.hs:65-67,133), two launches per chunk:
+//   k_gen_tensor_inv  per (ciphertext, operand limb i): c2_i = a1 b1 g s on the CRT basis (mulG = product with the CRT image
+//                     of g), crtInv in LDS, canonical Pow-basis residues to the digit scratch
+//   k_gen_ks          per (ciphertext, limb j of the hint's ring): c0 = a0 b0 g s, c1 = (a0 b1 + a1 b0) g s and the diagonal digit
+//                     (c2_j itself) from the operands; for every other digit i: centred lift + reduce in the loader, crt in LDS,
+//                     acc += crt(d_i) hint_i; the 2 n / T accumulators stay in registers
+// Against the composed path (element-wise tensor, batched crtInv, digit transforms, hint inner product) this removes two
+// HBM-bound element-wise kernels and the digit round trip through HBM (L (L-1) limb-polynomials written and read per op).
+// `dup` > 0: the operands live dup limbs below the hint's ring (PT2CT's mul_, see k_ks_accum_half).
+// ------------------------------------------------------------------------------------------------------
+constexpr int GEN_KS_T = 512;
+constexpr int GEN_KS_NPT = 24;              // slots per lane: n <= 12288 (every index of the reference)
+
+template <typename W>
+struct GenKsArgs {
+    const W* a;              // operands [ct][2][Ls][n], CRT basis
+    const W* b;
+    W* c2pow;                // [ct][Ls][n], Pow basis
+    const W* hint;           // [L][2][L][n], Montgomery form
+    W* out;                  // [ct][2][L][n]
+    Scal<W> sr2;             // s_i R^2 per operand limb
+    int dup;
+    int balanced;
+    int use_g;               // index has odd prime factors: mulG is not the identity
+};
+
+template <typename W>
+__global__ void __launch_bounds__(GEN_KS_T, 4) k_gen_tensor_inv(DevRing<W> R, GenDev<W> G, GenKsArgs<W> A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W* lds = reinterpret_cast<W*>(smem);
+    const int L = R.L, Ls = L - A.dup;
+    const size_t ct = blockIdx.x / (unsigned)Ls;
+    const int is = (int)(blockIdx.x % (unsigned)Ls), i = is + A.dup;
+    const u32 n = G.n;
+    const W q = R.mod[i].q, qni = R.mod[i].qni;
+    const W* a1 = A.a + ((2 * ct + 1) * (size_t)Ls + is) * n;
+    const W* b1 = A.b + ((2 * ct + 1) * (size_t)Ls + is) * n;
+    const W* g = G.gcrt[i];
+    const W sr2 = A.sr2.v[is];
+    for (u32 k = threadIdx.x; k < n; k += GEN_KS_T) {
+        W v = gmul(gmul(a1[k], sr2, q, qni), b1[k], q, qni);
+        if (A.use_g) v = gmul(v, g[k], q, qni);
+        lds[k] = v;
+    }
+    lds_barrier();
+    gen_transform<W, true, GEN_KS_T>(lds, G, i, q, qni);
+    const W sc = G.iscale_m[i];
+    W* dst = A.c2pow + (ct * (size_t)Ls + is) * n;
+    for (u32 k = threadIdx.x; k < n; k += GEN_KS_T) dst[k] = gmul(lds[k], sc, q, qni);
+}
+
+template <typename W>
+__global__ void __launch_bounds__(GEN_KS_T, 4) k_gen_ks(DevRing<W> R, GenDev<W> G, GenKsArgs<W> A) {
+    typedef typename Signed<W>::type SW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W* lds = reinterpret_cast<W*>(smem);
+    const int L = R.L, Ls = L - A.dup;
+    const size_t ct = blockIdx.x / (unsigned)L;
+    const int j = (int)(blockIdx.x % (unsigned)L), js = j - A.dup;
+    const u32 n = G.n;
+    const W q = R.mod[j].q, qni = R.mod[j].qni;
+    const size_t Ln = (size_t)L * n;
+    const W* hj = A.hint + (size_t)j * n;                    // + (2 i + c) * Ln
+    W acc0[GEN_KS_NPT], acc1[GEN_KS_NPT];
+    if (js < 0) {
+#pragma unroll
+        for (int k = 0; k < GEN_KS_NPT; ++k) { acc0[k] = 0; acc1[k] = 0; }
+    } else {
+        const size_t o = (size_t)js * n;
+        const W* a0 = A.a + (2 * ct) * (size_t)Ls * n + o;
+        const W* a1 = A.a + (2 * ct + 1) * (size_t)Ls * n + o;
+        const W* b0 = A.b + (2 * ct) * (size_t)Ls * n + o;
+        const W* b1 = A.b + (2 * ct + 1) * (size_t)Ls * n + o;
+        const W* h0 = hj + (size_t)(2 * j) * Ln;
+        const W* h1 = hj + (size_t)(2 * j + 1) * Ln;
+        const W* g = G.gcrt[j];
+        const W sr2 = A.sr2.v[js];
+#pragma unroll
+        for (int k = 0; k < GEN_KS_NPT; ++k) {
+            const u32 s = threadIdx.x + (u32)k * GEN_KS_T;
+            acc0[k] = 0; acc1[k] = 0;
+            if (s < n) {
+                const W x0 = gmul(a0[s], sr2, q, qni), x1 = gmul(a1[s], sr2, q, qni);
+                W c0 = gmul(x0, b0[s], q, qni);
+                W c1 = gadd(gmul(x0, b1[s], q, qni), gmul(x1, b0[s], q, qni), q);
+                W c2 = gmul(x1, b1[s], q, qni);
+                if (A.use_g) { const W gv = g[s]; c0 = gmul(c0, gv, q, qni); c1 = gmul(c1, gv, q, qni); c2 = gmul(c2, gv, q, qni); }
+                acc0[k] = gadd(c0, gmul(c2, h0[s], q, qni), q);
+                acc1[k] = gadd(c1, gmul(c2, h1[s], q, qni), q);
+            }
+        }
+    }
+    for (int is = 0; is < Ls; ++is) {
+        if (is == js) continue;
+        const int i = is + A.dup;
+        const W qi = R.mod[i].q, hqi = (qi - 1) >> 1;
+        const W* src = A.c2pow + (ct * (size_t)Ls + is) * n;
+        lds_barrier();                                      // the previous digit's products have been read
+        for (u32 k = threadIdx.x; k < n; k += GEN_KS_T) {
+            const W v = src[k];
+            const SW z = v > hqi ? (SW)v - (SW)qi : (SW)v;
+            SW r;
+            if (A.balanced) r = z < 0 ? z + (SW)q : z;
+            else { r = z % (SW)q; if (r < 0) r += (SW)q; }
+            lds[k] = (W)r;
+        }
+        lds_barrier();
+        gen_transform<W, false, GEN_KS_T>(lds, G, j, q, qni);
+        const W* h0 = hj + (size_t)(2 * i) * Ln;
+        const W* h1 = hj + (size_t)(2 * i + 1) * Ln;
+#pragma unroll
+        for (int k = 0; k < GEN_KS_NPT; ++k) {
+            const u32 s = threadIdx.x + (u32)k * GEN_KS_T;
+            if (s < n) {
+                const W x = lds[s];
+                acc0[k] = gadd(acc0[k], gmul(x, h0[s], q, qni), q);
+                acc1[k] = gadd(acc1[k], gmul(x, h1[s], q, qni), q);
+            }
+        }
+    }
+    W* o0 = A.out + ((2 * ct) * (size_t)L + j) * n;
+    W* o1 = A.out + ((2 * ct + 1) * (size_t)L + j) * n;
+#pragma unroll
+    for (int k = 0; k < GEN_KS_NPT; ++k) {
+        const u32 s = threadIdx.x + (u32)k * GEN_KS_T;
+        if (s < n) { o0[s] = acc0[k]; o1[s] = acc1[k]; }
+    }
+}
+
+template <typename W>
+inline hipError_t gen_launch_ks(const DevRing<W>& R, const GenDev<W>& G, const GenKsArgs<W>& A, size_t nct, hipStream_t stream) {
+    const size_t lds_bytes = (size_t)G.n * sizeof(W);
+    auto k1 = k_gen_tensor_inv<W>;
+    auto k2 = k_gen_ks<W>;
+    hipError_t e;
+    if ((e = set_lds(k1, lds_bytes)) != hipSuccess) return e;
+    if ((e = set_lds(k2, lds_bytes)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k1, dim3((unsigned)(nct * (size_t)(R.L - A.dup))), dim3(GEN_KS_T), lds_bytes, stream, R, G, A);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(k2, dim3((unsigned)(nct * (size_t)R.L)), dim3(GEN_KS_T), lds_bytes, stream, R, G, A);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -73,6 +73,8 @@ struct DropTab {
 struct LaunchOpts {
     int ti_split = 1;        // n = 2^15 tensor kernel: 1 = split form, one workgroup per item; 0 = whole-polynomial kernel; > 1 = that many persistent workgroups
     int ti_grid = -1;        // whole-polynomial tensor kernel: -1 = one resident set of persistent workgroups, 0 = one workgroup per item, n > 0 = n workgroups
+    int gen_fused = 0;       // general index: 1 = fused tensor + key switch kernels (kernel_gen.hpp).  Measured 0.69-0.82x the composed
+                             // path on H0'..H5' (48 accumulators + a CRT_13 pass spill at 128 VGPRs, 4-byte global accesses): off
     int rs_lin = 1;          // closing modSwitch: 1 = kept limbs stay in the CRT basis (k_rescale_out_lin), 0 = every limb through the Pow basis
     unsigned ks_grid = 4096; // persistent workgroups of k_ks_accum_half (measured, 1024-ciphertext chunks: 2048 -> 511k, 4096 -> 517k, 8192 -> 513k op/s)
 };

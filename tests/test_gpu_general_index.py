@@ -137,6 +137,21 @@ def test_ct_mul_full_general_index(oracle_lib, m, l_in, l_h, l_out):
             assert np.array_equal(got[2 * ct], w0) and np.array_equal(got[2 * ct + 1], w1), (ct, pow_out)
 
 
+def test_fused_general_key_switch_option(oracle_lib):
+    """gen_fused = 1 (two fused launches; slower than the composed path, kept as an option) gives the same bits."""
+    m, qs, batch = 20475, RLWR_QS[:4], 3
+    g, o = A.Ring(m, qs), oracle_lib.GenRing(m, qs)
+    g.set_option("gen_fused", 1)
+    rng = np.random.default_rng(77)
+    hint, a, b = rand_elems(rng, 8, g.n, qs), rand_elems(rng, 2 * batch, g.n, qs), rand_elems(rng, 2 * batch, g.n, qs)
+    gh, ga, gb, gout = g.hint_load(hint), g.upload(a), g.upload(b), g.alloc(2 * batch)
+    g.ct_mul_relin(gh, ga, gb, gout, batch)
+    got = gout.download()
+    for ct in range(batch):
+        w0, w1 = o.ct_mul_relin(list(hint), a[2 * ct], a[2 * ct + 1], b[2 * ct], b[2 * ct + 1])
+        assert np.array_equal(got[2 * ct], w0) and np.array_equal(got[2 * ct + 1], w1), ct
+
+
 def test_public_ops_general_index(oracle_lib):
     """mulPublic / addPublic (Eval.hs:131-132) on H5': every ciphertext component times one public element; one public
     element added to every c0."""

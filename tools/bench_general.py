@@ -9,6 +9,8 @@ from alchemy_amd import capi
 
 QS = [1543651201, 689270401, 718099201, 720720001, 1556755201, 1567238401]
 H = [11648, 29120, 43680, 54600, 27300, 20475]
+SCR = int(os.environ.get('GEN_SCRATCH_MIB', '1024'))
+FUSED = int(os.environ.get('GEN_FUSED', '1'))
 only = [int(x) for x in sys.argv[1:]] or H
 
 
@@ -24,6 +26,7 @@ for m in only:
     L = 4
     qs = QS[:L]
     g = A.Ring(m, qs)
+    g.set_option('scratch_mib', SCR); g.set_option('gen_fused', FUSED)
     n, E = g.n, 8192
     buf = g.alloc(E); buf.fill_uniform(1)
     t_f, t_i = timed(g, buf.crt), timed(g, buf.crtinv)
@@ -34,6 +37,7 @@ for m in only:
     t_r = timed(g, lambda: g.ct_mul_relin(hint, a, b, out, B))
     qh = list(reversed(QS[:5]))
     rh, rin, rout = A.Ring(m, qh), A.Ring(m, qh[1:]), A.Ring(m, qh[2:])
+    rh.set_option('scratch_mib', SCR); rh.set_option('gen_fused', FUSED)
     hs5 = rh.alloc(10); hs5.fill_uniform(5); hint5 = rh.hint_from_buf(hs5)
     a4, b4, o3 = rin.alloc(2 * B), rin.alloc(2 * B), rout.alloc(2 * B)
     a4.fill_uniform(6); b4.fill_uniform(7)
