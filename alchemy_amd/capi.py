@@ -91,7 +91,7 @@ def load_library():
         "alch_select_limbs": [PU64, C.c_int, C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4,
         "alch_modulus_units": [C.c_uint64],
         "alch_tunnel_info": [VP, VP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
-        "alch_tunnel_create": [VP, VP, VP, VP, C.POINTER(VP)],
+        "alch_tunnel_create": [VP, VP, C.c_int, VP, VP, C.POINTER(VP)],
         "alch_tunnel_free": [VP],
         "alch_ct_tunnel": [VP, VP, VP, C.c_size_t, PU64, C.c_uint],
         "alch_l": [VP, P64], "alch_linv": [VP, P64],
@@ -322,10 +322,10 @@ def ct_mul_full(hint: "Hint", a: "Buf", b: "Buf", out: "Buf", batch: int, s_pre=
 class Tunnel:
     """alch_tunnel: SymmSHE `tunnel hint` from ring_r = R'_q to ring_s = S'_q (device-resident linear function + hints)."""
 
-    def __init__(self, ring_r: "Ring", ring_s: "Ring", lin_crt: "Buf", ks_crt: "Buf"):
+    def __init__(self, ring_r: "Ring", ring_s: "Ring", lin_crt: "Buf", ks_crt: "Buf", gadget: int = ALCH_GAD_TRIV):
         self.ring_r, self.ring_s = ring_r, ring_s
         h = C.c_void_p()
-        _check(ring_s._l.alch_tunnel_create(ring_r._h, ring_s._h, lin_crt._h, ks_crt._h, C.byref(h)))
+        _check(ring_s._l.alch_tunnel_create(ring_r._h, ring_s._h, gadget, lin_crt._h, ks_crt._h, C.byref(h)))
         self._h = h
 
     @staticmethod

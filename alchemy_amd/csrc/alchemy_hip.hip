@@ -76,7 +76,9 @@ struct alch_tunnel {
     u32 linv_skip_mask;
     int32_t* table;                            // device: [d_rel][n_s] source positions in R', -1 = zero
     void* lin;                                 // device: f' values y_i, [d_rel][L][n_s], CRT basis, Montgomery form
-    void* ks;                                  // device: [d_rel * L][2][L][n_s], CRT basis, Montgomery form
+    void* ks;                                  // device: [d_rel * D][2][L][n_s], CRT basis, Montgomery form (D gadget digits)
+    int gadget;
+    int digits;                                // D: L for TrivGad, sum_i ceil(log2 q_i) for BaseBGad 2
 };
 
 struct alch_hint {
@@ -1900,9 +1902,10 @@ static int tunnel_to_mont(alch_ring* rs, void* dst, const void* src, size_t elem
     return ALCH_OK;
 }
 
-extern "C" int alch_tunnel_create(alch_ring* rr, alch_ring* rs, const alch_buf* lin_crt, const alch_buf* ks_crt, alch_tunnel** out) {
+extern "C" int alch_tunnel_create(alch_ring* rr, alch_ring* rs, int gadget, const alch_buf* lin_crt, const alch_buf* ks_crt, alch_tunnel** out) {
     if (!rr || !rs || !lin_crt || !ks_crt || !out) return fail(ALCH_E_INVALID, "null argument");
     *out = nullptr;
+    if (gadget != ALCH_GAD_TRIV && gadget != ALCH_GAD_BASE2) return fail(ALCH_E_INVALID, "unknown gadget");
     if (!rr->gen || !rs->gen || !rr->has_crt || !rs->has_crt) return fail(ALCH_E_UNSUPPORTED, "tunnelling runs on general-index rings with a CRT basis");
     if (rr->L != rs->L || rr->word != rs->word) return fail(ALCH_E_INVALID, "both rings must have the same moduli");
     for (int j = 0; j < rr->L; ++j) if (rr->q[j] != rs->q[j]) return fail(ALCH_E_INVALID, "both rings must have the same moduli");
@@ -1915,11 +1918,12 @@ extern "C" int alch_tunnel_create(alch_ring* rr, alch_ring* rs, const alch_buf* 
     std::vector<int32_t> tab;
     u32 mask = 0;
     if (!gen_tunnel_table(ge, rr->gh, rs->gh, d_rel, tab, mask)) return fail(ALCH_E_INVALID, "indices do not form a tunnel");
-    const size_t nlin = d_rel, nks = (size_t)d_rel * rs->L * 2;
+    const int digits = gadget_digits(rs, gadget);
+    const size_t nlin = d_rel, nks = (size_t)d_rel * (size_t)digits * 2;
     if (lin_crt->n_elems < nlin || ks_crt->n_elems < nks)
-        return fail(ALCH_E_INVALID, "need d_rel linear-function values and 2 * d_rel * L hint elements");
+        return fail(ALCH_E_INVALID, "need d_rel linear-function values and 2 * d_rel * (gadget digits) hint elements");
     BIND(rs);
-    alch_tunnel* t = new alch_tunnel{rr, rs, d_rel, mask, nullptr, nullptr, nullptr};
+    alch_tunnel* t = new alch_tunnel{rr, rs, d_rel, mask, nullptr, nullptr, nullptr, gadget, digits};
     if (hipMalloc((void**)&t->table, tab.size() * sizeof(int32_t)) != hipSuccess ||
         hipMalloc(&t->lin, nlin * elem_bytes(rs)) != hipSuccess || hipMalloc(&t->ks, nks * elem_bytes(rs)) != hipSuccess) {
         alch_tunnel_free(t);
@@ -1952,9 +1956,13 @@ static int do_tunnel(const alch_tunnel* t, const void* in, void* out, size_t bat
     alch_ring* rs = t->rs;
     const int L = rs->L;
     const u32 D = t->d_rel;
+    const u32 GD = (u32)t->digits;                  // gadget digits per embedded coefficient
+    const bool base2 = t->gadget == ALCH_GAD_BASE2;
+    Scal<u32> b2first, b2kd;
+    if (base2) base2_layout(rs, b2first, b2kd);
     const size_t ebr = elem_bytes(rr), ebs = elem_bytes(rs);
-    // scratch per ciphertext: Pow copy of the input (2 R'-elements), x0, x1 (D S'-elements each), digits (D * L S'-elements)
-    const size_t per_ct = 2 * ebr + (size_t)(2 * D + D * L) * ebs;
+    // scratch per ciphertext: Pow copy of the input (2 R'-elements), x0, x1 (D S'-elements each), digits (D * GD S'-elements)
+    const size_t per_ct = 2 * ebr + (size_t)(2 * D + D * GD) * ebs;
     size_t chunk = std::max<size_t>(1, (rs->scratch_mib << 20) / per_ct);
     chunk = std::min(chunk, batch);
     int rc = ensure_ws(&rs->ws_full, &rs->ws_full_bytes, chunk * per_ct);
@@ -1991,7 +1999,15 @@ static int do_tunnel(const alch_tunnel* t, const void* in, void* out, size_t bat
                            (const W*)t->lin, D, now);
         HIP_TRY(hipGetLastError());
         // linear term: decompose + reduce + crt of every embedded coefficient, inner product with the hints
-        {
+        if (base2) {                                 // BaseBGad 2 (examples/Tunnel.hs:24): element-wise decompose, batched crt
+            for (size_t y0 = 0; y0 < now * D; y0 += 32768) {
+                const unsigned ny = (unsigned)std::min<size_t>(32768, now * D - y0);
+                hipLaunchKernelGGL((k_decompose_base2<W>), dim3(ew_grid(elem_words(rs)), ny), dim3(256), 0, rs->stream, dev_ring<W>(rs),
+                                   reinterpret_cast<const W*>(x1 + y0 * ebs), reinterpret_cast<W*>(dig + y0 * GD * ebs), b2first, b2kd, GD);
+                HIP_TRY(hipGetLastError());
+            }
+            if ((rc = do_crt<W>(rs, dig, 0, now * D * GD, false)) != ALCH_OK) return rc;
+        } else {
             GenCall<W> g{};
             g.op = GEN_CRT_DIGITS; g.ring = &dev_ring<W>(rs); g.gen = &gen_dev<W>(rs); g.stream = rs->stream;
             g.src = reinterpret_cast<const W*>(x1); g.data = reinterpret_cast<W*>(dig);
@@ -2000,7 +2016,7 @@ static int do_tunnel(const alch_tunnel* t, const void* in, void* out, size_t bat
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("tunnel crt_digits launch: ") + hipGetErrorString(e));
         }
         hipLaunchKernelGGL((k_hint_mac<W>), dim3(ew_grid(now * elem_words(rs))), dim3(256), 0, rs->stream, dev_ring<W>(rs), po, (const W*)dig,
-                           (const W*)t->ks, now, D * (u32)L, (const W*)nullptr);
+                           (const W*)t->ks, now, D * GD, (const W*)nullptr);
         HIP_TRY(hipGetLastError());
     }
     return ALCH_OK;

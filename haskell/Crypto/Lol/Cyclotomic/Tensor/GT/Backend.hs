@@ -95,7 +95,7 @@ foreign import ccall safe   "alch_hint_free"           c_hintFree        :: Ptr 
 
 -- ring tunnelling (SymmSHE tunnel between PT2CT's two modSwitch_)
 foreign import ccall unsafe "alch_tunnel_info"         c_tunnelInfo      :: Ptr AlchRing -> Ptr AlchRing -> Ptr Word32 -> Ptr Word32 -> IO CInt
-foreign import ccall safe   "alch_tunnel_create"       c_tunnelCreate    :: Ptr AlchRing -> Ptr AlchRing -> Ptr AlchBuf -> Ptr AlchBuf -> Ptr (Ptr AlchTunnel) -> IO CInt
+foreign import ccall safe   "alch_tunnel_create"       c_tunnelCreate    :: Ptr AlchRing -> Ptr AlchRing -> CInt -> Ptr AlchBuf -> Ptr AlchBuf -> Ptr (Ptr AlchTunnel) -> IO CInt
 foreign import ccall safe   "alch_tunnel_free"         c_tunnelFree      :: Ptr AlchTunnel -> IO CInt
 foreign import ccall safe   "alch_ct_tunnel"           c_ctTunnel        :: Ptr AlchTunnel -> Ptr AlchBuf -> Ptr AlchBuf -> CSize -> Ptr Word64 -> CUInt -> IO CInt
 

@@ -257,13 +257,16 @@ int alch_ct_mul_full(const alch_hint *hint, const alch_buf *a, const alch_buf *b
  * satisfy Lol's tunnel conditions (alch_tunnel_info reports E' and d_rel = dim R'/E', or ALCH_E_INVALID).
  *   lin_crt : d_rel elements of ring_s, CRT basis: the values f'(d_i) of the E'-linear function on the relative decoding
  *             basis of R'/E' (Lol: `extendLin (lift f)` reduced mod q), i in the order of Tensor `coeffs`
- *   ks_crt  : 2 * d_rel * L elements of ring_s, CRT basis: for relative index i and TrivGad digit t the linear hint
+ *   gadget  : ALCH_GAD_TRIV (examples/HomomRLWR.hs:46) or ALCH_GAD_BASE2 (examples/Tunnel.hs:24); D digits (alch_decompose_base2
+ *             reports D for BaseBGad 2; D = L for TrivGad)
+ *   ks_crt  : 2 * d_rel * D elements of ring_s, CRT basis: for relative index i and gadget digit t the linear hint
  *             (b, a) with b + a s_out = g_t f'(s_in p_i) + e   (p_i = relative powerful basis of R'/E'); order i, t, (b, a)
  * alch_ct_tunnel: out[b] = (f'(c0), 0) + sum_i switch(hint_i, embed(coeffsPow(c1)_i)) for linear ciphertexts with k = 0
  * (elements (2b, 2b+1)); s_pre = toMSD's per-limb scalar (NULL = 1).  CRT basis in and out unless ALCH_POW_IN /
  * ALCH_POW_OUT.  Runs on ring_s's stream; the input is not modified. */
 int alch_tunnel_info(const alch_ring *ring_r, const alch_ring *ring_s, uint32_t *e_prime, uint32_t *d_rel);
-int alch_tunnel_create(alch_ring *ring_r, alch_ring *ring_s, const alch_buf *lin_crt, const alch_buf *ks_crt, alch_tunnel **out);
+int alch_tunnel_create(alch_ring *ring_r, alch_ring *ring_s, int gadget, const alch_buf *lin_crt, const alch_buf *ks_crt,
+                       alch_tunnel **out);
 int alch_tunnel_free(alch_tunnel *t);
 int alch_ct_tunnel(const alch_tunnel *t, const alch_buf *in, alch_buf *out, size_t batch, const uint64_t *s_pre, unsigned flags);
 

@@ -420,7 +420,7 @@ def rescale_down_basis(x, idx: Index, qs, drop: int, basis: str):
 import random
 from dataclasses import dataclass
 
-from .model import LSD, MSD, _crt_lift, _qprod, decompose_triv, gadget_triv, rescale_up
+from .model import LSD, MSD, _crt_lift, _qprod, decompose_baseb, decompose_triv, gadget_baseb, gadget_triv, rescale_up
 
 
 @dataclass
@@ -652,9 +652,9 @@ def tunnel_indices(r: int, s: int, rp: int, sp: int) -> TunnelInfo:
     return TunnelInfo(Index(e), Index(r), Index(s), Index(ep), Index(rp), Index(sp))
 
 
-def g_tunnel_hint(ys_pow_p, T: TunnelInfo, p: int, sk_in, sk_out, qs, rng: random.Random, bound: int = 2):
-    """tunnelHint f skout skin: (f' mod q as S'-elements, [hint_i]) with hint_i a TrivGad KSLinearHint for f'(s_in p_i),
-    p_i the relative powerful basis of R'/E'."""
+def g_tunnel_hint(ys_pow_p, T: TunnelInfo, p: int, sk_in, sk_out, qs, rng: random.Random, bound: int = 2, gadget: str = "triv"):
+    """tunnelHint f skout skin: (f' mod q as S'-elements, [hint_i]) with hint_i a KSLinearHint (TrivGad, or BaseBGad 2 --
+    the gadget of examples/Tunnel.hs:24) for f'(s_in p_i), p_i the relative powerful basis of R'/E'."""
     ysz = [embed_pow([centred(v, p) for v in y], T.s, T.sp) for y in ys_pow_p]           # lift f, extend to S'
     rows = coeffs_indices(T.ep, T.rp)
     hints = []
@@ -664,7 +664,7 @@ def g_tunnel_hint(ys_pow_p, T: TunnelInfo, p: int, sk_in, sk_out, qs, rng: rando
         x = ring_mul_def(sk_in, pi, T.rp, None)                                          # s_in * p_i  over Z
         val = eval_lin_dec(ysz, linv_def(x, T.rp, None), T.ep, T.rp, T.sp, None)         # f'(s_in p_i) over Z
         hint_i = []
-        for g in gadget_triv(qs):
+        for g in (gadget_triv(qs) if gadget == "triv" else gadget_baseb(qs, 2)):
             err = l_def(_small_dec(T.sp.n, bound, rng), T.sp, None)
             a = [[rng.randrange(q) for _ in range(T.sp.n)] for q in qs]
             b = []
@@ -677,7 +677,7 @@ def g_tunnel_hint(ys_pow_p, T: TunnelInfo, p: int, sk_in, sk_out, qs, rng: rando
     return lin_q, hints
 
 
-def g_tunnel(lin_q, hints, ct: GCT, T: TunnelInfo) -> GCT:
+def g_tunnel(lin_q, hints, ct: GCT, T: TunnelInfo, gadget: str = "triv") -> GCT:
     """SymmSHE.tunnel on a linear ciphertext with k = 0 (the state every ALCHEMY tunnel sees: PT2CT tunnels before it
     multiplies, examples/HomomRLWR.hs:45-50)."""
     ct = g_to_msd(ct)
@@ -690,7 +690,9 @@ def g_tunnel(lin_q, hints, ct: GCT, T: TunnelInfo) -> GCT:
     c1parts = [coeffs(ct.c[1][j], T.ep, T.rp) for j in range(len(qs))]                  # [limb][i] -> E'-element (Pow)
     for i, hint_i in enumerate(hints):
         emb = [embed_pow(c1parts[j][i], T.ep, T.sp) for j in range(len(qs))]            # RNS element of S' (Pow)
-        for d, (b, a) in zip(decompose_triv(emb, qs), hint_i):
+        digs = decompose_triv(emb, qs) if gadget == "triv" else decompose_baseb(emb, qs, 2)
+        assert len(digs) == len(hint_i)
+        for d, (b, a) in zip(digs, hint_i):
             dr = [[v % q for v in d] for q in qs]
             c0 = [[(u + v) % q for u, v in zip(cl, pl)] for cl, pl, q in zip(c0, rns_ring_mul(dr, b, T.sp, qs), qs)]
             c1 = [[(u + v) % q for u, v in zip(cl, pl)] for cl, pl, q in zip(c1, rns_ring_mul(dr, a, T.sp, qs), qs)]

@@ -58,6 +58,38 @@ def test_tunnel_hop_matches_the_oracle(oracle_lib, rp, sp, L, batch):
         assert np.array_equal(got[2 * ct], w0) and np.array_equal(got[2 * ct + 1], w1), ct
 
 
+def test_tunnel_with_base2_hints_decrypts_to_f_of_pt():
+    """BaseBGad 2 tunnel hints (the gadget of examples/Tunnel.hs:24) with its moduli (examples/Tunnel.hs:34-39) on a small tower:
+    a valid model instance through the device, compared bit for bit with the model and decrypted by it."""
+    import random
+    from oracle import model_gen as G
+    rng = random.Random(24)
+    r, s, rp, sp, p = 8, 12, 40, 60, 8
+    T = G.tunnel_indices(r, s, rp, sp)
+    qs = [537264001, 539884801, 555609601]                          # first three of Tunnel.hs's moduli: all = 1 mod 120
+    assert all((q - 1) % 120 == 0 for q in qs)
+    sk_in, sk_out = G.g_gen_sk(T.rp, rng), G.g_gen_sk(T.sp, rng)
+    ys = [[rng.randrange(p) for _ in range(T.s.n)] for _ in range(T.r.n // T.e.n)]
+    pt = [rng.randrange(p) for _ in range(T.r.n)]
+    ct = G.g_mod_switch_up(G.g_encrypt(sk_in, pt, T.r, T.rp, p, qs[1:], rng), qs[:1])
+    lin_q, hints = G.g_tunnel_hint(ys, T, p, sk_in, sk_out, qs, rng, gadget="base2")
+    want = G.g_tunnel(lin_q, hints, ct, T, gadget="base2")
+    gr, gs = A.Ring(rp, qs), A.Ring(sp, qs)
+    D = gs.gadget_digits(capi.ALCH_GAD_BASE2)
+    assert D == len(hints[0]) == sum(q.bit_length() for q in qs)
+    lin = gs.upload(np.stack([to_aos(y) for y in lin_q]))
+    ks = gs.upload(np.stack([to_aos(x) for hint_i in hints for pair in hint_i for x in pair]))
+    lin.crt(); ks.crt()
+    tun = A.Tunnel(gr, gs, lin, ks, gadget=capi.ALCH_GAD_BASE2)
+    cin, cout = gr.upload(np.stack([to_aos(c) for c in ct.c])), gs.alloc(2)
+    tun.apply(cin, cout, 1, flags=capi.ALCH_POW_IN | capi.ALCH_POW_OUT)
+    got = cout.download()
+    lm = lambda a: np.asarray(a).T.tolist()
+    assert lm(got[0]) == want.c[0] and lm(got[1]) == want.c[1]
+    dev = G.GCT(want.enc, want.k, want.l, [lm(got[0]), lm(got[1])], p, qs, T.sp, T.s)
+    assert G.g_decrypt(sk_out, G.g_mod_switch_down(dev, 1)) == G.eval_lin_dec(ys, G.linv_def(pt, T.r, p), T.e, T.r, T.s, p)
+
+
 def test_tunnel_argument_checks():
     qs = primes_1_mod(40 * 60, 3, 1 << 29)
     gr, gs, gs2 = A.Ring(40, qs[:2]), A.Ring(60, qs[:2]), A.Ring(60, qs[1:])

@@ -27,6 +27,19 @@ def test_tunnel_decrypts_to_the_linear_function_of_the_plaintext(r, s, rp, sp, p
     assert G.g_decrypt(sk_out, out) == G.eval_lin_dec(ys, G.linv_def(pt, T.r, p), T.e, T.r, T.s, p)
 
 
+def test_tunnel_with_base2_hints():
+    rng = random.Random(5)
+    T = G.tunnel_indices(8, 12, 40, 60)
+    qs, p = primes_1_mod(120, 3, 1 << 29), 4
+    sk_in, sk_out = G.g_gen_sk(T.rp, rng), G.g_gen_sk(T.sp, rng)
+    ys = [[rng.randrange(p) for _ in range(T.s.n)] for _ in range(2)]
+    pt = [rng.randrange(p) for _ in range(T.r.n)]
+    ct = G.g_encrypt(sk_in, pt, T.r, T.rp, p, qs[1:], rng)
+    lin_q, hints = G.g_tunnel_hint(ys, T, p, sk_in, sk_out, qs, rng, gadget="base2")
+    out = G.g_mod_switch_down(G.g_tunnel(lin_q, hints, G.g_mod_switch_up(ct, qs[:1]), T, gadget="base2"), 1)
+    assert G.g_decrypt(sk_out, out) == G.eval_lin_dec(ys, G.linv_def(pt, T.r, p), T.e, T.r, T.s, p)
+
+
 def test_reference_hops_are_tunnels():
     """The five hops of examples/Common.hs:78-95 with the index maps of :41-54 satisfy Lol's tunnel conditions."""
     H = [128, 448, 2912, 3640, 5460, 4095]
