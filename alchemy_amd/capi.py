@@ -29,7 +29,7 @@ SYMBOLS = [
     "alch_buf_decompose_triv", "alch_buf_rescale_add0", "alch_decompose_base2", "alch_ct_mul_full", "alch_buf_device_ptr",
     "alch_ring_set_option", "alch_ring_create_nocrt", "alch_l", "alch_linv", "alch_buf_l", "alch_buf_linv", "alch_buf_mulg",
     "alch_buf_divg", "alch_buf_mul_public", "alch_buf_add_public", "alch_select_limbs", "alch_modulus_units",
-    "alch_tunnel_info", "alch_tunnel_create", "alch_tunnel_free", "alch_ct_tunnel",
+    "alch_tunnel_info", "alch_tunnel_create", "alch_tunnel_free", "alch_ct_tunnel", "alch_ct_mod_switch",
 ]
 
 
@@ -94,6 +94,7 @@ def load_library():
         "alch_tunnel_create": [VP, VP, C.c_int, VP, VP, C.POINTER(VP)],
         "alch_tunnel_free": [VP],
         "alch_ct_tunnel": [VP, VP, VP, C.c_size_t, PU64, C.c_uint],
+        "alch_ct_mod_switch": [VP, VP, C.c_size_t, C.c_uint],
         "alch_l": [VP, P64], "alch_linv": [VP, P64],
         "alch_buf_l": [VP, C.c_size_t, C.c_size_t], "alch_buf_linv": [VP, C.c_size_t, C.c_size_t],
         "alch_buf_mulg": [VP, C.c_size_t, C.c_size_t, C.c_int], "alch_buf_divg": [VP, C.c_size_t, C.c_size_t, C.c_int],
@@ -311,6 +312,11 @@ class Ring:
     def ct_mul_relin(self, hint: "Hint", a: "Buf", b: "Buf", out: "Buf", batch: int, s_pre=None, flags: int = 0):
         sp = _pu64(s_pre) if s_pre is not None else None
         _check(self._l.alch_ct_mul_relin(self._h, hint._h, a._h, b._h, out._h, batch, sp, flags))
+
+
+def ct_mod_switch(src: "Buf", dst: "Buf", batch: int, flags: int = 0):
+    """SymmSHE modSwitch of a batch of linear MSD ciphertexts between two rings whose moduli nest (up or down)."""
+    _check(load_library().alch_ct_mod_switch(src._h, dst._h, batch, flags))
 
 
 def ct_mul_full(hint: "Hint", a: "Buf", b: "Buf", out: "Buf", batch: int, s_pre=None, flags: int = 0):

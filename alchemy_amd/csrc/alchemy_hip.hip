@@ -429,6 +429,16 @@ __global__ void k_tunnel_lin(DevRing<W> Rs, W* out, const W* x0crt, const W* lin
     }
 }
 
+// Rescale b -> (a_1, .., a_dup, b): dst limb j < dup = 0, dst limb j >= dup = (prod of the added moduli) * src limb j - dup.
+template <typename W>
+__global__ void k_rescale_up(DevRing<W> Rd, const W* src, W* dst, size_t elems, int dup, Scal<W> mult_m) {
+    const size_t n = (size_t)Rd.n, L = (size_t)Rd.L, Ls = L - (size_t)dup;
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < elems * L * n; w += (size_t)gridDim.x * blockDim.x) {
+        const size_t k = w % n, j = (w / n) % L, e = w / (n * L);
+        dst[w] = j < (size_t)dup ? (W)0 : mont_mul(src[(e * Ls + (j - dup)) * n + k], mult_m.v[j], Rd.mod[j]);
+    }
+}
+
 template <typename W>
 __global__ void k_checksum(const W* data, size_t words, u64* sum) {
     u64 acc = 0;
@@ -2043,6 +2053,102 @@ extern "C" int alch_ct_tunnel(const alch_tunnel* t, const alch_buf* in, alch_buf
         HIP_TRY(hipEventRecord(rs->ev_x, rs->stream));
         HIP_TRY(hipStreamWaitEvent(rr->stream, rs->ev_x, 0));
     }
+    return ALCH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// SymmSHE modSwitch on batches of linear ciphertexts (Eval.hs:130; PT2CT.hs:177,224-229)
+// ------------------------------------------------------------------------------------------------------
+template <typename W>
+static int do_mod_switch(alch_ring* rin, alch_ring* rout, const void* in, void* out, size_t batch, unsigned flags) {
+    const size_t n = rin->n;
+    if (rout->L > rin->L) {                                   // up: Rescale b -> (a, b), any basis
+        const int dup = rout->L - rin->L;
+        uint64_t mult[MAXL] = {0};
+        for (int j = dup; j < rout->L; ++j) {
+            u64 v = 1;
+            for (int u = 0; u < dup; ++u) v = h_mulmod(v, rout->q[u] % rout->q[j], rout->q[j]);
+            mult[j] = v;
+        }
+        Scal<W> sm;
+        scal_to_mont<W>(rout, mult, 1, sm);
+        const size_t total = 2 * batch * elem_words(rout);
+        hipLaunchKernelGGL((k_rescale_up<W>), dim3(ew_grid(total)), dim3(256), 0, rout->stream, dev_ring<W>(rout), (const W*)in, (W*)out,
+                           2 * batch, dup, sm);
+        HIP_TRY(hipGetLastError());
+        return ALCH_OK;
+    }
+    // down: Pow basis (c0 on the Dec basis for a general index), one limb at a time, outermost first
+    const int L = rin->L, ddn = L - rout->L;
+    const size_t eb = elem_bytes(rin);
+    const bool dec_c0 = rin->gen && rin->gh.rad > 1;
+    const size_t per_ct = 3 * 2 * eb;                          // Pow copy + ping + pong
+    size_t chunk = std::max<size_t>(1, (rin->scratch_mib << 20) / per_ct);
+    chunk = std::min(chunk, batch);
+    int rc = ensure_ws(&rin->ws_full, &rin->ws_full_bytes, chunk * per_ct);
+    if (rc != ALCH_OK) return rc;
+    char* cur0 = reinterpret_cast<char*>(rin->ws_full);
+    char* ping = cur0 + chunk * 2 * eb;
+    char* pong = ping + chunk * 2 * eb;
+    auto suffix = [&](int u) {
+        DevRing<W> d = dev_ring<W>(rin);
+        d.L = L - u;
+        for (int j = 0; j + u < L; ++j) d.mod[j] = d.mod[j + u];
+        return d;
+    };
+    const size_t in_bytes = 2 * eb, out_bytes = 2 * elem_bytes(rout);
+    for (size_t done = 0; done < batch; done += chunk) {
+        const size_t now = std::min(chunk, batch - done);
+        const char* src = reinterpret_cast<const char*>(in) + done * in_bytes;
+        if (flags & ALCH_POW_IN) HIP_TRY(hipMemcpyAsync(cur0, src, now * in_bytes, hipMemcpyDeviceToDevice, rin->stream));
+        else if (rin->gen || !split_ring(rin)) { if ((rc = do_crt<W>(rin, cur0, 0, 2 * now, true, src)) != ALCH_OK) return rc; }
+        else {                                                 // split transforms work in place
+            HIP_TRY(hipMemcpyAsync(cur0, src, now * in_bytes, hipMemcpyDeviceToDevice, rin->stream));
+            if ((rc = do_crt<W>(rin, cur0, 0, 2 * now, true)) != ALCH_OK) return rc;
+        }
+        if (dec_c0 && (rc = do_columns<W>(rin, GEN_LINV, cur0, 0, now, 2)) != ALCH_OK) return rc;
+        char* cur = cur0;
+        for (int u = 0; u < ddn; ++u) {
+            char* nxt = (u + 1 == ddn) ? reinterpret_cast<char*>(out) + done * out_bytes : ((u & 1) ? pong : ping);
+            const DevRing<W> rs = suffix(u);
+            Scal<W> sm;
+            for (int j = 0; j < MAXL; ++j) sm.v[j] = 0;
+            const int bits = 8 * (int)sizeof(W);
+            for (int j = 1; j < rs.L; ++j) {
+                const u64 qj = rin->q[u + j];
+                sm.v[j] = (W)h_mulmod(h_powmod(rin->q[u] % qj, qj - 2, qj), h_powmod(2, (u64)bits, qj), qj);
+            }
+            const size_t total = 2 * now * (size_t)(rs.L - 1) * n;
+            hipLaunchKernelGGL((k_rescale_drop0<W>), dim3(ew_grid(total)), dim3(256), 0, rin->stream, rs, (const W*)cur, (W*)nxt, 2 * now, sm);
+            HIP_TRY(hipGetLastError());
+            cur = nxt;
+        }
+        if (dec_c0 && (rc = do_columns<W>(rout, GEN_L, out, 2 * done, now, 2, rin->stream)) != ALCH_OK) return rc;
+        if (!(flags & ALCH_POW_OUT) && (rc = do_crt<W>(rout, out, 2 * done, 2 * now, false, nullptr, rin->stream)) != ALCH_OK) return rc;
+    }
+    return ALCH_OK;
+}
+
+extern "C" int alch_ct_mod_switch(const alch_buf* in, alch_buf* out, size_t batch, unsigned flags) {
+    if (!in || !out) return fail(ALCH_E_INVALID, "null buffer");
+    alch_ring* rin = in->ring;
+    alch_ring* rout = out->ring;
+    if (flags & ~(unsigned)(ALCH_POW_IN | ALCH_POW_OUT)) return fail(ALCH_E_INVALID, "unknown flag");
+    if (!rin->has_crt || !rout->has_crt) return fail(ALCH_E_NO_CRT, "modSwitch runs on rings with a CRT basis");
+    const bool up = rout->L > rin->L;
+    if (rin->L == rout->L || !(up ? is_suffix_ring(rin, rout) : is_suffix_ring(rout, rin)))
+        return fail(ALCH_E_INVALID, "the smaller ring's moduli must be the last limbs of the bigger ring's (same index and word size)");
+    if (batch == 0) return ALCH_OK;
+    if (in->n_elems < 2 * batch || out->n_elems < 2 * batch) return fail(ALCH_E_INVALID, "buffers must hold 2*batch ring elements");
+    alch_ring* rw = up ? rout : rin;                          // the ring whose stream carries the work
+    alch_ring* ro = up ? rin : rout;
+    BIND(rw);
+    if (!rw->ev_x) HIP_TRY(hipEventCreateWithFlags(&rw->ev_x, hipEventDisableTiming));
+    if (ro->stream != rw->stream) { HIP_TRY(hipEventRecord(rw->ev_x, ro->stream)); HIP_TRY(hipStreamWaitEvent(rw->stream, rw->ev_x, 0)); }
+    int rc = rin->word == 4 ? do_mod_switch<u32>(rin, rout, in->dptr, out->dptr, batch, flags)
+                            : do_mod_switch<u64>(rin, rout, in->dptr, out->dptr, batch, flags);
+    if (rc != ALCH_OK) return rc;
+    if (ro->stream != rw->stream) { HIP_TRY(hipEventRecord(rw->ev_x, rw->stream)); HIP_TRY(hipStreamWaitEvent(ro->stream, rw->ev_x, 0)); }
     return ALCH_OK;
 }
 

@@ -99,6 +99,8 @@ foreign import ccall safe   "alch_tunnel_create"       c_tunnelCreate    :: Ptr 
 foreign import ccall safe   "alch_tunnel_free"         c_tunnelFree      :: Ptr AlchTunnel -> IO CInt
 foreign import ccall safe   "alch_ct_tunnel"           c_ctTunnel        :: Ptr AlchTunnel -> Ptr AlchBuf -> Ptr AlchBuf -> CSize -> Ptr Word64 -> CUInt -> IO CInt
 
+foreign import ccall safe   "alch_ct_mod_switch"       c_ctModSwitch     :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> CUInt -> IO CInt
+
 -- the hot path: keySwitchQuadCirc hint (a * b), and PT2CT's whole mul_
 foreign import ccall safe   "alch_ct_mul_relin"        c_ctMulRelin      :: Ptr AlchRing -> Ptr AlchHint -> Ptr AlchBuf -> Ptr AlchBuf -> Ptr AlchBuf -> CSize -> Ptr Word64 -> CUInt -> IO CInt
 foreign import ccall safe   "alch_ct_mul_full"         c_ctMulFull       :: Ptr AlchHint -> Ptr AlchBuf -> Ptr AlchBuf -> Ptr AlchBuf -> CSize -> Ptr Word64 -> CUInt -> IO CInt

@@ -270,6 +270,14 @@ int alch_tunnel_create(alch_ring *ring_r, alch_ring *ring_s, int gadget, const a
 int alch_tunnel_free(alch_tunnel *t);
 int alch_ct_tunnel(const alch_tunnel *t, const alch_buf *in, alch_buf *out, size_t batch, const uint64_t *s_pre, unsigned flags);
 
+/* ---- SymmSHE modSwitch on batches of linear ciphertexts (Eval.hs:130; the two modSwitch_ of PT2CT.hs:177 and :224-229) ----
+ * The rings come from the handles; the smaller ring's moduli are the LAST limbs of the bigger ring's (Noise.hs:82-89).  The
+ * ciphertexts are in MSD form already (apply toMSD's per-limb scalar with alch_buf_scale first).
+ *   out has more limbs: Rescale b -> (a, b) -- added limbs 0, the others times the added moduli; any basis, flags ignored.
+ *   out has fewer limbs: Rescale (a, b) -> b per dropped limb (any number), c0 rescaled on the Dec basis and c1 on the Pow basis
+ *   (Lol: rescaleDec / rescalePow); CRT basis in and out unless ALCH_POW_IN / ALCH_POW_OUT.  The input is not modified. */
+int alch_ct_mod_switch(const alch_buf *in, alch_buf *out, size_t batch, unsigned flags);
+
 /* ---- modSwitch building block (Eval.hs:130) ---------------------------------------
  * Rescale (a,b) -> b on Pow-basis elements: src lives in ring_src (L limbs), dst in ring_dst whose
  * limbs are ring_src's limbs 1..L-1:  dst_j = q_0^-1 * (src_j - reduce(lift src_0)). */

@@ -137,6 +137,48 @@ def test_ct_mul_full_general_index(oracle_lib, m, l_in, l_h, l_out):
             assert np.array_equal(got[2 * ct], w0) and np.array_equal(got[2 * ct + 1], w1), (ct, pow_out)
 
 
+@pytest.mark.parametrize("m,L,drop", [(20475, 5, 1), (54600, 6, 1), (11648, 5, 2), (455, 4, 3), (1 << 12, 4, 2), (1 << 16, 3, 1)])
+def test_ct_mod_switch_down_and_up(oracle_lib, m, L, drop):
+    """SymmSHE modSwitch on linear ciphertexts: down = rescaleDec on c0 / rescalePow on c1 one limb at a time, up = times the
+    added moduli; general and two-power indices, CRT basis in and out."""
+    big = m >= 1000
+    if m & (m - 1) == 0:
+        qs = primes_1_mod(m, L, 1 << 30)
+    else:
+        qs = list(reversed(RLWR_QS[:L])) if big else primes_1_mod(m, L, 1 << 29)
+    gen = m & (m - 1) != 0
+    Rb, Rs = A.Ring(m, qs), A.Ring(m, qs[drop:])
+    ob = oracle_lib.GenRing(m, qs) if gen else oracle_lib.Ring(m // 2, qs)
+    mk = (lambda q: oracle_lib.GenRing(m, q)) if gen else (lambda q: oracle_lib.Ring(m // 2, q))
+    batch = 2
+    rng = np.random.default_rng(m + L)
+    x = rand_elems(rng, 2 * batch, Rb.n, qs)
+    gx, gy = Rb.upload(x), Rs.alloc(2 * batch)
+    capi.ct_mod_switch(gx, gy, batch)
+    got = gy.download()
+    for e in range(2 * batch):
+        cur = ob.crtinv(x[e])
+        if e % 2 == 0 and gen:
+            cur = ob.linv(cur)
+        for u in range(drop):
+            cur = mk(qs[u:]).rescale_drop0(cur)
+        osm = mk(qs[drop:])
+        if e % 2 == 0 and gen:
+            cur = osm.l(cur)
+        assert np.array_equal(got[e], osm.crt(cur)), e
+    assert np.array_equal(gx.download(), x)                   # input untouched
+    # and up again: (0, .., 0, q_a x)
+    gz = Rb.alloc(2 * batch)
+    capi.ct_mod_switch(gy, gz, batch)
+    up = gz.download()
+    mult = 1
+    for q in qs[:drop]:
+        mult *= q
+    for e in range(2 * batch):
+        assert not up[e][:, :drop].any()
+        assert np.array_equal(up[e][:, drop:], mk(qs[drop:]).scale(got[e], [mult % q for q in qs[drop:]])), e
+
+
 def test_fused_general_key_switch_option(oracle_lib):
     """gen_fused = 1 (two fused launches; slower than the composed path, kept as an option) gives the same bits."""
     m, qs, batch = 20475, RLWR_QS[:4], 3

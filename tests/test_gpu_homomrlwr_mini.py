@@ -74,7 +74,7 @@ def test_mini_homomrlwr_pipeline_on_the_device():
     # 2. modSwitch up to the hint modulus: toMSD (p^-1 per limb), then Rescale b -> (a, b)
     x1.scale(x1, 2 * B, [pow(p, -1, q) for q in q_ct])
     x2 = R4.alloc(2 * B)
-    x1.rescale_add0_into(x2, 2 * B)
+    capi.ct_mod_switch(x1, x2, B)                            # alch_ct_mod_switch, up (any basis)
     m2 = [G.g_mod_switch_up(ct, qs[:1]) for ct in m1]
     check(x2, m2, "modSwitch up")
     # 3. tunnel (Pow in, Pow out)
@@ -83,12 +83,8 @@ def test_mini_homomrlwr_pipeline_on_the_device():
     m3 = [G.g_tunnel(lin_q, thints, ct, T) for ct in m2]
     check(y, m3, "tunnel")
     # 4. modSwitch down: rescaleDec on c0, rescalePow on c1
-    for b in range(B):
-        y.linv(2 * b, 1)
     y3 = S3.alloc(2 * B)
-    y.rescale_drop0_into(y3, 2 * B)
-    for b in range(B):
-        y3.l(2 * b, 1)
+    capi.ct_mod_switch(y, y3, B, flags=capi.ALCH_POW_IN | capi.ALCH_POW_OUT)       # alch_ct_mod_switch, down
     m4 = [G.g_mod_switch_down(ct, 1) for ct in m3]
     check(y3, m4, "modSwitch down")
     assert all(G.g_decrypt(sk_out, ct) == G.eval_lin_dec(ys, G.linv_def(G.ring_mul_def(sv, a_pub, T.r, p), T.r, p), T.e, T.r, T.s, p)
