@@ -50,7 +50,8 @@ struct alch_ring {
     LaunchOpts opts;                           // launch-structure options (alch_ring_set_option)
     bool one_stream = false;
     unsigned rs_slots = 512;                   // resident workgroups of k_rescale_out (each owns a stash slot)
-    size_t scratch_mib = 1024;                 // scratch of the composed (unfused) paths: digits + intermediates of one chunk
+    size_t scratch_mib = 4096;                 // scratch of the composed (unfused) paths: digits + intermediates of one chunk
+                                               // (n = 2^16: 66.3 k op/s at 1 GiB, 73.3 k at 4 GiB, 77.7 k at 16 GiB -- small chunks leave CUs idle)
     alch_buf* scratch = nullptr;               // staging elements of the host-buffer Tensor methods
     // general cyclotomic index (kernel_gen.hpp); two-power rings with n >= 16 keep the radix-16 engine
     bool gen = false;
@@ -772,6 +773,7 @@ extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) 
     else if (k == "ti_split") { if (value < 0) return fail(ALCH_E_INVALID, "ti_split must be >= 0"); r->opts.ti_split = (int)value; }
     else if (k == "rs_lin") r->opts.rs_lin = value != 0;
     else if (k == "gen_fused") r->opts.gen_fused = value != 0;
+    else if (k == "split_fused") r->opts.split_fused = value != 0;
     else if (k == "scratch_mib") { if (value < 1 || value > 65536) return fail(ALCH_E_INVALID, "scratch_mib must be 1 .. 65536"); r->scratch_mib = (size_t)value; }
     else if (k == "rs_slots") { if (value < 1) return fail(ALCH_E_INVALID, "rs_slots must be >= 1"); r->rs_slots = (unsigned)value; }
     else return fail(ALCH_E_INVALID, "unknown option '" + k + "'");
@@ -1430,14 +1432,17 @@ static int do_mul_relin_unfused(alch_ring* r, const alch_hint* hint, const void*
     const u32 D = base2 ? (u32)base2_layout(r, first, kd) : (u32)r->L;
     const size_t eb = elem_bytes(r);
     // scratch: c2 (1 element) + digits (D elements) per ciphertext of a chunk, at most ~1 GiB
-    size_t chunk = std::max<size_t>(1, (r->scratch_mib << 20) / ((D + 2) * eb));
+    const bool fused_digits = !base2 && (split_ring(r) || r->gen);
+    // the one-kernel forms (k_ks_accum_split, k_gen_ks) keep no digits in HBM: only c2 in both bases
+    const bool no_digits = fused_digits && ((!r->gen && r->opts.split_fused) || gen_ks_fused(r, hint));
+    const size_t per_ct = (no_digits ? 2 : D + 2) * eb;
+    size_t chunk = std::max<size_t>(1, (r->scratch_mib << 20) / per_ct);
     chunk = std::min(chunk, batch);
-    int rc = ensure_ws(&r->ws_digits, &r->ws_digits_bytes, chunk * (D + 2) * eb);
+    int rc = ensure_ws(&r->ws_digits, &r->ws_digits_bytes, chunk * per_ct);
     if (rc != ALCH_OK) return rc;
     char* c2 = reinterpret_cast<char*>(r->ws_digits);
     char* c2crt = c2 + chunk * eb;                       // CRT-basis copy of c2 (diagonal digits, split rings)
     char* dig = c2crt + chunk * eb;
-    const bool fused_digits = !base2 && (split_ring(r) || r->gen);
     Scal<W> sr2;
     scal_to_mont<W>(r, s_pre, 2, sr2);
     GTab<W> gt{};
@@ -1474,6 +1479,22 @@ static int do_mul_relin_unfused(alch_ring* r, const alch_hint* hint, const void*
             hipLaunchKernelGGL((k_hint_mac<W>), dim3(ew_grid(words)), dim3(256), 0, r->stream, dev_ring<W>(r), po, (const W*)dig,
                                (const W*)hint->dptr, now, D, (const W*)c2crt);
             HIP_TRY(hipGetLastError());
+            continue;
+        }
+        if (fused_digits && r->opts.split_fused) {                  // split rings: digit transforms + hint products in one kernel
+            NttCall<W> dc{};
+            dc.op = OP_KS_SPLIT;
+            dc.ring = &dev_ring<W>(r);
+            dc.stream = r->stream;
+            dc.src = reinterpret_cast<const W*>(c2);
+            dc.a = reinterpret_cast<const W*>(c2crt);
+            dc.hint = reinterpret_cast<const W*>(hint->dptr);
+            dc.out = po;
+            dc.nct = now;
+            dc.dup = 0;
+            dc.balanced = r->balanced;
+            hipError_t e = dispatch(r->logn, dc);
+            if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("ks_accum_split launch: ") + hipGetErrorString(e));
             continue;
         }
         if (fused_digits) {                                         // decompose fused into the digit transforms
@@ -1726,7 +1747,9 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
     const int L = rh->L, dup = L - rin->L, ddn = L - rout->L;
     const size_t eb = elem_bytes(rh);
     // scratch per ciphertext: key-switched pair (2) + c2 in both bases (2) + digits (L) + rescale ping-pong (2 + 2), in ring_h elements
-    const size_t per_ct = (size_t)(2 + 2 + L + 4) * eb;
+    const bool no_digits = (!rh->gen && rh->opts.split_fused) || gen_ks_fused(rh, hint);    // one-kernel key switch: no digits in HBM
+    const size_t dig_elems = no_digits ? 0 : (size_t)L;
+    const size_t per_ct = (size_t)(2 + 2 + 4 + dig_elems) * eb;
     size_t chunk = std::max<size_t>(1, (rh->scratch_mib << 20) / per_ct);
     chunk = std::min(chunk, batch);
     int rc = ensure_ws(&rh->ws_full, &rh->ws_full_bytes, chunk * per_ct);
@@ -1735,7 +1758,7 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
     char* c2 = ks + chunk * 2 * eb;
     char* c2crt = c2 + chunk * eb;
     char* dig = c2crt + chunk * eb;
-    char* ping = dig + chunk * (size_t)L * eb;
+    char* ping = dig + chunk * dig_elems * eb;
     char* pong = ping + chunk * 2 * eb;
     uint64_t s_eff[MAXL];
     for (int j = 0; j < rin->L; ++j) {
@@ -1765,7 +1788,7 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
         const W* pb = reinterpret_cast<const W*>(reinterpret_cast<const char*>(b) + done * in_bytes);
         const size_t words = now * elem_words(rh);
         // (*) and modSwitch up
-        bool fused_ks = false;
+        bool fused_ks = false, split_done = false;
         if constexpr (sizeof(W) == 4) {
             if (gen_ks_fused(rh, hint)) {
                 if ((rc = launch_gen_ks(rh, hint, pa, pb, reinterpret_cast<u32*>(ks), reinterpret_cast<u32*>(c2), now, dup, sr2, rh->stream)) != ALCH_OK) return rc;
@@ -1790,6 +1813,21 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
             g.balanced = rh->balanced;
             hipError_t e = gen_dispatch(g);
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("general-index crt_digits launch: ") + hipGetErrorString(e));
+        } else if (rh->opts.split_fused) {   // digit transforms + hint products in one kernel (k_ks_accum_split)
+            NttCall<W> dc{};
+            dc.op = OP_KS_SPLIT;
+            dc.ring = &dev_ring<W>(rh);
+            dc.stream = rh->stream;
+            dc.src = reinterpret_cast<const W*>(c2);
+            dc.a = reinterpret_cast<const W*>(c2crt);
+            dc.hint = reinterpret_cast<const W*>(hint->dptr);
+            dc.out = reinterpret_cast<W*>(ks);
+            dc.nct = now;
+            dc.dup = dup;
+            dc.balanced = rh->balanced;
+            hipError_t e = dispatch(rh->logn, dc);
+            if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("ks_accum_split launch: ") + hipGetErrorString(e));
+            split_done = true;
         } else {   // decompose + reduce fused into the digit transforms (k_crt_split_digits)
             NttCall<W> dc{};
             dc.op = OP_CRT_DIGITS;
@@ -1802,9 +1840,11 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
             hipError_t e = dispatch(rh->logn, dc);
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("crt_digits launch: ") + hipGetErrorString(e));
         }
+        if (!split_done) {
         hipLaunchKernelGGL((k_hint_mac<W>), dim3(ew_grid(words)), dim3(256), 0, rh->stream, dev_ring<W>(rh), (W*)ks, (const W*)dig,
                            (const W*)hint->dptr, now, (u32)L, (const W*)c2crt);
         HIP_TRY(hipGetLastError());
+        }
         }
         // modSwitch down: Pow basis (c0: Dec basis for a general index), one limb at a time, then back to the CRT basis on ring_out
         if ((rc = do_crt<W>(rh, ks, 0, 2 * now, true)) != ALCH_OK) return rc;

@@ -180,6 +180,113 @@ __global__ void __launch_bounds__(Geo<LOGN - 1>::T) k_crt_split_digits(DevRing<W
     }
 }
 
+// Fused digit transforms + hint inner product for split rings (n = 2^16 / 32-bit, n = 2^15 / 64-bit): the second half of
+// keySwitchQuadCirc (Eval.hs:133) without the digit round trip through HBM.  One workgroup per (ciphertext, limb j, half of the
+// slots), XCD-aware numbering as k_ks_accum: the 2 x 32 accumulators of the half stay in registers; per digit i != j the loader
+// takes the centred lift of c2's limb i (Pow basis), reduces it mod q_j, runs stage 0 for this half (x +- w1 y: both halves of the
+// coefficients are read, from L2 -- the 2L items of a ciphertext share them) and the half-size sub-transform (prefix 2 + half)
+// in LDS; the closing pass's epilogue multiplies by the hint rows.  out holds c0, c1 on entry (element-wise tensor product) and
+// the diagonal digit comes from c2's CRT-basis copy, as in the composed path this replaces (k_crt_split_digits + k_hint_mac:
+// L (L-1) limb-polynomials of 256 KiB written and read back per ciphertext).  dup: leading limbs added by modSwitch (their c2 is 0).
+template <int LOGN, typename W, bool BALANCED>
+__global__ void __launch_bounds__(Geo<LOGN - 1>::T)
+k_ks_accum_split(DevRing<W> R, const W* __restrict__ c2pow, const W* __restrict__ c2crt, const W* __restrict__ hint, W* __restrict__ out,
+                 unsigned nct, int dup) {
+    constexpr int LOGM = LOGN - 1;
+    typedef Geo<LOGM> G;
+    typedef typename Vec4<W>::type V;
+    typedef typename Signed<W>::type SW;
+    constexpr int VL = Vec4<W>::LANES;
+    constexpr int M = G::N, NG = G::E / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W* lds = reinterpret_cast<W*>(smem);
+    const int L = R.L;
+    const unsigned per = 16u * (unsigned)L;
+    const unsigned grp = blockIdx.x / per, rem = blockIdx.x % per, which = rem >> 3;
+    const int j = (int)(which >> 1), half = (int)(which & 1u);
+    const size_t ct = (size_t)grp * 8u + (rem & 7u);
+    if (ct >= nct) return;
+    const ModP<W> m = R.mod[j];
+    const W q = m.q, qni = m.qni;
+    const size_t n = (size_t)(2 * M), Ln = (size_t)L * n, hoff = (size_t)half * M;
+    const W* hj = hint + (size_t)j * n + hoff;                 // + (2 i + c) * Ln
+    W* o0 = out + ((2 * ct) * (size_t)L + j) * n + hoff;
+    W* o1 = out + ((2 * ct + 1) * (size_t)L + j) * n + hoff;
+    W acc0[G::E], acc1[G::E];
+    {   // c0, c1 (already in out) + the diagonal digit c2_j * hint_j
+        const W* d = c2crt + (ct * (size_t)L + j) * n + hoff;
+        const W* h0 = hj + (size_t)(2 * j) * Ln;
+        const W* h1 = hj + (size_t)(2 * j + 1) * Ln;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int k = 0; k < 16; k += VL) {
+                const int idx = (threadIdx.x + G::T * g) * 16 + k;
+                const V v0 = *reinterpret_cast<const V*>(o0 + idx), v1 = *reinterpret_cast<const V*>(o1 + idx);
+                const V vd = *reinterpret_cast<const V*>(d + idx);
+                const V vh0 = *reinterpret_cast<const V*>(h0 + idx), vh1 = *reinterpret_cast<const V*>(h1 + idx);
+#pragma unroll
+                for (int e = 0; e < VL; ++e) {
+                    acc0[g * 16 + k + e] = csub(v0[e] + csub(mont_mul_lazy(vd[e], vh0[e], q, qni), q), q);
+                    acc1[g * 16 + k + e] = csub(v1[e] + csub(mont_mul_lazy(vd[e], vh1[e], q, qni), q), q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    const W w1 = half ? q - R.twf[j][1] : R.twf[j][1];          // upper half: x - w1 y = x + (-w1) y
+    for (int i = dup; i < L; ++i) {
+        if (i == j) continue;
+        const W qi = R.mod[i].q, hqi = (qi - 1) >> 1;
+        const W* src = c2pow + (ct * (size_t)L + i) * n;
+        auto reduce = [&](W v) -> W {                         // centred lift of v mod q_i, reduced mod q_j
+            const SW z = v > hqi ? (SW)v - (SW)qi : (SW)v;
+            if constexpr (BALANCED) return z < 0 ? (W)(z + (SW)q) : (W)z;
+            else { SW r = z % (SW)q; return r < 0 ? (W)(r + (SW)q) : (W)r; }
+        };
+        lds_barrier();                                        // the previous transform's last pass has finished reading LDS
+#pragma unroll
+        for (int r = 0; r < G::E / VL; ++r) {
+            const int idx = (threadIdx.x + G::T * r) * VL;
+            const V x = *reinterpret_cast<const V*>(src + idx), y = *reinterpret_cast<const V*>(src + M + idx);
+            V u;
+#pragma unroll
+            for (int e = 0; e < VL; ++e) u[e] = reduce(x[e]) + csub(mont_mul_lazy(reduce(y[e]), w1, q, qni), q);     // [0, 2q)
+            *reinterpret_cast<V*>(&lds[swz<LOGM>(idx)]) = u;
+        }
+        lds_barrier();
+        const W* h0 = hj + (size_t)(2 * i) * Ln;
+        const W* h1 = hj + (size_t)(2 * i + 1) * Ln;
+        auto twf = fwd_tw(R, j);
+        const W* twm = R.twf[j];
+        int tid = threadIdx.x;
+        asm volatile("" : "+s"(twf), "+s"(twm), "+v"(tid));  // keep pass addresses / twiddles inside the digit loop (VGPR pressure)
+        ntt_forward<LOGM, W, true, true>(lds, twf, twm, q, qni, tid, [&acc0, &acc1, h0, h1, q, qni](int g, int base, W* x) {
+#pragma unroll
+            for (int k = 0; k < 16; k += VL) {
+                const V vh0 = *reinterpret_cast<const V*>(h0 + base + k), vh1 = *reinterpret_cast<const V*>(h1 + base + k);
+#pragma unroll
+                for (int e = 0; e < VL; ++e) {
+                    acc0[g * 16 + k + e] = csub(acc0[g * 16 + k + e] + csub(mont_mul_lazy(x[k + e], vh0[e], q, qni), q), q);
+                    acc1[g * 16 + k + e] = csub(acc1[g * 16 + k + e] + csub(mont_mul_lazy(x[k + e], vh1[e], q, qni), q), q);
+                }
+            }
+        }, 2 + half);
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int k = 0; k < 16; k += VL) {
+            const int idx = (threadIdx.x + G::T * g) * 16 + k;
+            V v0, v1;
+#pragma unroll
+            for (int e = 0; e < VL; ++e) { v0[e] = acc0[g * 16 + k + e]; v1[e] = acc1[g * 16 + k + e]; }
+            *reinterpret_cast<V*>(o0 + idx) = v0;
+            *reinterpret_cast<V*>(o1 + idx) = v1;
+        }
+    }
+}
+
 template <typename W, int LOGN>
 inline hipError_t run_call_split(const NttCall<W>& c) {
     typedef Geo<LOGN - 1> G;
@@ -197,8 +304,20 @@ inline hipError_t run_call_split(const NttCall<W>& c) {
         auto k = k_crt_split_digits<LOGN, W>;
         if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(G::T), lds_bytes, c.stream, *c.ring, c.src, c.data, c.balanced ? 1 : 0);
+    } else if (c.op == OP_KS_SPLIT) {
+        const size_t groups = (c.nct + 7) / 8;
+        const unsigned grid = (unsigned)(groups * 16 * (size_t)c.ring->L);
+        if (c.balanced) {
+            auto k = k_ks_accum_split<LOGN, W, true>;
+            if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
+            hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), lds_bytes, c.stream, *c.ring, c.src, c.a, c.hint, c.out, (unsigned)c.nct, c.dup);
+        } else {
+            auto k = k_ks_accum_split<LOGN, W, false>;
+            if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
+            hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), lds_bytes, c.stream, *c.ring, c.src, c.a, c.hint, c.out, (unsigned)c.nct, c.dup);
+        }
     } else {
-        return hipErrorInvalidValue;        // the fused kernels exist for LDS-resident sizes only
+        return hipErrorInvalidValue;        // the two-launch fused kernels exist for LDS-resident sizes only
     }
     return hipGetLastError();
 }

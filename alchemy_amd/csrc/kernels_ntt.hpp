@@ -58,7 +58,8 @@ namespace alch {
 
 enum OpKind { OP_CRT = 0, OP_CRTINV = 1, OP_TENSOR_INTT = 2, OP_KS_ACCUM = 3, OP_RESCALE_OUT = 4,
               OP_CRT_DIGITS = 5 /* split rings: src = c2 (Pow), data = digits [ct][L][L][n], npoly = ct*L*L */,
-              OP_CRT_BASE2 = 6 /* src = c2 (Pow), data = digits [ct][D][L][n], npoly = ct*D*L; b2_first / b2_kd / b2_D */ };
+              OP_CRT_BASE2 = 6 /* src = c2 (Pow), data = digits [ct][D][L][n], npoly = ct*D*L; b2_first / b2_kd / b2_D */,
+              OP_KS_SPLIT = 7 /* split rings: src = c2 (Pow), a = c2 (CRT copy), hint, out (holds c0, c1; updated in place), nct, dup */ };
 
 constexpr int MAXDROP = 3;
 template <typename W>
@@ -73,6 +74,7 @@ struct DropTab {
 struct LaunchOpts {
     int ti_split = 1;        // n = 2^15 tensor kernel: 1 = split form, one workgroup per item; 0 = whole-polynomial kernel; > 1 = that many persistent workgroups
     int ti_grid = -1;        // whole-polynomial tensor kernel: -1 = one resident set of persistent workgroups, 0 = one workgroup per item, n > 0 = n workgroups
+    int split_fused = 1;     // n = 2^16 (32-bit) / 2^15 (64-bit): digit transforms + hint products in one kernel (k_ks_accum_split)
     int gen_fused = 0;       // general index: 1 = fused tensor + key switch kernels (kernel_gen.hpp).  Measured 0.69-0.82x the composed
                              // path on H0'..H5' (48 accumulators + a CRT_13 pass spill at 128 VGPRs, 4-byte global accesses): off
     int rs_lin = 1;          // closing modSwitch: 1 = kept limbs stay in the CRT basis (k_rescale_out_lin), 0 = every limb through the Pow basis
