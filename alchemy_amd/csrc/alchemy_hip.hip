@@ -149,7 +149,38 @@ __global__ void k_transpose(DevRing<W> R, W* dev, int64_t* host, size_t elems) {
     }
 }
 
+// Position (outer, mid, k) of word w in an [outer][mid < M][k < n] array, advanced by the grid stride with adds and
+// carries: n is a run-time value (and not a power of two for a general index), so w / n and w % n per word would be
+// 64-bit software divisions -- several hundred instructions against the handful a word of element-wise work needs.
+struct Walk3 {
+    u32 k, mid; size_t outer;
+    u32 sk, smid; size_t souter;
+    u32 n, M;
+    __device__ Walk3(size_t w0, size_t stride, u32 n_, u32 M_) : n(n_), M(M_) {
+        k = (u32)(w0 % n); const size_t t = w0 / n; mid = (u32)(t % M); outer = t / M;
+        sk = (u32)(stride % n); const size_t s = stride / n; smid = (u32)(s % M); souter = s / M;
+    }
+    __device__ void step() {
+        k += sk; u32 c = k >= n ? 1u : 0u; k -= c ? n : 0u;
+        mid += smid + c; c = mid >= M ? 1u : 0u; mid -= c ? M : 0u;
+        outer += souter + c;
+    }
+};
+#define ALCH_WALK(w, total, walk) \
+    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < (total); w += (size_t)gridDim.x * blockDim.x, walk.step())
+#define ALCH_WALK_INIT(n_, M_) Walk3 wk(blockIdx.x * (size_t)blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x, (u32)(n_), (u32)(M_))
+
 enum PwOp { PW_MUL = 0, PW_ADD = 1, PW_SUB = 2 };
+
+// z mod q in [0, q) for a signed z.  |z| < q is the common case (a digit, or a centred residue of a modulus of q's
+// size): one conditional add; the software division only runs for the lanes that need it.
+template <typename W>
+__device__ inline typename Signed<W>::type reduce_signed(typename Signed<W>::type z, W q) {
+    typedef typename Signed<W>::type SW;
+    if (z < (SW)q && z > -(SW)q) return z < 0 ? z + (SW)q : z;
+    SW r = z % (SW)q;
+    return r < 0 ? r + (SW)q : r;
+}
 
 template <typename W, int OP>
 __global__ void k_pointwise(DevRing<W> R, W* dst, const W* a, const W* b, size_t words) {
@@ -157,9 +188,9 @@ __global__ void k_pointwise(DevRing<W> R, W* dst, const W* a, const W* b, size_t
     typedef typename Vec4<W>::type V;
     constexpr int VL = Vec4<W>::LANES;
     const size_t nv = words / VL;
-    for (size_t v = blockIdx.x * (size_t)blockDim.x + threadIdx.x; v < nv; v += (size_t)gridDim.x * blockDim.x) {
-        const int j = (int)(((v * VL) / n) % (size_t)R.L);
-        const ModP<W> m = R.mod[j];
+    ALCH_WALK_INIT(n / VL, R.L);
+    ALCH_WALK(v, nv, wk) {
+        const ModP<W> m = R.mod[wk.mid];
         V x = reinterpret_cast<const V*>(a)[v], y = reinterpret_cast<const V*>(b)[v], z;
 #pragma unroll
         for (int e = 0; e < VL; ++e) {
@@ -175,9 +206,9 @@ __global__ void k_pointwise(DevRing<W> R, W* dst, const W* a, const W* b, size_t
 // m = 9, n = 6), where a 16-byte piece would straddle two limbs.
 template <typename W, int OP>
 __global__ void k_pointwise_scalar(DevRing<W> R, W* dst, const W* a, const W* b, size_t words) {
-    const size_t n = (size_t)R.n;
-    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < words; w += (size_t)gridDim.x * blockDim.x) {
-        const ModP<W> m = R.mod[(w / n) % (size_t)R.L];
+    ALCH_WALK_INIT(R.n, R.L);
+    ALCH_WALK(w, words, wk) {
+        const ModP<W> m = R.mod[wk.mid];
         if (OP == PW_MUL) dst[w] = mont_mul(mont_mul(a[w], m.r2, m), b[w], m);
         else if (OP == PW_ADD) dst[w] = add_mod(a[w], b[w], m.q);
         else dst[w] = sub_mod(a[w], b[w], m.q);
@@ -187,11 +218,8 @@ __global__ void k_pointwise_scalar(DevRing<W> R, W* dst, const W* a, const W* b,
 // dst = src * s_j (mod q_j); sm[j] = s_j in Montgomery form.  TO_MONT callers pass sm = R^2 mod q.
 template <typename W>
 __global__ void k_scale(DevRing<W> R, W* dst, const W* src, size_t words, Scal<W> sm) {
-    const size_t n = (size_t)R.n;
-    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < words; w += (size_t)gridDim.x * blockDim.x) {
-        const int j = (int)((w / n) % (size_t)R.L);
-        dst[w] = mont_mul(src[w], sm.v[j], R.mod[j]);
-    }
+    ALCH_WALK_INIT(R.n, R.L);
+    ALCH_WALK(w, words, wk) dst[w] = mont_mul(src[w], sm.v[wk.mid], R.mod[wk.mid]);
 }
 
 // TrivGad decompose + reduce on one Pow-basis element: digits[i] (limb-major element i) limb j =
@@ -204,14 +232,15 @@ __global__ void k_decompose_triv(DevRing<W> R, const W* c, W* digits, int balanc
     const size_t total = L * L * n;
     c += (size_t)blockIdx.y * L * n;                       // blockIdx.y: which ring element
     digits += (size_t)blockIdx.y * total;
-    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < total; w += (size_t)gridDim.x * blockDim.x) {
-        const size_t k = w % n, j = (w / n) % L, i = w / (n * L);
+    ALCH_WALK_INIT(R.n, R.L);
+    ALCH_WALK(w, total, wk) {
+        const size_t k = wk.k, j = wk.mid, i = wk.outer;
         const W qi = R.mod[i].q, qj = R.mod[j].q;
         const W v = c[i * n + k];
         const SW z = v > ((qi - 1) >> 1) ? (SW)v - (SW)qi : (SW)v;
         SW r;
         if (balanced) r = z < 0 ? z + (SW)qj : z;            // |z| < q_j for every pair of limbs: one add
-        else { r = z % (SW)qj; if (r < 0) r += (SW)qj; }
+        else r = reduce_signed<W>(z, qj);
         digits[w] = (W)r;
     }
 }
@@ -226,8 +255,9 @@ __global__ void k_decompose_base2(DevRing<W> R, const W* c, W* digits, Scal<u32>
     const size_t L = (size_t)R.L;
     c += (size_t)blockIdx.y * L * n;                       // blockIdx.y: which ring element
     digits += (size_t)blockIdx.y * D * L * n;
-    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < L * n; w += (size_t)gridDim.x * blockDim.x) {
-        const size_t k = w % n, i = w / n;
+    ALCH_WALK_INIT(R.n, R.L);
+    ALCH_WALK(w, L * n, wk) {
+        const size_t k = wk.k, i = wk.mid;
         const W qi = R.mod[i].q;
         const W x = c[i * n + k];
         SW v = x > ((qi - 1) >> 1) ? (SW)x - (SW)qi : (SW)x;
@@ -240,11 +270,7 @@ __global__ void k_decompose_base2(DevRing<W> R, const W* c, W* digits, Scal<u32>
                 d = v;
             }
             W* out = digits + (size_t)(first_digit.v[i] + t) * L * n;
-            for (size_t j = 0; j < L; ++j) {
-                SW r = d % (SW)R.mod[j].q;
-                if (r < 0) r += (SW)R.mod[j].q;
-                out[j * n + k] = (W)r;
-            }
+            for (size_t j = 0; j < L; ++j) out[j * n + k] = (W)reduce_signed<W>(d, R.mod[j].q);
         }
     }
 }
@@ -263,24 +289,25 @@ __global__ void k_tensor_ew(DevRing<W> R, const W* a, const W* b, W* out, W* c2b
     // results are zero (modSwitch up: Rescale b -> (a,b), its q_a factor folded into sr2 by the host)
     const size_t n = (size_t)R.n;
     const size_t Ln = (size_t)R.L * n, Lsn = (size_t)(R.L - dup) * n, off = (size_t)dup * n;
-    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < nct * Ln; w += (size_t)gridDim.x * blockDim.x) {
-        const size_t ct = w / Ln, rem = w % Ln;
+    ALCH_WALK_INIT(R.n, R.L);
+    ALCH_WALK(w, nct * Ln, wk) {
+        const size_t ct = wk.outer, rem = (size_t)wk.mid * n + wk.k;
         if (rem < off) {
             out[2 * ct * Ln + rem] = 0; out[(2 * ct + 1) * Ln + rem] = 0; c2buf[ct * Ln + rem] = 0;
             if (c2crt) c2crt[ct * Ln + rem] = 0;
             continue;
         }
-        const size_t rs = rem - off, js = rs / n;
-        const ModP<W> m = R.mod[rem / n];
+        const size_t rs = rem - off, js = wk.mid - (u32)dup;
+        const ModP<W> m = R.mod[wk.mid];
         const W a0 = a[2 * ct * Lsn + rs], a1 = a[(2 * ct + 1) * Lsn + rs];
         const W b0 = b[2 * ct * Lsn + rs], b1 = b[(2 * ct + 1) * Lsn + rs];
         const W x0 = mont_mul(a0, sr2.v[js], m), x1 = mont_mul(a1, sr2.v[js], m);      // a s R
         W c0v = mont_mul(b0, x0, m);
         W c1v = add_mod(mont_mul(b1, x0, m), mont_mul(b0, x1, m), m.q);
         W c2v = mont_mul(b1, x1, m);
-        const W* g = gt.p[rem / n];
+        const W* g = gt.p[wk.mid];
         if (g) {
-            const W gv = g[rem % n];
+            const W gv = g[wk.k];
             c0v = mont_mul(c0v, gv, m); c1v = mont_mul(c1v, gv, m); c2v = mont_mul(c2v, gv, m);
         }
         out[2 * ct * Ln + rem] = c0v;
@@ -302,10 +329,11 @@ __global__ void k_hint_mac(DevRing<W> R, W* out, const W* digits, const W* hint,
     const size_t n = (size_t)R.n;
     const size_t Ln = (size_t)R.L * n;
     const size_t ntile = (nct + TILE - 1) / TILE;
-    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < ntile * Ln; w += (size_t)gridDim.x * blockDim.x) {
-        const size_t ct0 = (w / Ln) * TILE, rem = w % Ln;
-        const ModP<W> m = R.mod[rem / n];
-        const u32 limb = (u32)(rem / n);
+    ALCH_WALK_INIT(R.n, R.L);
+    ALCH_WALK(w, ntile * Ln, wk) {
+        const size_t ct0 = wk.outer * TILE, rem = (size_t)wk.mid * n + wk.k;
+        const u32 limb = wk.mid;
+        const ModP<W> m = R.mod[limb];
         W acc0[TILE], acc1[TILE];
 #pragma unroll
         for (int c = 0; c < TILE; ++c) {
@@ -341,14 +369,14 @@ __global__ void k_rescale_drop0(DevRing<W> R, const W* src, W* dst, size_t elems
     const size_t L = (size_t)R.L;
     const size_t total = elems * (L - 1) * n;
     const W q0 = R.mod[0].q;
-    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < total; w += (size_t)gridDim.x * blockDim.x) {
-        const size_t k = w % n, jm = (w / n) % (L - 1), e = w / (n * (L - 1));
-        const size_t j = jm + 1;
+    ALCH_WALK_INIT(R.n, R.L - 1);
+    ALCH_WALK(w, total, wk) {
+        const size_t k = wk.k, e = wk.outer;
+        const size_t j = (size_t)wk.mid + 1;
         const ModP<W> m = R.mod[j];
         const W x0 = src[(e * L) * n + k];
         const SW z = x0 > ((q0 - 1) >> 1) ? (SW)x0 - (SW)q0 : (SW)x0;
-        SW zr = z % (SW)m.q;
-        if (zr < 0) zr += (SW)m.q;
+        const SW zr = reduce_signed<W>(z, m.q);
         const W d = sub_mod(src[(e * L + j) * n + k], (W)zr, m.q);
         dst[w] = mont_mul(d, q0inv_m.v[j], m);
     }
@@ -360,8 +388,9 @@ __global__ void k_rescale_add0(DevRing<W> Rd, const W* src, W* dst, size_t elems
     const size_t n = (size_t)Rd.n;
     const size_t L = (size_t)Rd.L;
     const size_t total = elems * L * n;
-    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < total; w += (size_t)gridDim.x * blockDim.x) {
-        const size_t k = w % n, j = (w / n) % L, e = w / (n * L);
+    ALCH_WALK_INIT(Rd.n, Rd.L);
+    ALCH_WALK(w, total, wk) {
+        const size_t k = wk.k, j = wk.mid, e = wk.outer;
         dst[w] = j == 0 ? (W)0 : mont_mul(src[(e * (L - 1) + (j - 1)) * n + k], qa_m.v[j], Rd.mod[j]);
     }
 }
@@ -369,20 +398,18 @@ __global__ void k_rescale_add0(DevRing<W> Rd, const W* src, W* dst, size_t elems
 // mulGCRT / divGCRT: element-wise product with a per-limb table of n words (Montgomery form).
 template <typename W>
 __global__ void k_mul_table(DevRing<W> R, W* data, size_t words, GTab<W> gt) {
-    const size_t n = (size_t)R.n;
-    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < words; w += (size_t)gridDim.x * blockDim.x) {
-        const int j = (int)((w / n) % (size_t)R.L);
-        data[w] = mont_mul(data[w], gt.p[j][w % n], R.mod[j]);
-    }
+    ALCH_WALK_INIT(R.n, R.L);
+    ALCH_WALK(w, words, wk) data[w] = mont_mul(data[w], gt.p[wk.mid][wk.k], R.mod[wk.mid]);
 }
 
 // SymmSHE mulPublic (Eval.hs:132): every ring element of src times one public ring element (CRT basis, pointwise).
 template <typename W>
 __global__ void k_mul_bcast(DevRing<W> R, W* dst, const W* src, const W* pub, size_t words) {
-    const size_t n = (size_t)R.n, Ln = (size_t)R.L * n;
-    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < words; w += (size_t)gridDim.x * blockDim.x) {
-        const ModP<W> m = R.mod[(w / n) % (size_t)R.L];
-        dst[w] = mont_mul(mont_mul(src[w], m.r2, m), pub[w % Ln], m);
+    const size_t n = (size_t)R.n;
+    ALCH_WALK_INIT(R.n, R.L);
+    ALCH_WALK(w, words, wk) {
+        const ModP<W> m = R.mod[wk.mid];
+        dst[w] = mont_mul(mont_mul(src[w], m.r2, m), pub[(size_t)wk.mid * n + wk.k], m);
     }
 }
 
@@ -390,10 +417,11 @@ __global__ void k_mul_bcast(DevRing<W> R, W* dst, const W* src, const W* pub, si
 template <typename W>
 __global__ void k_add_bcast(DevRing<W> R, W* dst, const W* pub, size_t cts) {
     const size_t n = (size_t)R.n, Ln = (size_t)R.L * n;
-    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < cts * Ln; w += (size_t)gridDim.x * blockDim.x) {
-        const size_t ct = w / Ln, rem = w % Ln;
+    ALCH_WALK_INIT(R.n, R.L);
+    ALCH_WALK(w, cts * Ln, wk) {
+        const size_t ct = wk.outer, rem = (size_t)wk.mid * n + wk.k;
         W* p = dst + 2 * ct * Ln + rem;
-        *p = add_mod(*p, pub[rem], R.mod[rem / n].q);
+        *p = add_mod(*p, pub[rem], R.mod[wk.mid].q);
     }
 }
 
@@ -403,9 +431,12 @@ template <typename W>
 __global__ void k_tunnel_gather(DevRing<W> Rs, const W* in, W* x0, W* x1, const int32_t* table, u32 d_rel, u32 n_r, size_t nct, Scal<W> s_m, int scale) {
     const size_t n = (size_t)Rs.n, L = (size_t)Rs.L;
     const size_t per_ct = (size_t)d_rel * L * n;
-    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < nct * 2 * per_ct; w += (size_t)gridDim.x * blockDim.x) {
-        const size_t ct = w / (2 * per_ct), rem = w % (2 * per_ct), comp = rem / per_ct, r2 = rem % per_ct;
-        const size_t i = r2 / (L * n), limb = (r2 / n) % L, k = r2 % n;
+    // words as [ct * 2 + comp][i * L + limb][k]
+    ALCH_WALK_INIT(Rs.n, d_rel * Rs.L);
+    ALCH_WALK(w, nct * 2 * per_ct, wk) {
+        const size_t ct = wk.outer >> 1, comp = wk.outer & 1, k = wk.k;
+        const u32 i = wk.mid / (u32)L, limb = wk.mid - i * (u32)L;
+        const size_t r2 = (size_t)wk.mid * n + k;
         const int32_t src = table[i * n + k];
         W v = 0;
         if (src >= 0) {
@@ -420,9 +451,10 @@ __global__ void k_tunnel_gather(DevRing<W> Rs, const W* in, W* x0, W* x1, const 
 template <typename W>
 __global__ void k_tunnel_lin(DevRing<W> Rs, W* out, const W* x0crt, const W* lin, u32 d_rel, size_t nct) {
     const size_t n = (size_t)Rs.n, Ln = (size_t)Rs.L * n;
-    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < nct * Ln; w += (size_t)gridDim.x * blockDim.x) {
-        const size_t ct = w / Ln, rem = w % Ln;
-        const ModP<W> m = Rs.mod[rem / n];
+    ALCH_WALK_INIT(Rs.n, Rs.L);
+    ALCH_WALK(w, nct * Ln, wk) {
+        const size_t ct = wk.outer, rem = (size_t)wk.mid * n + wk.k;
+        const ModP<W> m = Rs.mod[wk.mid];
         W acc = 0;
         for (u32 i = 0; i < d_rel; ++i) acc = add_mod(acc, mont_mul(x0crt[(ct * d_rel + i) * Ln + rem], lin[(size_t)i * Ln + rem], m), m.q);
         out[2 * ct * Ln + rem] = acc;
@@ -434,8 +466,9 @@ __global__ void k_tunnel_lin(DevRing<W> Rs, W* out, const W* x0crt, const W* lin
 template <typename W>
 __global__ void k_rescale_up(DevRing<W> Rd, const W* src, W* dst, size_t elems, int dup, Scal<W> mult_m) {
     const size_t n = (size_t)Rd.n, L = (size_t)Rd.L, Ls = L - (size_t)dup;
-    for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < elems * L * n; w += (size_t)gridDim.x * blockDim.x) {
-        const size_t k = w % n, j = (w / n) % L, e = w / (n * L);
+    ALCH_WALK_INIT(Rd.n, Rd.L);
+    ALCH_WALK(w, elems * L * n, wk) {
+        const size_t k = wk.k, j = wk.mid, e = wk.outer;
         dst[w] = j < (size_t)dup ? (W)0 : mont_mul(src[(e * Ls + (j - dup)) * n + k], mult_m.v[j], Rd.mod[j]);
     }
 }
