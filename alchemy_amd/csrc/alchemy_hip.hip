@@ -30,7 +30,7 @@ struct alch_ring {
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void* tables = nullptr;                    // all twiddle tables, one allocation
-    void* tables_p = nullptr;                  // Plantard forward constants (32-bit rings)
+    void* tables_p = nullptr;                  // Plantard forward constants (32-bit rings) / Shoup pairs (64-bit rings)
     DevRing<u32> d32;
     DevRing<u64> d64;
     void* ws_digits = nullptr;                 // digit scratch, two halves of [chunk][L][n] signed words
@@ -536,6 +536,28 @@ static int build_dev_ring(alch_ring* r, DevRing<W>& d) {
         HIP_TRY(hipMalloc(&r->tables_p, pl.size() * sizeof(u64)));
         HIP_TRY(hipMemcpy(r->tables_p, pl.data(), pl.size() * sizeof(u64), hipMemcpyHostToDevice));
         for (int j = 0; j < L; ++j) d.twp[j] = reinterpret_cast<const u64*>(r->tables_p) + (size_t)j * n;
+    } else {
+        // 64-bit rings: the transforms multiply by Shoup pairs (plain twiddle, floor(w 2^64 / q)); the Montgomery
+        // tables above still serve the hand-written stage 0 of the split kernels
+        std::vector<Sh64> sh(2 * (size_t)L * n);
+        for (int j = 0; j < L; ++j) {
+            const u64 q = r->q[j];
+            const u64 psi = h_root(q, r->m), ipsi = h_powmod(psi, q - 2, q);
+            std::vector<u64> pw(n), ipw(n);
+            u64 a = 1, b = 1;
+            for (size_t i = 0; i < n; ++i) { pw[i] = a; ipw[i] = b; a = h_mulmod(a, psi, q); b = h_mulmod(b, ipsi, q); }
+            for (size_t k = 0; k < n; ++k) {
+                const u32 e = h_brev((u32)k, r->logn);
+                sh[(size_t)(2 * j) * n + k] = h_shoup_const(pw[e], q);
+                sh[(size_t)(2 * j + 1) * n + k] = h_shoup_const(ipw[e], q);
+            }
+        }
+        HIP_TRY(hipMalloc(&r->tables_p, sh.size() * sizeof(Sh64)));
+        HIP_TRY(hipMemcpy(r->tables_p, sh.data(), sh.size() * sizeof(Sh64), hipMemcpyHostToDevice));
+        for (int j = 0; j < L; ++j) {
+            d.tws[j] = reinterpret_cast<const Sh64*>(r->tables_p) + (size_t)(2 * j) * n;
+            d.twsi[j] = reinterpret_cast<const Sh64*>(r->tables_p) + (size_t)(2 * j + 1) * n;
+        }
     }
     return ALCH_OK;
 }
@@ -1811,6 +1833,7 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
         for (int j = 0; j + u < L; ++j) {
             d.mod[j] = d.mod[j + u]; d.ninv_m[j] = d.ninv_m[j + u]; d.w1ninv_m[j] = d.w1ninv_m[j + u];
             d.twf[j] = d.twf[j + u]; d.twi[j] = d.twi[j + u]; d.twp[j] = d.twp[j + u];
+            d.tws[j] = d.tws[j + u]; d.twsi[j] = d.twsi[j + u];
         }
         return d;
     };

@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(Geo<LOGN - 1>::T) k_crt_split(DevRing<W> R, W*
             lds_barrier();
             int t2 = tid;
             asm volatile("" : "+v"(t2));
-            ntt_forward<LOGM, W, false>(lds, fwd_tw(R, j), R.twf[j], q, qni, t2, NoEpilogue(), 2 + half);
+            ntt_forward<LOGM, W, false>(lds, fwd_tw(R, j), fwd_twm(R, j), q, qni, t2, NoEpilogue(), 2 + half);
 #pragma unroll
             for (int r = 0; r < G::E / VL; ++r) {
                 const int idx = (t2 + G::T * r) * VL;
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(Geo<LOGN - 1>::T) k_crt_split(DevRing<W> R, W*
             lds_barrier();
             int t2 = tid;
             asm volatile("" : "+v"(t2));
-            ntt_inverse<LOGM, W, false, false, false>(lds, R.twi[j], q, qni, (W)0, (W)0, t2, NoEpilogue(), NoHook(), 2 + half);
+            ntt_inverse<LOGM, W, false, false, false>(lds, inv_tw(R, j), q, qni, (W)0, (W)0, t2, NoEpilogue(), NoHook(), 2 + half);
             if (half == 0) {
 #pragma unroll
                 for (int r = 0; r < G::E / VL; ++r) {
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(Geo<LOGN - 1>::T) k_crt_split_digits(DevRing<W
         lds_barrier();
         int t2 = tid;
         asm volatile("" : "+v"(t2));
-        ntt_forward<LOGM, W, false>(lds, fwd_tw(R, j), R.twf[j], q, qni, t2, NoEpilogue(), 2 + half);
+        ntt_forward<LOGM, W, false>(lds, fwd_tw(R, j), fwd_twm(R, j), q, qni, t2, NoEpilogue(), 2 + half);
 #pragma unroll
         for (int r = 0; r < G::E / VL; ++r) {
             const int idx = (t2 + G::T * r) * VL;
@@ -258,7 +258,7 @@ k_ks_accum_split(DevRing<W> R, const W* __restrict__ c2pow, const W* __restrict_
         const W* h0 = hj + (size_t)(2 * i) * Ln;
         const W* h1 = hj + (size_t)(2 * i + 1) * Ln;
         auto twf = fwd_tw(R, j);
-        const W* twm = R.twf[j];
+        auto twm = fwd_twm(R, j);
         int tid = threadIdx.x;
         asm volatile("" : "+s"(twf), "+s"(twm), "+v"(tid));  // keep pass addresses / twiddles inside the digit loop (VGPR pressure)
         ntt_forward<LOGM, W, true, true>(lds, twf, twm, q, qni, tid, [&acc0, &acc1, h0, h1, q, qni](int g, int base, W* x) {

@@ -100,10 +100,10 @@ k_rescale_out(DevRing<W> R, const W* __restrict__ src, W* __restrict__ out, type
                     for (int k = 0; k < RR; ++k) lds[swz<LOGN>(base + k * STRIDE)] = v[k];   // the words this lane just read
                 }
             };
-            ntt_inverse<LOGN, W, true>(lds, R.twi[t], q, qni, R.ninv_m[t], R.w1ninv_m[t], tid, epi);
+            ntt_inverse<LOGN, W, true>(lds, inv_tw(R, t), q, qni, R.ninv_m[t], R.w1ninv_m[t], tid, epi);
             if (t >= ddn && !pow_out) {
                 lds_barrier();
-                ntt_forward<LOGN, W, false>(lds, fwd_tw(R, t), R.twf[t], q, qni, tid, NoEpilogue());
+                ntt_forward<LOGN, W, false>(lds, fwd_tw(R, t), fwd_twm(R, t), q, qni, tid, NoEpilogue());
 #pragma unroll
                 for (int r = 0; r < G::E / VL; ++r) {
                     const int idx = (tid + G::T * r) * VL;
@@ -184,7 +184,7 @@ k_rescale_out_lin(DevRing<W> R, const W* __restrict__ src, W* __restrict__ out, 
                     if constexpr (u == 0) rr0[g * RR + k] = lifted; else rr1[g * RR + k] = lifted;
                 }
             };
-            ntt_inverse<LOGN, W, true, (u > 0)>(lds, R.twi[u], q, qni, R.ninv_m[u], R.w1ninv_m[u], tid, epi);
+            ntt_inverse<LOGN, W, true, (u > 0)>(lds, inv_tw(R, u), q, qni, R.ninv_m[u], R.w1ninv_m[u], tid, epi);
         };
         drop_limb(std::integral_constant<int, 0>());
         if constexpr (DDN > 1) drop_limb(std::integral_constant<int, 1>());
@@ -213,7 +213,7 @@ k_rescale_out_lin(DevRing<W> R, const W* __restrict__ src, W* __restrict__ out, 
             const u32 xt = x + (u32)t * ROW, ot = o + (u32)(t - DDN) * ROW;
             const W Ct = D.comb_m[0][t];
             auto twf = fwd_tw(R, t);
-            const W* twm = R.twf[t];
+            auto twm = fwd_twm(R, t);
             ntt_forward<LOGN, W, true, true>(lds, twf, twm, q, qni, tid, [&](int, int base, W* v) {
 #pragma unroll
                 for (int k = 0; k < 16; k += VL) {

@@ -30,6 +30,8 @@ struct DevRing {
     const W* twf[MAXL];  // forward twiddles (device, Montgomery form), n words
     const W* twi[MAXL];  // inverse twiddles
     const u64* twp[MAXL]; // forward twiddles as Plantard constants (32-bit rings only), n x 8 bytes
+    const Sh64* tws[MAXL];  // 64-bit rings: forward twiddles as Shoup pairs (plain residue, floor(w 2^64 / q)), n x 16 bytes
+    const Sh64* twsi[MAXL]; // 64-bit rings: inverse twiddles likewise
 };
 
 // Forward-transform twiddle table of limb j.  ALCH_USE_PLANTARD=1 switches 32-bit rings to Plantard constants
@@ -44,7 +46,12 @@ __device__ __forceinline__ const u64* fwd_tw(const DevRing<u32>& R, int j) { ret
 #else
 __device__ __forceinline__ const u32* fwd_tw(const DevRing<u32>& R, int j) { return R.twf[j]; }
 #endif
-__device__ __forceinline__ const u64* fwd_tw(const DevRing<u64>& R, int j) { return R.twf[j]; }
+__device__ __forceinline__ const Sh64* fwd_tw(const DevRing<u64>& R, int j) { return R.tws[j]; }
+// table of the forward transform's last pass (per-lane twiddles) and of the inverse transform
+__device__ __forceinline__ const u32* fwd_twm(const DevRing<u32>& R, int j) { return R.twf[j]; }
+__device__ __forceinline__ const Sh64* fwd_twm(const DevRing<u64>& R, int j) { return R.tws[j]; }
+__device__ __forceinline__ const u32* inv_tw(const DevRing<u32>& R, int j) { return R.twi[j]; }
+__device__ __forceinline__ const Sh64* inv_tw(const DevRing<u64>& R, int j) { return R.twsi[j]; }
 
 template <typename W> struct Scal { W v[MAXL]; };   // per-limb scalars passed by value
 
@@ -140,8 +147,8 @@ __global__ void __launch_bounds__(Geo<LOGN>::T) k_crt(DevRing<W> R, W* data, con
 
     stage_in<LOGN, W>(lds, [&](int idx) { return *reinterpret_cast<const V*>(in + idx); });
     lds_barrier();
-    if constexpr (!INVERSE) ntt_forward<LOGN, W, false>(lds, fwd_tw(R, j), R.twf[j], q, qni, (int)threadIdx.x, NoEpilogue());
-    else ntt_inverse<LOGN, W, false>(lds, R.twi[j], q, qni, R.ninv_m[j], R.w1ninv_m[j], (int)threadIdx.x, NoEpilogue());
+    if constexpr (!INVERSE) ntt_forward<LOGN, W, false>(lds, fwd_tw(R, j), fwd_twm(R, j), q, qni, (int)threadIdx.x, NoEpilogue());
+    else ntt_inverse<LOGN, W, false>(lds, inv_tw(R, j), q, qni, R.ninv_m[j], R.w1ninv_m[j], (int)threadIdx.x, NoEpilogue());
 #pragma unroll
     for (int r = 0; r < G::E / VL; ++r) {
         const int idx = (threadIdx.x + G::T * r) * VL;
@@ -191,7 +198,7 @@ __global__ void __launch_bounds__(Geo<LOGN>::T) k_crt_base2_digits(DevRing<W> R,
         return o;
     });
     lds_barrier();
-    ntt_forward<LOGN, W, false>(lds, fwd_tw(R, j), R.twf[j], q, qni, (int)threadIdx.x, NoEpilogue());
+    ntt_forward<LOGN, W, false>(lds, fwd_tw(R, j), fwd_twm(R, j), q, qni, (int)threadIdx.x, NoEpilogue());
 #pragma unroll
     for (int r = 0; r < G::E / VL; ++r) {
         const int idx = (threadIdx.x + G::T * r) * VL;
@@ -326,7 +333,7 @@ k_tensor_intt(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
 #ifdef ALCH_STAMPS
         if constexpr (LOGN == 15) {            // ntt_inverse spelled out so that the passes can be stamped
             NoEpilogue none;
-            const W* twi = R.twi[i];
+            auto twi = inv_tw(R, i);
             ntt_pass<LOGN, G::LOGT, W, 11, 4, true, false, false>(lds, twi, q, qni, R.ninv_m[i], R.w1ninv_m[i], tid, 1, none);
             TI_STAMP(6); pair_sync<LOGN>(); TI_STAMP(3);
             ntt_pass<LOGN, G::LOGT, W, 7, 4, true, false, false>(lds, twi, q, qni, R.ninv_m[i], R.w1ninv_m[i], tid, 1, none);
@@ -339,7 +346,7 @@ k_tensor_intt(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
         } else
 #endif
         if (!TI_DBG(2u))
-        ntt_inverse<LOGN, W, true>(lds, R.twi[i], q, qni, ninv_s, w1ninv_s, tid, epi,
+        ntt_inverse<LOGN, W, true>(lds, inv_tw(R, i), q, qni, ninv_s, w1ninv_s, tid, epi,
                                    [&]() { if (item + gridDim.x < nitems) issue(item + gridDim.x); });
         lds_barrier();                       // every lane has read its last-pass inputs before LDS is refilled
         TI_STAMP(5);
@@ -441,7 +448,7 @@ k_ks_accum(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
         // compiler hoists every pass's address arithmetic and twiddle loads out of the digit loop and
         // spills ~250 VGPRs per lane.
         auto twf = fwd_tw(R, j);
-        const W* twm = R.twf[j];
+        auto twm = fwd_twm(R, j);
         int tid = threadIdx.x;
         asm volatile("" : "+s"(twf), "+s"(twm), "+v"(tid));
         ntt_forward<LOGN, W, true, true>(lds, twf, twm, q, qni, tid, [&acc0, &acc1, h0, h1, q, qni](int g, int base, W* x) {

@@ -107,6 +107,52 @@ ALCH_HD void bfly_inv(W& x, W& y, W w, W q, W qni) {
     y = mont_mul_lazy((W)(a - b + q), w, q, qni);
 }
 
+// ---- 64-bit rings: Shoup twiddles ----------------------------------------------------------------------
+// A 64-bit Montgomery product is 11 multiplier instructions and, with the register-pair moves hipcc needs for the
+// zero-extended addends, 27 VALU instructions.  A product by a CONSTANT w (a twiddle) with the precomputed quotient
+// w' = floor(w 2^64 / q) (Shoup / Harvey, "Faster arithmetic for number-theoretic transforms", 2014):
+//     Q = hi64(a w'),   r = a w - Q q  (mod 2^64)   in [0, 2q)   for ANY 64-bit a
+// needs the high half of one product and the low halves of two: 17 VALU instructions (the subtraction rides on the
+// multiply-add chain as + Q (2^64 - q)).  4q < 2^64 for every supported modulus (q < 2^62), so the forward butterflies
+// are Harvey's: values in [0,4q) inside a register-resident pass, one conditional subtraction per butterfly, and
+// [0,2q) again at the pass boundary (what every loader and epilogue of the engine expects).  w is a plain residue
+// (ring data are never in Montgomery form), two words per twiddle.
+struct alignas(16) Sh64 { u64 w, wp; };
+
+ALCH_HD u64 shoup_mul_lazy(u64 a, Sh64 t, u64 q) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), p0 = (u32)t.wp, p1 = (u32)(t.wp >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u64 m1 = (u64)a1 * p0 + __umulhi(a0, p0);
+#else
+    const u64 m1 = (u64)a1 * p0 + (((u64)a0 * p0) >> 32);
+#endif
+    const u64 m2 = (u64)a0 * p1 + (u32)m1;
+    const u64 Q = (u64)a1 * p1 + ((m1 >> 32) + (m2 >> 32));     // hi64(a w'), exact
+    return a * t.w + Q * ((u64)0 - q);
+}
+
+// Forward butterfly of stage r of a register-resident pass (FIRST: inputs in [0,2q), else [0,4q); LAST: outputs
+// reduced to [0,2q), else left in [0,4q)).
+// (first / last are compile-time constants after the stage loops are unrolled)
+ALCH_HD void bfly_fwd_st(u64& x, u64& y, Sh64 w, u64 q, u64 /*qni*/, bool FIRST, bool LAST) {
+    const u64 q2 = 2 * q;
+    const u64 xx = FIRST ? x : csub(x, q2);
+    const u64 t = shoup_mul_lazy(y, w, q);
+    x = xx + t;
+    y = xx + (q2 - t);
+    if (LAST) { x = csub(x, q2); y = csub(y, q2); }
+}
+// Inverse (Gentleman-Sande) butterfly, [0,2q) in and out: one conditional subtraction.
+ALCH_HD void bfly_inv(u64& x, u64& y, Sh64 w, u64 q, u64 /*qni*/) {
+    const u64 q2 = 2 * q;
+    const u64 s = x + y, d = x + (q2 - y);
+    x = csub(s, q2);
+    y = shoup_mul_lazy(d, w, q);
+}
+// every other twiddle type: the stage position does not matter
+template <typename W, typename TW>
+ALCH_HD void bfly_fwd_st(W& x, W& y, TW w, W q, W qni, bool, bool) { bfly_fwd(x, y, w, q, qni); }
+
 // ---- host-side helpers (table building) ------------------------------------------------------
 inline u64 h_mulmod(u64 a, u64 b, u64 q) { return (u64)(((unsigned __int128)a * b) % q); }
 inline u64 h_powmod(u64 b, u64 e, u64 q) {
@@ -118,6 +164,13 @@ inline u64 h_powmod(u64 b, u64 e, u64 q) {
         e >>= 1;
     }
     return r;
+}
+
+inline Sh64 h_shoup_const(u64 c, u64 q) {
+    Sh64 t;
+    t.w = c;
+    t.wp = (u64)((((unsigned __int128)c) << 64) / q);
+    return t;
 }
 
 // Plantard constant of c (< q) for modulus q < 2^31.

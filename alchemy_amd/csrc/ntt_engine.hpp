@@ -105,6 +105,9 @@ __device__ __forceinline__ void load_tw(const W* __restrict__ tw, int first, W (
         const int f = __builtin_amdgcn_readfirstlane(first);
 #pragma unroll
         for (int c = 0; c < CNT; ++c) w[c] = tw[f + c];
+    } else if constexpr (sizeof(W) == 16) {               // two-word Shoup twiddles: one 16-byte load each
+#pragma unroll
+        for (int c = 0; c < CNT; ++c) w[c] = tw[first + c];
     } else if constexpr (sizeof(W) == 4 && CNT >= 4) {
         typedef u32 V __attribute__((ext_vector_type(4)));
 #pragma unroll
@@ -198,7 +201,7 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const TW* __restri
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     if (k & half) continue;
-                    bfly_fwd(x[k], x[k + half], w[k >> (NS - r)], q, qni);
+                    bfly_fwd_st(x[k], x[k + half], w[k >> (NS - r)], q, qni, r == 0, r == NS - 1);
                 }
             }
         } else {
@@ -275,15 +278,16 @@ __device__ __forceinline__ void pair_sync() {
     else lds_barrier();
 }
 
-template <int LOGN, typename W, bool KEEP_LAST, bool SERIAL = false, typename TW, typename Epi>
-__device__ __forceinline__ void ntt_forward(W* lds, const TW* tw, const W* twm, W q, W qni, int tid, Epi&& epi,
+template <int LOGN, typename W, bool KEEP_LAST, bool SERIAL = false, typename TW, typename TWM, typename Epi>
+__device__ __forceinline__ void ntt_forward(W* lds, const TW* tw, const TWM* twm, W q, W qni, int tid, Epi&& epi,
                                             int prefix = 1) {
     // prefix != 1: the transform is one half of a transform twice its size whose stage 0 ran elsewhere
     // (k_crt_split); tw / twm are then the tables of the big ring.
     // tw : twiddle table for the passes whose twiddles are shared by many lanes (Plantard constants on 32-bit
     //      rings: one instruction less per butterfly, fetched by scalar or broadcast loads);
     // twm: Montgomery table for the last pass, where every lane needs its own 15 twiddles and two-word
-    //      constants would double the per-lane load traffic and register pressure.
+    //      constants would double the per-lane load traffic and register pressure (64-bit rings: Shoup pairs in every
+    //      pass -- a two-word twiddle still beats a 27-instruction Montgomery product).
     typedef Geo<LOGN> G;
     constexpr int P = G::NPASS, F = G::NS0, LT = G::LOGT;
     NoEpilogue none;
@@ -318,8 +322,8 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // the transform issues no vector-memory loads, so global loads started in the hook (a prefetch for the next
 // work item) are never waited for by this transform -- vmcnt retires in order, and a later twiddle load would
 // otherwise drag the whole prefetch's HBM latency into the pass.
-template <int LOGN, typename W, bool KEEP_LAST, bool SERIAL = false, bool FOLD = true, typename Epi, typename Hook = NoHook>
-__device__ __forceinline__ void ntt_inverse(W* lds, const W* twi, W q, W qni, W ninv_m, W w1ninv_m, int tid,
+template <int LOGN, typename W, bool KEEP_LAST, bool SERIAL = false, bool FOLD = true, typename TWI, typename Epi, typename Hook = NoHook>
+__device__ __forceinline__ void ntt_inverse(W* lds, const TWI* twi, W q, W qni, W ninv_m, W w1ninv_m, int tid,
                                             Epi&& epi, Hook&& hook = NoHook(), int prefix = 1) {
     // FOLD = false, prefix = 2 + half: the stages 1.. of a transform twice this size on one half of its slots
     // (k_crt_split); the caller runs stage 0 and the n^-1 scaling itself.
@@ -330,14 +334,14 @@ __device__ __forceinline__ void ntt_inverse(W* lds, const W* twi, W q, W qni, W 
     constexpr bool U3 = (LOGN - (F + 8) - 4 >= 6), U2 = (LOGN - (F + 4) - 4 >= 6), U1 = (LOGN - F - 4 >= 6);
     bool hooked = false;
     if constexpr (P >= 4) { if (U3 && !hooked) { hook(); hooked = true; }
-        ntt_pass<LOGN, LT, W, F + 8, 4, true, false, SERIAL, W, NoEpilogue&, FOLD>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, prefix, none); pair_sync<LOGN>(); }
+        ntt_pass<LOGN, LT, W, F + 8, 4, true, false, SERIAL, TWI, NoEpilogue&, FOLD>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, prefix, none); pair_sync<LOGN>(); }
     if constexpr (P >= 3) { if (U2 && !hooked) { hook(); hooked = true; }
-        ntt_pass<LOGN, LT, W, F + 4, 4, true, false, SERIAL, W, NoEpilogue&, FOLD>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, prefix, none);
+        ntt_pass<LOGN, LT, W, F + 4, 4, true, false, SERIAL, TWI, NoEpilogue&, FOLD>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, prefix, none);
         if constexpr (P == 3) pair_sync<LOGN>(); else lds_barrier(); }
     if constexpr (P >= 2) { if (U1 && !hooked) { hook(); hooked = true; }
-        ntt_pass<LOGN, LT, W, F, 4, true, false, SERIAL, W, NoEpilogue&, FOLD>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, prefix, none); lds_barrier(); }
+        ntt_pass<LOGN, LT, W, F, 4, true, false, SERIAL, TWI, NoEpilogue&, FOLD>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, prefix, none); lds_barrier(); }
     if (!hooked) hook();
-    ntt_pass<LOGN, LT, W, 0, F, true, KEEP_LAST, SERIAL, W, Epi&, FOLD>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, prefix, epi);
+    ntt_pass<LOGN, LT, W, 0, F, true, KEEP_LAST, SERIAL, TWI, Epi&, FOLD>(lds, twi, q, qni, ninv_m, w1ninv_m, tid, prefix, epi);
     if constexpr (!KEEP_LAST) lds_barrier();
 }
 
