@@ -827,6 +827,7 @@ extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) 
     else if (k == "ti_grid") r->opts.ti_grid = (int)value;
     else if (k == "ti_split") { if (value < 0) return fail(ALCH_E_INVALID, "ti_split must be >= 0"); r->opts.ti_split = (int)value; }
     else if (k == "rs_lin") r->opts.rs_lin = value != 0;
+    else if (k == "crt_half") r->opts.crt_half = value != 0;
     else if (k == "gen_fused") r->opts.gen_fused = value != 0;
     else if (k == "split_fused") r->opts.split_fused = value != 0;
     else if (k == "scratch_mib") { if (value < 1 || value > 65536) return fail(ALCH_E_INVALID, "scratch_mib must be 1 .. 65536"); r->scratch_mib = (size_t)value; }

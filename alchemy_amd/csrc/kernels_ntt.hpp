@@ -61,6 +61,7 @@ template <> struct Signed<u64> { typedef int64_t type; };
 
 }  // namespace alch
 #include "kernel_ks_half.hpp"
+#include "kernel_crt_half.hpp"
 namespace alch {
 
 enum OpKind { OP_CRT = 0, OP_CRTINV = 1, OP_TENSOR_INTT = 2, OP_KS_ACCUM = 3, OP_RESCALE_OUT = 4,
@@ -84,6 +85,7 @@ struct LaunchOpts {
     int split_fused = 1;     // n = 2^16 (32-bit) / 2^15 (64-bit): digit transforms + hint products in one kernel (k_ks_accum_split)
     int gen_fused = 0;       // general index: 1 = fused tensor + key switch kernels (kernel_gen.hpp).  Measured 0.69-0.82x the composed
                              // path on H0'..H5' (48 accumulators + a CRT_13 pass spill at 128 VGPRs, 4-byte global accesses): off
+    int crt_half = 1;        // crt / crtInv of a 128-KiB limb-polynomial: 1 = two half-size workgroups per CU (k_crt_half), 0 = k_crt
     int rs_lin = 1;          // closing modSwitch: 1 = kept limbs stay in the CRT basis (k_rescale_out_lin), 0 = every limb through the Pow basis
     unsigned ks_grid = 4096; // persistent workgroups of k_ks_accum_half (measured, 1024-ciphertext chunks: 2048 -> 511k, 4096 -> 517k, 8192 -> 513k op/s)
 };
@@ -502,12 +504,30 @@ inline hipError_t run_call(const NttCall<W>& c) {
     hipError_t e;
     switch (c.op) {
     case OP_CRT: {
+        if constexpr ((sizeof(W) == 4 && LOGN == 15) || (sizeof(W) == 8 && LOGN == 14)) {
+            if (c.opts.crt_half) {             // 128-KiB polynomials: two half-size workgroups per CU (kernel_crt_half.hpp)
+                auto k = k_crt_half<LOGN, W, false>;
+                const size_t hb = (size_t)lds_words<LOGN - 1>() * sizeof(W);
+                if ((e = set_lds(k, hb)) != hipSuccess) return e;
+                hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(1 << CrtHalfGeo<LOGN, W>::LT), hb, c.stream, R, c.data, c.src, c.first_poly);
+                break;
+            }
+        }
         auto k = k_crt<LOGN, W, false>;
         if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(G::T), lds_bytes, c.stream, R, c.data, c.src, c.first_poly);
         break;
     }
     case OP_CRTINV: {
+        if constexpr ((sizeof(W) == 4 && LOGN == 15) || (sizeof(W) == 8 && LOGN == 14)) {
+            if (c.opts.crt_half) {
+                auto k = k_crt_half<LOGN, W, true>;
+                const size_t hb = (size_t)lds_words<LOGN - 1>() * sizeof(W);
+                if ((e = set_lds(k, hb)) != hipSuccess) return e;
+                hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(1 << CrtHalfGeo<LOGN, W>::LT), hb, c.stream, R, c.data, c.src, c.first_poly);
+                break;
+            }
+        }
         auto k = k_crt<LOGN, W, true>;
         if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(G::T), lds_bytes, c.stream, R, c.data, c.src, c.first_poly);

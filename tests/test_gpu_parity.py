@@ -143,3 +143,28 @@ def test_device_pointer_view_is_the_limb_major_buffer():
     torch.cuda.synchronize()
     got = buf.download()
     assert np.array_equal(got[0], x[0]) and not got[1:].any()
+
+
+@pytest.mark.parametrize("logn,qs", [(15, CFG3_QS[:2]), (14, [CFG2_Q60])])
+@pytest.mark.parametrize("half", [0, 1])
+def test_crt_whole_and_half_forms(oracle_lib, logn, qs, half):
+    """A 128-KiB limb-polynomial has two crt kernels (k_crt: whole polynomial in LDS; k_crt_half: two half-size
+    sub-transforms, two workgroups per CU; option "crt_half"): both against the oracle, in place and on CRT-basis input."""
+    n = 1 << logn
+    g, o = _ring_pair(oracle_lib, n, qs)
+    g.set_option("crt_half", half)
+    rng = np.random.default_rng(300 + logn + half)
+    x = _rand_elems(rng, 3, n, qs)
+    buf = g.upload(x)
+    buf.crt()
+    got = buf.download()
+    for e in range(3):
+        assert np.array_equal(got[e], o.crt(x[e])), f"crt mismatch elem {e}"
+    buf.crtinv()
+    assert np.array_equal(buf.download(), x), "crtInv . crt != id"
+    y = _rand_elems(rng, 2, n, qs)
+    b2 = g.upload(y)
+    b2.crtinv()
+    got = b2.download()
+    for e in range(2):
+        assert np.array_equal(got[e], o.crtinv(y[e]))
