@@ -1,0 +1,157 @@
+"""The ciphertext-op sequence of the reference's HomomRLWR example (BASELINE config 4) on resident batches.
+
+`eval (pt2ct ringRound)` in examples/HomomRLWR.hs:45-59 runs: mulPublic, the five ring tunnels switch1..5 over
+H0' .. H5' (examples/Common.hs:49-54,78-95), then rescaleTreePow2 (Language/RescaleTree.hs:64-87): x (1 + x), eight
+leaves (addPublic + div2), 4 + 2 + 1 pairwise mul_ each followed by div2.  This module issues exactly those library
+calls on a batch of ciphertexts that stays in HBM, with the limb counts PT2CT's type-level rules pick
+(alch_select_limbs, SURVEY 3.3: tunnels 5/6/5 .. 5/5/4, products 4/5/3, 3/4/2, 2/3/1, 1/2/1) and the HomomRLWR moduli
+(examples/HomomRLWR.hs:37-43).  Residues and hints are synthetic: throughput does not need valid encryptions;
+bit-exactness of every op is covered by the parity tests, the op ORDER by tests/test_gpu_homomrlwr_mini.py.
+Used by bench.py (extra field `homomrlwr`) and tools/bench_homomrlwr.py."""
+import time
+
+from . import capi
+from .capi import Ring, Tunnel
+
+QS = [1543651201, 689270401, 718099201, 720720001, 1556755201, 1567238401]          # Zqs order
+HP = [11648, 29120, 43680, 54600, 27300, 20475]                                     # H0' .. H5'
+P = 32                                                                              # plaintext modulus 2^5 (K = P5)
+
+
+def moduli(L):
+    return list(reversed(QS[:L]))                                                   # last-taken modulus outermost
+
+
+class RingRound:
+    def __init__(self, batch, ring_opts=()):
+        self.B = batch
+        self.rings, self.pool, self.cursor, self.pubs, self.stages = {}, [], 0, {}, {}
+        self.ring_opts = tuple(ring_opts)
+        # PT2CT's limb counts, resolved backwards from the output pNoise 0
+        p, muls, tuns = 0, [], []
+        for _ in range(4):
+            lin, lh, lout, p = capi.select_limbs(QS, p, capi.ALCH_OP_MUL)
+            muls.append((lin, lh, lout))
+        for _ in range(5):
+            lin, lh, lout, p = capi.select_limbs(QS, p, capi.ALCH_OP_TUNNEL)
+            tuns.append((lin, lh, lout))
+        muls.reverse(); tuns.reverse()                 # execution order: switch1..5, x(1+x), tree levels 1..3
+        self.muls, self.tuns = muls, tuns
+        # resident hints
+        self.tunnels = []
+        for k in range(5):
+            _, lh_, _ = tuns[k]
+            rr, rs = self.ring(HP[k], lh_), self.ring(HP[k + 1], lh_)
+            _, d_rel = Tunnel.info(rr, rs)
+            self.tunnels.append(Tunnel(rr, rs, self.seeded(rs, d_rel, 100 + k), self.seeded(rs, 2 * d_rel * lh_, 200 + k)))
+        self.quads = []
+        for _, lh_, _ in muls:
+            rh = self.ring(HP[5], lh_)
+            self.quads.append(rh.hint_from_buf(self.seeded(rh, 2 * lh_, 300 + lh_)))
+
+    def ring(self, m, L):
+        if (m, L) not in self.rings:
+            r = Ring(m, moduli(L))
+            for k, v in self.ring_opts:
+                r.set_option(k, v)
+            self.rings[(m, L)] = r
+        return self.rings[(m, L)]
+
+    @staticmethod
+    def seeded(r, count, seed):
+        b = r.alloc(count); b.fill_uniform(seed); return b
+
+    # buffer pool: the first pass allocates, later passes replay the same sequence of requests without any hipMalloc
+    def scratch(self, r, count):
+        i = self.cursor; self.cursor += 1
+        if i == len(self.pool):
+            self.pool.append(r.alloc(count))
+        assert self.pool[i].ring is r and self.pool[i].n_elems == count
+        return self.pool[i]
+
+    def public(self, r, seed):
+        if (id(r), seed) not in self.pubs:
+            self.pubs[(id(r), seed)] = self.seeded(r, 1, seed)
+        return self.pubs[(id(r), seed)]
+
+    def sync(self):
+        for r in self.rings.values():
+            r.sync()
+
+    def run(self, stage_times=False):
+        """One pass over the batch; returns the result buffer (ciphertexts over H5' on one limb).  stage_times: synchronise
+        around every stage and accumulate seconds per stage in self.stages."""
+        B, muls, tuns = self.B, self.muls, self.tuns
+        ring, scratch, public = self.ring, self.scratch, self.public
+
+        def timed(name, r, fn):
+            if not stage_times:
+                return fn()
+            r.sync(); t0 = time.perf_counter(); v = fn(); r.sync()
+            self.stages[name] = self.stages.get(name, 0.0) + time.perf_counter() - t0
+            return v
+
+        # fresh ciphertexts over H0', mulPublic a
+        r0 = ring(HP[0], tuns[0][0])
+        self.cursor = 0
+        if "x" not in self.pubs:
+            self.pubs["x"] = self.seeded(r0, 2 * B, 1)
+        x, pub, x1 = self.pubs["x"], public(r0, 2), scratch(r0, 2 * B)
+        timed("mulPublic", r0, lambda: (x1.mul_public(x, pub, 0, 2 * B),
+                                        x1.scale(x1, 2 * B, [pow(P, -1, q) for q in moduli(tuns[0][0])])))
+        cur = x1
+        for k in range(5):
+            lin_, lh_, lout_ = tuns[k]
+            rr, rs, ro = ring(HP[k], lh_), ring(HP[k + 1], lh_), ring(HP[k + 1], lout_)
+
+            def hop(cur=cur, rr=rr, rs=rs, ro=ro, k=k, lin_=lin_, lh_=lh_, lout_=lout_):
+                src = cur
+                if lh_ > lin_:
+                    up = scratch(rr, 2 * B); capi.ct_mod_switch(src, up, B); src = up
+                mid = scratch(rs, 2 * B)
+                self.tunnels[k].apply(src, mid, B)
+                if lout_ < lh_:
+                    dn = scratch(ro, 2 * B); capi.ct_mod_switch(mid, dn, B); mid = dn
+                return mid
+            cur = timed(f"tunnel{k + 1}", rs, hop)
+        # rescale tree on H5'
+        m5 = HP[5]
+
+        def product(level, a, b):
+            lin_, _, lout_ = muls[level]
+            o = scratch(ring(m5, lout_), 2 * B)
+            capi.ct_mul_full(self.quads[level], a, b, o, B, s_pre=[pow(P, -1, q) for q in moduli(lin_)])
+            return o
+
+        def plus_public(src, L, seed):                 # toLSD, addPublic, back to MSD (div2_'s modSwitchPT) -- element-wise
+            r = ring(m5, L)
+            o = scratch(r, 2 * B)
+            o.scale(src, 2 * B, [P % q for q in moduli(L)])
+            o.add_public(public(r, seed), 0, B)
+            return o
+
+        L0 = muls[0][0]
+
+        def level0():
+            x_lsd = scratch(ring(m5, L0), 2 * B); x_lsd.scale(cur, 2 * B, [P % q for q in moduli(L0)])
+            return product(0, x_lsd, plus_public(cur, L0, 50))
+        y = timed("x(1+x)", ring(m5, muls[0][1]), level0)
+        L1 = muls[1][0]
+        t = timed("leaves(addPublic,div2)", ring(m5, L1), lambda: [plus_public(y, L1, 60 + i) for i in range(8)])
+
+        def tree(t=t):
+            for level in (1, 2, 3):
+                t = [product(level, t[2 * i], t[2 * i + 1]) for i in range(len(t) // 2)]
+                for o in t:                             # div2_: toMSD scalar, plaintext modulus halves (metadata)
+                    o.scale(o, 2 * B, [pow(2, -1, q) for q in moduli(muls[level][2])])
+            return t[0]
+        return timed("tree(4+2+1 mul_, div2)", ring(m5, muls[3][1]), tree)
+
+    def measure(self, passes=1):
+        """Warm-up pass (allocations), then `passes` timed passes; wall-clock seconds per pass."""
+        self.run(); self.sync()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            out = self.run()
+        self.sync()
+        return (time.perf_counter() - t0) / passes, out

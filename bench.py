@@ -141,6 +141,10 @@ def main():
                     help="skip PT2CT's whole mul_ (modSwitch . keySwitchQuad . modSwitch . (*)), 4 -> 5 -> 3 limbs (extra field)")
     ap.add_argument("--no-general", dest="general", action="store_false",
                     help="skip the general-index line (keySwitchQuadCirc(a*b) on the reference's H5' = F20475 ring)")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
+                    help="skip the HomomRLWR ringRound pipeline (BASELINE config 4 at the reference's indices and moduli; every rank "
+                         "runs its own 1024-ciphertext shard, extra field `homomrlwr`)")
+    ap.add_argument("--pipeline-batch", type=int, default=1024, help="ciphertexts per GPU in the HomomRLWR pipeline")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="launch-structure option for every ring (alch_ring_set_option), e.g. one_stream=1 for kernel traces "
                          "whose durations add up to the step time")
@@ -312,6 +316,35 @@ def main():
     if args.general and rank == 0:
         general = general_index_line()
 
+    homomrlwr = None
+    if args.pipeline:
+        # BASELINE config 4: "examples/HomomRLWR.hs pipeline, 8192-ciphertext batch sharded over 8 GPUs" = 1024 ciphertexts per
+        # GPU.  Every rank runs the whole op sequence on its own shard (no collective inside), bracketed like the headline.
+        from alchemy_amd.ringround import RingRound
+        del a, b, out
+        Bp = args.pipeline_batch
+        rr = RingRound(Bp, RING_OPTS)
+        rr.run(); rr.sync()                                    # allocations, first touch
+        torch.cuda.synchronize()
+        shard.barrier(dist)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            res = rr.run()
+        rr.sync()
+        torch.cuda.synchronize()
+        shard.barrier(dist)
+        secs = shard.max_over_ranks((time.perf_counter() - t0) / 2, dist, red_dev)
+        if rank == 0:
+            rr.stages.clear()
+            rr.run(stage_times=True)
+            homomrlwr = {"workload": "HomomRLWR ringRound op sequence: mulPublic, 5 ring tunnels H0' -> H5', rescale tree with 8 mul_ "
+                         "(examples/HomomRLWR.hs:45-59), real indices and moduli, limb counts from alch_select_limbs, synthetic residues",
+                         "ciphertexts_per_gpu": Bp, "n_gpus": world, "pipelines_per_s": Bp * world / secs, "ms_per_batch": secs * 1e3,
+                         "tunnel_limbs": rr.tuns, "mul_limbs": rr.muls,
+                         "stage_ms_rank0": {k: round(v * 1e3, 3) for k, v in rr.stages.items()},
+                         "out_checksum": f"{res.checksum(0, 2):016x}"}
+        del rr
+
     if rank == 0:
         total_ops = B * world * args.steps
         value = total_ops / wall_max
@@ -369,6 +402,8 @@ def main():
             line["full_mul"] = full
         if general is not None:
             line["general_index"] = general
+        if homomrlwr is not None:
+            line["homomrlwr"] = homomrlwr
         line["result_gather"] = gather
         if world == 1 and args.cpu_ops > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_ops)

@@ -25,7 +25,7 @@ def _run(extra_env):
     env = dict(os.environ, ALCH_DIST_BACKEND="gloo", ALCH_FORCE_DEVICE="0", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch", "64", "--cpu-ops", "0", "--no-full", "--no-pow", "--no-general"]
+           "--batch", "64", "--cpu-ops", "0", "--no-full", "--no-pow", "--no-general", "--pipeline-batch", "48"]
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
 
 
@@ -40,6 +40,10 @@ def test_two_rank_rehearsal_prints_one_line():
     assert len(d["hip_event_ms_per_step_by_rank"]) == 2 and all(t > 0 for t in d["hip_event_ms_per_step_by_rank"])
     assert d["result_gather"]["own_slice_intact"] is True
     assert d["cpu_baseline"] is None
+    # BASELINE config 4's pipeline: every rank ran its own shard, the rate is the aggregate
+    h = d["homomrlwr"]
+    assert h["n_gpus"] == 2 and h["ciphertexts_per_gpu"] == 48 and h["pipelines_per_s"] > 0
+    assert h["tunnel_limbs"][0] == [5, 6, 5] and h["mul_limbs"][0] == [4, 5, 3]
 
 
 def test_failed_broadcast_is_fatal():

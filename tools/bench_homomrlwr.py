@@ -1,142 +1,17 @@
 #!/usr/bin/env python3
-"""BASELINE config 4 at the reference's real parameters: the ciphertext-op sequence that `eval (pt2ct ringRound)` runs in
-examples/HomomRLWR.hs:45-59 -- mulPublic, the five ring tunnels switch1..5 over H0' .. H5' (examples/Common.hs:49-54,78-95), then
-rescaleTreePow2 (Language/RescaleTree.hs:64-87): x (1 + x), eight leaves (addPublic + div2), 4 + 2 + 1 pairwise mul_ each followed
-by div2 -- on a batch of ciphertexts resident in HBM, with the limb counts PT2CT's type-level rules pick (alch_select_limbs,
-SURVEY 3.3: tunnels 5/6/5 .. 5/5/4, products 4/5/3, 3/4/2, 2/3/1, 1/2/1) and the HomomRLWR moduli (examples/HomomRLWR.hs:37-43).
-Synthetic residues and hints (throughput does not need valid encryptions; bit-exactness of every op is covered by the parity
-tests, the op ORDER by tests/test_gpu_homomrlwr_mini.py).  One JSON line: pipelines per second and the time per stage."""
-import json, os, sys, time
+"""BASELINE config 4 at the reference's real parameters: the HomomRLWR ringRound op sequence (alchemy_amd/ringround.py) on a
+batch of ciphertexts resident in HBM.  One JSON line: pipelines per second and the time per stage.
+Usage: tools/bench_homomrlwr.py [batch]"""
+import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import alchemy_amd as A
-from alchemy_amd import capi
+from alchemy_amd.ringround import RingRound
 
-QS = [1543651201, 689270401, 718099201, 720720001, 1556755201, 1567238401]          # Zqs order
-HP = [11648, 29120, 43680, 54600, 27300, 20475]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-P = 32                                                                                   # plaintext modulus 2^5 (K = P5)
-
-rings = {}
-def ring(m, L):
-    if (m, L) not in rings:
-        rings[(m, L)] = A.Ring(m, list(reversed(QS[:L])))                                # last-taken modulus outermost
-    return rings[(m, L)]
-
-def moduli(L):
-    return list(reversed(QS[:L]))
-
-# ---- PT2CT's limb counts, resolved backwards from the output pNoise 0
-p, muls, tuns = 0, [], []
-for _ in range(4):
-    lin, lh, lout, p = capi.select_limbs(QS, p, capi.ALCH_OP_MUL)
-    muls.append((lin, lh, lout))
-for _ in range(5):
-    lin, lh, lout, p = capi.select_limbs(QS, p, capi.ALCH_OP_TUNNEL)
-    tuns.append((lin, lh, lout))
-muls.reverse(); tuns.reverse()                       # execution order: switch1..5, x(1+x), tree levels 1..3
-
-def seeded(r, count, seed):
-    b = r.alloc(count); b.fill_uniform(seed); return b
-
-# buffer pool: the warm-up pass allocates, the timed pass replays the same sequence of requests without any hipMalloc
-pool, cursor, pubs = [], [0], {}
-def scratch(r, count):
-    i = cursor[0]; cursor[0] += 1
-    if i == len(pool):
-        pool.append(r.alloc(count))
-    assert pool[i].ring is r and pool[i].n_elems == count
-    return pool[i]
-def public(r, seed):
-    if (id(r), seed) not in pubs:
-        pubs[(id(r), seed)] = seeded(r, 1, seed)
-    return pubs[(id(r), seed)]
-
-# ---- resident hints
-tunnels = []
-for k in range(5):
-    lin_, lh_, lout_ = tuns[k]
-    rr, rs = ring(HP[k], lh_), ring(HP[k + 1], lh_)
-    _, d_rel = A.Tunnel.info(rr, rs)
-    tunnels.append(A.Tunnel(rr, rs, seeded(rs, d_rel, 100 + k), seeded(rs, 2 * d_rel * lh_, 200 + k)))
-quads = []
-for lin_, lh_, lout_ in muls:
-    rh = ring(HP[5], lh_)
-    quads.append(rh.hint_from_buf(seeded(rh, 2 * lh_, 300 + lh_)))
-
-stages = {}
-def timed(name, r, fn):
-    r.sync(); t0 = time.perf_counter(); fn(); r.sync()
-    stages[name] = stages.get(name, 0.0) + time.perf_counter() - t0
-
-def public_x(r0):
-    if 'x' not in pubs:
-        pubs['x'] = seeded(r0, 2 * B, 1)
-    return pubs['x']
-
-def run():
-    # fresh ciphertexts over H0' on 5 limbs, mulPublic a
-    r0 = ring(HP[0], tuns[0][0])
-    cursor[0] = 0
-    x = public_x(r0); pub = public(r0, 2); x1 = scratch(r0, 2 * B)
-    timed("mulPublic", r0, lambda: (x1.mul_public(x, pub, 0, 2 * B), x1.scale(x1, 2 * B, [pow(P, -1, q) for q in moduli(tuns[0][0])])))
-    cur = x1
-    for k in range(5):
-        lin_, lh_, lout_ = tuns[k]
-        rr, rs, ro = ring(HP[k], lh_), ring(HP[k + 1], lh_), ring(HP[k + 1], lout_)
-        def hop(cur=cur, rr=rr, rs=rs, ro=ro, k=k, lin_=lin_, lh_=lh_, lout_=lout_):
-            src = cur
-            if lh_ > lin_:
-                up = scratch(rr, 2 * B); capi.ct_mod_switch(src, up, B); src = up
-            mid = scratch(rs, 2 * B)
-            tunnels[k].apply(src, mid, B)
-            if lout_ < lh_:
-                dn = scratch(ro, 2 * B); capi.ct_mod_switch(mid, dn, B); mid = dn
-            return mid
-        out = {}
-        timed(f"tunnel{k + 1}", rs, lambda: out.setdefault("v", hop()))
-        cur = out["v"]
-    # rescale tree on H5'
-    m5 = HP[5]
-    def product(level, a, b):
-        lin_, lh_, lout_ = muls[level]
-        ro = ring(m5, lout_)
-        o = scratch(ro, 2 * B)
-        capi.ct_mul_full(quads[level], a, b, o, B, s_pre=[pow(P, -1, q) for q in moduli(lin_)])
-        return o
-    def plus_public(src, L, seed):                    # toLSD, addPublic, back to MSD (div2_'s modSwitchPT) -- element-wise
-        r = ring(m5, L)
-        o = scratch(r, 2 * B)
-        o.scale(src, 2 * B, [P % q for q in moduli(L)])
-        o.add_public(public(r, seed), 0, B)
-        return o
-    L0 = muls[0][0]
-    res = {}
-    def level0():
-        x_lsd = scratch(ring(m5, L0), 2 * B); x_lsd.scale(cur, 2 * B, [P % q for q in moduli(L0)])
-        res["y"] = product(0, x_lsd, plus_public(cur, L0, 50))
-    timed("x(1+x)", ring(m5, muls[0][1]), level0)
-    L1 = muls[1][0]
-    def leaves():
-        res["t"] = [plus_public(res["y"], L1, 60 + i) for i in range(8)]
-    timed("leaves(addPublic,div2)", ring(m5, L1), leaves)
-    def tree():
-        t = res["t"]
-        for level in (1, 2, 3):
-            t = [product(level, t[2 * i], t[2 * i + 1]) for i in range(len(t) // 2)]
-            for o in t:                                 # div2_: toMSD scalar, plaintext modulus halves (metadata)
-                o.scale(o, 2 * B, [pow(2, -1, q) for q in moduli(muls[level][2])])
-        res["out"] = t[0]
-    timed("tree(4+2+1 mul_, div2)", ring(m5, muls[3][1]), tree)
-    return res["out"]
-
-run()                                                   # warm-up: allocations, first-touch
-stages.clear()
-t0 = time.perf_counter()
-out = run()
-for r in rings.values():
-    r.sync()
-wall = time.perf_counter() - t0
+rr = RingRound(B)
+secs, out = rr.measure(passes=2)
+rr.stages.clear()
+rr.run(stage_times=True)
 print(json.dumps({"workload": "HomomRLWR ringRound op sequence (mulPublic, 5 tunnels H0'->H5', rescale tree with 8 mul_), real indices and moduli, "
-                              "synthetic residues; limb counts from alch_select_limbs", "batch": B, "tunnel_limbs": tuns, "mul_limbs": muls,
-                  "pipelines_per_s": B / wall, "ms_per_batch": wall * 1e3, "stage_ms": {k: v * 1e3 for k, v in stages.items()},
+                              "synthetic residues; limb counts from alch_select_limbs", "batch": B, "tunnel_limbs": rr.tuns, "mul_limbs": rr.muls,
+                  "pipelines_per_s": B / secs, "ms_per_batch": secs * 1e3, "stage_ms": {k: v * 1e3 for k, v in rr.stages.items()},
                   "out_checksum": f"{out.checksum(0, 2):016x}"}))
