@@ -1699,6 +1699,31 @@ extern "C" int alch_ct_mul_relin(alch_ring* r, const alch_hint* hint, const alch
 }
 
 // ---- the complete mul_: (*) . modSwitch up . keySwitchQuadCirc . modSwitch down -------------------------------
+// Constants of the closing modSwitch that drops the first ddn limbs of `r` (outermost first): q_u^-1 mod q_t for the
+// limb-at-a-time form, prod_{w >= u} q_w^-1 mod q_t for the forms that keep the surviving limbs in the CRT basis.
+template <typename W>
+static void fill_drop_tab(const alch_ring* r, int ddn, DropTab<W>& d) {
+    d.ddn = ddn;
+    d.balanced = 1;
+    const int bits = 8 * (int)sizeof(W);
+    for (int u = 0; u < MAXDROP; ++u)
+        for (int t = 0; t < MAXL; ++t) { d.qinv_m[u][t] = 0; d.comb_m[u][t] = 0; }
+    for (int u = 0; u < ddn; ++u)
+        for (int t = u + 1; t < r->L; ++t) {
+            const u64 qt = r->q[t], qu = r->q[u];
+            if ((qu - 1) / 2 >= qt) d.balanced = 0;
+            const u64 inv = h_powmod(qu % qt, qt - 2, qt);
+            d.qinv_m[u][t] = (W)h_mulmod(inv, h_powmod(2, (u64)bits, qt), qt);
+        }
+    for (int u = 0; u < ddn; ++u)
+        for (int t = ddn; t < r->L; ++t) {
+            const u64 qt = r->q[t];
+            u64 v = 1;
+            for (int w = u; w < ddn; ++w) v = h_mulmod(v, h_powmod(r->q[w] % qt, qt - 2, qt), qt);
+            d.comb_m[u][t] = (W)h_mulmod(v, h_powmod(2, (u64)bits, qt), qt);
+        }
+}
+
 template <typename W>
 static int do_mul_full(alch_ring* rh, alch_ring* rin, alch_ring* rout, const alch_hint* hint, const void* a, const void* b,
                        void* out, size_t batch, const uint64_t* s_pre, bool pow_out) {
@@ -1728,27 +1753,7 @@ static int do_mul_full(alch_ring* rh, alch_ring* rin, alch_ring* rout, const alc
     c.balanced = rh->balanced;
     c.opts = rh->opts;
     scal_to_mont<W>(rin, s_eff, 2, c.spre_r2);
-    c.drop.ddn = ddn;
-    c.drop.balanced = 1;
-    const int bits = 8 * (int)sizeof(W);
-    for (int u = 0; u < ddn; ++u)
-        for (int t = 0; t < rh->L; ++t) {
-            c.drop.qinv_m[u][t] = 0;
-            if (t <= u) continue;
-            const u64 qt = rh->q[t], qu = rh->q[u];
-            if ((qu - 1) / 2 >= qt) c.drop.balanced = 0;
-            const u64 inv = h_powmod(qu % qt, qt - 2, qt);
-            c.drop.qinv_m[u][t] = (W)h_mulmod(inv, h_powmod(2, (u64)bits, qt), qt);
-        }
-    for (int u = 0; u < MAXDROP; ++u)
-        for (int t = 0; t < MAXL; ++t) c.drop.comb_m[u][t] = 0;
-    for (int u = 0; u < ddn; ++u)
-        for (int t = ddn; t < rh->L; ++t) {
-            const u64 qt = rh->q[t];
-            u64 v = 1;
-            for (int w = u; w < ddn; ++w) v = h_mulmod(v, h_powmod(rh->q[w] % qt, qt - 2, qt), qt);
-            c.drop.comb_m[u][t] = (W)h_mulmod(v, h_powmod(2, (u64)bits, qt), qt);
-        }
+    fill_drop_tab<W>(rh, ddn, c.drop);
     c.stash_slots = slots;
     c.pow_out = pow_out;
 
@@ -1902,6 +1907,17 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
                            (const W*)hint->dptr, now, (u32)L, (const W*)c2crt);
         HIP_TRY(hipGetLastError());
         }
+        }
+        if (rh->gen && rh->opts.rs_lin && !pow_out) {
+            // modSwitch down with the kept limbs in the CRT basis (k_gen_rescale_drop / k_gen_rescale_keep): ddn inverse +
+            // (L - ddn) forward transforms per component instead of L + (L - ddn)
+            DropTab<W> dt;
+            fill_drop_tab<W>(rh, ddn, dt);
+            hipError_t e = gen_rescale_lin_dispatch(dev_ring<W>(rh), gen_dev<W>(rh), reinterpret_cast<const W*>(ks), reinterpret_cast<W*>(ping),
+                                                    reinterpret_cast<W*>(reinterpret_cast<char*>(out) + done * out_bytes), dt, dec_c0 ? 1 : 0,
+                                                    2 * now, rh->stream);
+            if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("rescale launch: ") + hipGetErrorString(e));
+            continue;
         }
         // modSwitch down: Pow basis (c0: Dec basis for a general index), one limb at a time, then back to the CRT basis on ring_out
         if ((rc = do_crt<W>(rh, ks, 0, 2 * now, true)) != ALCH_OK) return rc;
@@ -2179,6 +2195,25 @@ static int do_mod_switch(alch_ring* rin, alch_ring* rout, const void* in, void* 
     const int L = rin->L, ddn = L - rout->L;
     const size_t eb = elem_bytes(rin);
     const bool dec_c0 = rin->gen && rin->gh.rad > 1;
+    if (rin->gen && rin->opts.rs_lin && ddn <= MAXDROP && !(flags & (ALCH_POW_IN | ALCH_POW_OUT))) {
+        // kept limbs stay in the CRT basis (k_gen_rescale_drop / k_gen_rescale_keep)
+        DropTab<W> dt;
+        fill_drop_tab<W>(rin, ddn, dt);
+        const size_t per = 2 * (size_t)ddn * n * sizeof(W);
+        size_t chunk = std::min(batch, std::max<size_t>(1, (rin->scratch_mib << 20) / per));
+        int rc = ensure_ws(&rin->ws_full, &rin->ws_full_bytes, chunk * per);
+        if (rc != ALCH_OK) return rc;
+        for (size_t done = 0; done < batch; done += chunk) {
+            const size_t now = std::min(chunk, batch - done);
+            hipError_t e = gen_rescale_lin_dispatch(dev_ring<W>(rin), gen_dev<W>(rin),
+                                                    reinterpret_cast<const W*>(reinterpret_cast<const char*>(in) + done * 2 * eb),
+                                                    reinterpret_cast<W*>(rin->ws_full),
+                                                    reinterpret_cast<W*>(reinterpret_cast<char*>(out) + done * 2 * elem_bytes(rout)), dt,
+                                                    dec_c0 ? 1 : 0, 2 * now, rin->stream);
+            if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("rescale launch: ") + hipGetErrorString(e));
+        }
+        return ALCH_OK;
+    }
     const size_t per_ct = 3 * 2 * eb;                          // Pow copy + ping + pong
     size_t chunk = std::max<size_t>(1, (rin->scratch_mib << 20) / per_ct);
     chunk = std::min(chunk, batch);

@@ -97,6 +97,8 @@ struct GenCall {
 hipError_t gen_dispatch(const GenCall<u32>& c);
 hipError_t gen_dispatch(const GenCall<u64>& c);
 template <typename W> struct GenKsArgs;
+hipError_t gen_rescale_lin_dispatch(const DevRing<u32>& R, const GenDev<u32>& G, const u32* in, u32* res, u32* out, const DropTab<u32>& D, int dec_c0, size_t nelem, hipStream_t stream);
+hipError_t gen_rescale_lin_dispatch(const DevRing<u64>& R, const GenDev<u64>& G, const u64* in, u64* res, u64* out, const DropTab<u64>& D, int dec_c0, size_t nelem, hipStream_t stream);
 hipError_t gen_ks_dispatch(const DevRing<u32>& R, const GenDev<u32>& G, const GenKsArgs<u32>& A, size_t nct, hipStream_t stream);
 hipError_t gen_ks_dispatch(const DevRing<u64>& R, const GenDev<u64>& G, const GenKsArgs<u64>& A, size_t nct, hipStream_t stream);
 
@@ -559,6 +561,22 @@ __device__ __forceinline__ void gen_column(W* __restrict__ x, u32 b, u32 s, int 
     }
 }
 
+// the recurrence OP along every odd-prime axis of an LDS-resident limb-polynomial (ends with a barrier)
+template <typename W, bool ZDOM, int OP>
+__device__ __forceinline__ void gen_columns_lds(W* lds, const GenDev<W>& G, const ColArith<W, ZDOM>& A, u32 skip_mask) {
+    const u32 n = G.n;
+    for (int l = 0; l < G.nfact; ++l) {
+        const GenFact f = G.fact[l];
+        if (f.p == 2 || ((skip_mask >> l) & 1u)) continue;
+        const u32 step = f.mp * f.rts, span = f.dim * f.rts, ncol = n / (u32)(f.p - 1);
+        for (u32 c = threadIdx.x; c < ncol; c += GEN_T) {
+            const u32 o = c / step, in = c % step;
+            gen_column<W, ZDOM, OP>(lds, o * span + in, step, f.p, A);
+        }
+        lds_barrier();
+    }
+}
+
 template <typename W, bool ZDOM, int OP>
 __global__ void __launch_bounds__(GEN_T) k_gen_columns(DevRing<W> R, GenDev<W> G, W* data, size_t first_elem, size_t elem_stride, int* fail_flag, u32 skip_mask) {
     typedef typename Signed<W>::type SW;
@@ -572,16 +590,7 @@ __global__ void __launch_bounds__(GEN_T) k_gen_columns(DevRing<W> R, GenDev<W> G
     ColArith<W, ZDOM> A{R.mod[j].q, R.mod[j].qni, R.mod[j].r2, G.plain};
     for (u32 i = threadIdx.x; i < n; i += GEN_T) lds[i] = poly[i];
     lds_barrier();
-    for (int l = 0; l < G.nfact; ++l) {
-        const GenFact f = G.fact[l];
-        if (f.p == 2 || ((skip_mask >> l) & 1u)) continue;
-        const u32 step = f.mp * f.rts, span = f.dim * f.rts, ncol = n / (u32)(f.p - 1);
-        for (u32 c = threadIdx.x; c < ncol; c += GEN_T) {
-            const u32 o = c / step, in = c % step;
-            gen_column<W, ZDOM, OP>(lds, o * span + in, step, f.p, A);
-        }
-        lds_barrier();
-    }
+    gen_columns_lds<W, ZDOM, OP>(lds, G, A, skip_mask);
     if (OP == GEN_DIVG_POW || OP == GEN_DIVG_DEC) {      // divide by the odd radical of m (lol-cpp: Z_q multiplies by rad^-1, Z checks)
         bool bad = false;
         if (G.rad > 1) {
@@ -600,6 +609,102 @@ __global__ void __launch_bounds__(GEN_T) k_gen_columns(DevRing<W> R, GenDev<W> G
         if (bad) atomicOr(fail_flag, 1);
     }
     for (u32 i = threadIdx.x; i < n; i += GEN_T) poly[i] = lds[i];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// SymmSHE modSwitch down (Rescale (a,b) -> b, Eval.hs:130; PT2CT.hs:177,224-229) with the kept limbs never leaving the
+// CRT basis.  Lol rescales c0 on the Dec basis and c1 on the Pow basis, one limb at a time.  For a kept limb t the result
+// is affine in its own residues,  z_t = x_t C_t - sum_u R_u c_{u,t}  (R_u: centred lift of the u-th dropped residue after
+// the earlier drops, in the basis B the component is rescaled in; C_t, c_{u,t}: products of q_u^-1), and crt and the basis
+// change B -> Pow are linear, so   crt(z_t) = crt(x_t) C_t - crt(toPow(sum_u reduce_t(R_u) c_{u,t}))
+// -- the same residues bit for bit with ddn inverse + (L - ddn) forward transforms per component instead of
+// L inverse + (L - ddn) forward (k_rescale_out_lin is the two-power, fused form).
+//   k_gen_rescale_drop  per (element, dropped limb u):  crtInv (+ lInv for c0 when the index has odd factors) -> res
+//   k_gen_rescale_keep  per (element, kept limb t):     the lift chain from res (element-wise, recomputed per kept limb),
+//                       the combination into LDS, (l,) crt, epilogue x_t C_t - . from the CRT-basis input
+// ------------------------------------------------------------------------------------------------------
+template <typename W>
+__global__ void __launch_bounds__(GEN_T) k_gen_rescale_drop(DevRing<W> R, GenDev<W> G, const W* __restrict__ in, W* __restrict__ res,
+                                                            int ddn, int dec_c0) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W* lds = reinterpret_cast<W*>(smem);
+    const int L = R.L;
+    const size_t e = blockIdx.x / (unsigned)ddn;             // element = 2 ct + component
+    const int u = (int)(blockIdx.x % (unsigned)ddn);
+    const u32 n = G.n;
+    const W* src = in + (e * (size_t)L + u) * (size_t)n;
+    W* dst = res + (size_t)blockIdx.x * (size_t)n;
+    const W q = R.mod[u].q, qni = R.mod[u].qni;
+    for (u32 i = threadIdx.x; i < n; i += GEN_T) lds[i] = src[i];
+    lds_barrier();
+    gen_transform<W, true>(lds, G, u, q, qni);
+    if (dec_c0 && (e & 1) == 0) {                            // c0 is rescaled on the Dec basis
+        ColArith<W, false> A{q, qni, R.mod[u].r2, 0};
+        gen_columns_lds<W, false, GEN_LINV>(lds, G, A, 0u);
+    }
+    const W sc = G.iscale_m[u];                              // crtInv's closing scalar commutes with lInv
+    for (u32 i = threadIdx.x; i < n; i += GEN_T) dst[i] = csub(mont_mul_lazy(lds[i], sc, q, qni), q);
+}
+
+template <typename W>
+__global__ void __launch_bounds__(GEN_T) k_gen_rescale_keep(DevRing<W> R, GenDev<W> G, const W* __restrict__ in, const W* __restrict__ res,
+                                                            W* __restrict__ out, DropTab<W> D, int dec_c0) {
+    typedef typename Signed<W>::type SW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W* lds = reinterpret_cast<W*>(smem);
+    const int L = R.L, ddn = D.ddn, Lo = L - ddn;
+    const size_t e = blockIdx.x / (unsigned)Lo;
+    const int t = ddn + (int)(blockIdx.x % (unsigned)Lo);
+    const u32 n = G.n;
+    const W q = R.mod[t].q, qni = R.mod[t].qni;
+    auto reduce = [](SW z, W qq) -> W {                      // z mod qq; |z| < qq is the common case
+        if (z < (SW)qq && z > -(SW)qq) return z < 0 ? (W)(z + (SW)qq) : (W)z;
+        SW r = z % (SW)qq;
+        return r < 0 ? (W)(r + (SW)qq) : (W)r;
+    };
+    const W* r0 = res + (e * (size_t)ddn) * (size_t)n;
+    for (u32 k = threadIdx.x; k < n; k += GEN_T) {
+        SW lifted[MAXDROP];
+        W acc = 0;
+#pragma unroll
+        for (int u = 0; u < MAXDROP; ++u) {
+            if (u >= ddn) continue;
+            const W qu = R.mod[u].q, qniu = R.mod[u].qni;
+            W y = r0[(size_t)u * n + k];
+#pragma unroll
+            for (int v = 0; v < u; ++v)                       // the drops of the limbs in front of u come first
+                y = csub(mont_mul_lazy((W)(y + (qu - reduce(lifted[v], qu))), D.qinv_m[v][u], qu, qniu), qu);
+            lifted[u] = y > ((qu - 1) >> 1) ? (SW)y - (SW)qu : (SW)y;
+            acc = csub((W)(acc + csub(mont_mul_lazy(reduce(lifted[u], q), D.comb_m[u][t], q, qni), q)), q);
+        }
+        lds[k] = acc;
+    }
+    lds_barrier();
+    if (dec_c0 && (e & 1) == 0) {                            // Dec -> Pow
+        ColArith<W, false> A{q, qni, R.mod[t].r2, 0};
+        gen_columns_lds<W, false, GEN_L>(lds, G, A, 0u);
+    }
+    gen_transform<W, false>(lds, G, t, q, qni);
+    const W Ct = D.comb_m[0][t];
+    const W* x = in + (e * (size_t)L + t) * (size_t)n;
+    W* o = out + (e * (size_t)Lo + (t - ddn)) * (size_t)n;
+    for (u32 k = threadIdx.x; k < n; k += GEN_T)
+        o[k] = csub((W)(csub(mont_mul_lazy(x[k], Ct, q, qni), q) + (q - lds[k])), q);
+}
+
+template <typename W>
+inline hipError_t gen_launch_rescale_lin(const DevRing<W>& R, const GenDev<W>& G, const W* in, W* res, W* out, const DropTab<W>& D,
+                                         int dec_c0, size_t nelem, hipStream_t stream) {
+    const size_t lds_bytes = (size_t)G.n * sizeof(W);
+    auto k1 = k_gen_rescale_drop<W>;
+    auto k2 = k_gen_rescale_keep<W>;
+    hipError_t e;
+    if ((e = set_lds(k1, lds_bytes)) != hipSuccess) return e;
+    if ((e = set_lds(k2, lds_bytes)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k1, dim3((unsigned)(nelem * (size_t)D.ddn)), dim3(GEN_T), lds_bytes, stream, R, G, in, res, D.ddn, dec_c0);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(k2, dim3((unsigned)(nelem * (size_t)(R.L - D.ddn))), dim3(GEN_T), lds_bytes, stream, R, G, in, res, out, D, dec_c0);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -128,13 +128,16 @@ def test_ct_mul_full_general_index(oracle_lib, m, l_in, l_h, l_out):
     a, b = rand_elems(rng, 2 * batch, rh.n, qs_h[l_h - l_in:]), rand_elems(rng, 2 * batch, rh.n, qs_h[l_h - l_in:])
     s_pre = [int(rng.integers(1, q)) for q in qs_h[l_h - l_in:]]
     gh, ga, gb, gout = rh.hint_load(hint), rin.upload(a), rin.upload(b), rout.alloc(2 * batch)
-    for pow_out in (False, True):
+    want = {po: [oracle_full_mul_general(oracle_lib, m, qs_h, l_in, l_out, list(hint), a[2 * ct], a[2 * ct + 1], b[2 * ct], b[2 * ct + 1],
+                                         s_pre, po) for ct in range(batch)] for po in (False, True)}
+    # rs_lin = 1 (default): the closing modSwitch keeps the surviving limbs in the CRT basis; 0: every limb through Pow / Dec
+    for pow_out, lin in ((False, 1), (False, 0), (True, 1)):
+        rh.set_option("rs_lin", lin)
         capi.ct_mul_full(gh, ga, gb, gout, batch, s_pre=s_pre, flags=capi.ALCH_POW_OUT if pow_out else 0)
         got = gout.download()
         for ct in range(batch):
-            w0, w1 = oracle_full_mul_general(oracle_lib, m, qs_h, l_in, l_out, list(hint), a[2 * ct], a[2 * ct + 1],
-                                             b[2 * ct], b[2 * ct + 1], s_pre, pow_out)
-            assert np.array_equal(got[2 * ct], w0) and np.array_equal(got[2 * ct + 1], w1), (ct, pow_out)
+            w0, w1 = want[pow_out][ct]
+            assert np.array_equal(got[2 * ct], w0) and np.array_equal(got[2 * ct + 1], w1), (ct, pow_out, lin)
 
 
 @pytest.mark.parametrize("m,L,drop", [(20475, 5, 1), (54600, 6, 1), (11648, 5, 2), (455, 4, 3), (1 << 12, 4, 2), (1 << 16, 3, 1)])
@@ -154,8 +157,7 @@ def test_ct_mod_switch_down_and_up(oracle_lib, m, L, drop):
     rng = np.random.default_rng(m + L)
     x = rand_elems(rng, 2 * batch, Rb.n, qs)
     gx, gy = Rb.upload(x), Rs.alloc(2 * batch)
-    capi.ct_mod_switch(gx, gy, batch)
-    got = gy.download()
+    want = []
     for e in range(2 * batch):
         cur = ob.crtinv(x[e])
         if e % 2 == 0 and gen:
@@ -165,7 +167,13 @@ def test_ct_mod_switch_down_and_up(oracle_lib, m, L, drop):
         osm = mk(qs[drop:])
         if e % 2 == 0 and gen:
             cur = osm.l(cur)
-        assert np.array_equal(got[e], osm.crt(cur)), e
+        want.append(osm.crt(cur))
+    for lin in ((1, 0) if gen else (1,)):      # general index: surviving limbs kept in the CRT basis / the limb-at-a-time form
+        Rb.set_option("rs_lin", lin)
+        capi.ct_mod_switch(gx, gy, batch)
+        got = gy.download()
+        for e in range(2 * batch):
+            assert np.array_equal(got[e], want[e]), (e, lin)
     assert np.array_equal(gx.download(), x)                   # input untouched
     # and up again: (0, .., 0, q_a x)
     gz = Rb.alloc(2 * batch)
