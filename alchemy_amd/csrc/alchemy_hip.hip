@@ -320,7 +320,11 @@ __global__ void k_tensor_ew(DevRing<W> R, const W* a, const W* b, W* out, W* c2b
 // keySwitchQuadCirc's inner product for a many-digit gadget: out_c += sum_d digit_d * hint_{d,c} (CRT basis).
 // digits: [ct][D][L][n]; hint: [D][2][L][n] in Montgomery form.
 template <typename W>
-__global__ void k_hint_mac(DevRing<W> R, W* out, const W* digits, const W* hint, size_t nct, u32 D, const W* diag = nullptr) {
+__global__ void k_hint_mac(DevRing<W> R, W* out, const W* digits, const W* hint, size_t nct, u32 D, const W* diag = nullptr,
+                           u32 grp = 0, u32 hskip = 0) {
+    // hskip != 0 (tunnel on ciphertexts `hskip` limbs below the hint's ring): the digits come in groups of grp = L - hskip
+    // source limbs per embedded coefficient and the hint rows of the absent (zero) limbs are skipped: digit d uses hint row
+    // d + (d / grp + 1) * hskip.
     // diag != null (TrivGad, D = L): digit d reduced into its own limb d is c2's limb d itself, read from the CRT-basis
     // copy `diag` [ct][L][n] instead of a transformed digit (those slots of `digits` are never written).
     // One thread owns one (limb, slot) of TILE consecutive ciphertexts, so a hint word is loaded once per TILE
@@ -342,7 +346,8 @@ __global__ void k_hint_mac(DevRing<W> R, W* out, const W* digits, const W* hint,
             acc1[c] = live ? out[(2 * (ct0 + c) + 1) * Ln + rem] : (W)0;
         }
         for (u32 d = 0; d < D; ++d) {
-            const W h0 = hint[(size_t)(2 * d) * Ln + rem], h1 = hint[(size_t)(2 * d + 1) * Ln + rem];
+            const u32 hd = hskip ? d + (d / grp + 1) * hskip : d;
+            const W h0 = hint[(size_t)(2 * hd) * Ln + rem], h1 = hint[(size_t)(2 * hd + 1) * Ln + rem];
 #pragma unroll
             for (int c = 0; c < TILE; ++c) {
                 if (ct0 + c >= nct) continue;
@@ -426,37 +431,44 @@ __global__ void k_add_bcast(DevRing<W> R, W* dst, const W* pub, size_t cts) {
 }
 
 // Tunnel, step 1: the E'-coefficients of (c0, c1) embedded into S' (coeffs + embedPow as one index gather; toMSD's
-// per-limb scalar folded in).  in: [ct][2][L][n_r]; x0 / x1: [ct][d_rel][L][n_s].
+// per-limb scalar folded in).  in: [ct][2][L - dup][n_r] -- the ciphertexts may live `dup` limbs below the tunnel's ring
+// (PT2CT's modSwitch_ in front of tunnel_, PT2CT.hs:224-229: x -> (0, q_a x), the factor folded into s_m by the host);
+// x0 / x1: [ct][d_rel][Lx][n_s] holding the limbs xoff .. xoff + Lx - 1 (compact: the zero limbs are left out).
 template <typename W>
-__global__ void k_tunnel_gather(DevRing<W> Rs, const W* in, W* x0, W* x1, const int32_t* table, u32 d_rel, u32 n_r, size_t nct, Scal<W> s_m, int scale) {
-    const size_t n = (size_t)Rs.n, L = (size_t)Rs.L;
-    const size_t per_ct = (size_t)d_rel * L * n;
-    // words as [ct * 2 + comp][i * L + limb][k]
-    ALCH_WALK_INIT(Rs.n, d_rel * Rs.L);
+__global__ void k_tunnel_gather(DevRing<W> Rs, const W* in, W* x0, W* x1, const int32_t* table, u32 d_rel, u32 n_r, size_t nct, Scal<W> s_m,
+                                int scale, u32 Lx, u32 xoff, u32 dup) {
+    const size_t n = (size_t)Rs.n, Lin = (size_t)Rs.L - dup;
+    const size_t per_ct = (size_t)d_rel * Lx * n;
+    // words as [ct * 2 + comp][i * Lx + limb'][k]
+    ALCH_WALK_INIT(Rs.n, d_rel * Lx);
     ALCH_WALK(w, nct * 2 * per_ct, wk) {
         const size_t ct = wk.outer >> 1, comp = wk.outer & 1, k = wk.k;
-        const u32 i = wk.mid / (u32)L, limb = wk.mid - i * (u32)L;
+        const u32 i = wk.mid / Lx, limb = wk.mid - i * Lx + xoff;
         const size_t r2 = (size_t)wk.mid * n + k;
         const int32_t src = table[i * n + k];
         W v = 0;
-        if (src >= 0) {
-            v = in[((2 * ct + comp) * L + limb) * (size_t)n_r + (size_t)src];
+        if (src >= 0 && limb >= dup) {
+            v = in[((2 * ct + comp) * Lin + (limb - dup)) * (size_t)n_r + (size_t)src];
             if (scale) v = mont_mul(v, s_m.v[limb], Rs.mod[limb]);
         }
         (comp ? x1 : x0)[ct * per_ct + r2] = v;
     }
 }
 
-// Tunnel, step 2: c0' = sum_i crt(x0_i) * y_i (evalLin on the constant term), c1' = 0.  out: [ct][2][L][n].
+// Tunnel, step 2: c0' = sum_i crt(x0_i) * y_i (evalLin on the constant term), c1' = 0.  out: [ct][2][L][n];
+// x0crt: [ct][d_rel][Lx][n] holding the limbs xoff .. (the limbs in front of xoff are zero).
 template <typename W>
-__global__ void k_tunnel_lin(DevRing<W> Rs, W* out, const W* x0crt, const W* lin, u32 d_rel, size_t nct) {
-    const size_t n = (size_t)Rs.n, Ln = (size_t)Rs.L * n;
+__global__ void k_tunnel_lin(DevRing<W> Rs, W* out, const W* x0crt, const W* lin, u32 d_rel, size_t nct, u32 Lx, u32 xoff) {
+    const size_t n = (size_t)Rs.n, Ln = (size_t)Rs.L * n, Lxn = (size_t)Lx * n;
     ALCH_WALK_INIT(Rs.n, Rs.L);
     ALCH_WALK(w, nct * Ln, wk) {
         const size_t ct = wk.outer, rem = (size_t)wk.mid * n + wk.k;
         const ModP<W> m = Rs.mod[wk.mid];
         W acc = 0;
-        for (u32 i = 0; i < d_rel; ++i) acc = add_mod(acc, mont_mul(x0crt[(ct * d_rel + i) * Ln + rem], lin[(size_t)i * Ln + rem], m), m.q);
+        if (wk.mid >= xoff) {
+            const size_t xr = (size_t)(wk.mid - xoff) * n + wk.k;
+            for (u32 i = 0; i < d_rel; ++i) acc = add_mod(acc, mont_mul(x0crt[(ct * d_rel + i) * Lxn + xr], lin[(size_t)i * Ln + rem], m), m.q);
+        }
         out[2 * ct * Ln + rem] = acc;
         out[(2 * ct + 1) * Ln + rem] = 0;
     }
@@ -2072,54 +2084,89 @@ extern "C" int alch_tunnel_free(alch_tunnel* t) {
     return ALCH_OK;
 }
 
-// SymmSHE.tunnel on a batch of linear ciphertexts (k = 0):  out = (f'(c0), 0) + sum_i switch(hint_i, embed(c1_i)).
+// View of the last L - u limbs of a general-index ring (device tables shared with the ring itself).
 template <typename W>
-static int do_tunnel(const alch_tunnel* t, const void* in, void* out, size_t batch, const uint64_t* s_pre, unsigned flags) {
+static void gen_suffix_view(alch_ring* r, int u, DevRing<W>& d, GenDev<W>& g) {
+    d = dev_ring<W>(r);
+    g = gen_dev<W>(r);
+    d.L = r->L - u;
+    for (int j = 0; j + u < r->L; ++j) {
+        d.mod[j] = d.mod[j + u];
+        g.tabf[j] = g.tabf[j + u]; g.tabi[j] = g.tabi[j + u]; g.iscale_m[j] = g.iscale_m[j + u];
+        g.gcrt[j] = g.gcrt[j + u]; g.gcrt_inv[j] = g.gcrt_inv[j + u]; g.radinv_m[j] = g.radinv_m[j + u];
+    }
+}
+
+// SymmSHE.tunnel on a batch of linear ciphertexts (k = 0):  out = (f'(c0), 0) + sum_i switch(hint_i, embed(c1_i)).
+// rin: the ring the ciphertexts live in -- the tunnel's R' ring or its last limbs (PT2CT emits modSwitch_ .: tunnel_ hint .: modSwitch_,
+// PT2CT.hs:224-229; the leading modSwitch up, x -> (0, q_a x), is then folded in: the added limbs are zero, so neither their
+// crtInv, nor the crt of their embedded constant terms, nor their digits' transforms and hint products are computed).
+template <typename W>
+static int do_tunnel(const alch_tunnel* t, alch_ring* rin, const void* in, void* out, size_t batch, const uint64_t* s_pre, unsigned flags) {
     alch_ring* rr = t->rr;
     alch_ring* rs = t->rs;
-    const int L = rs->L;
+    const int L = rs->L, dup = rr->L - rin->L;
     const u32 D = t->d_rel;
-    const u32 GD = (u32)t->digits;                  // gadget digits per embedded coefficient
     const bool base2 = t->gadget == ALCH_GAD_BASE2;
+    // compact: embedded coefficients and digits hold the L - dup non-zero limbs only (TrivGad; BaseBGad 2 keeps the
+    // full layout with explicit zero limbs)
+    const bool compact = dup > 0 && !base2;
+    const u32 Lx = compact ? (u32)(L - dup) : (u32)L, xoff = compact ? (u32)dup : 0u;
+    const u32 GD = base2 ? (u32)t->digits : Lx;     // gadget digits per embedded coefficient
     Scal<u32> b2first, b2kd;
     if (base2) base2_layout(rs, b2first, b2kd);
-    const size_t ebr = elem_bytes(rr), ebs = elem_bytes(rs);
-    // scratch per ciphertext: Pow copy of the input (2 R'-elements), x0, x1 (D S'-elements each), digits (D * GD S'-elements)
-    const size_t per_ct = 2 * ebr + (size_t)(2 * D + D * GD) * ebs;
+    const size_t ebr = elem_bytes(rin), ebs = elem_bytes(rs), ebx = ebs / (size_t)L * Lx;
+    // scratch per ciphertext: Pow copy of the input (2 R'-elements), x0, x1 (D embedded coefficients each), digits (D * GD S'-elements)
+    const size_t per_ct = 2 * ebr + 2 * (size_t)D * ebx + (size_t)D * GD * ebs;
     size_t chunk = std::max<size_t>(1, (rs->scratch_mib << 20) / per_ct);
     chunk = std::min(chunk, batch);
     int rc = ensure_ws(&rs->ws_full, &rs->ws_full_bytes, chunk * per_ct);
     if (rc != ALCH_OK) return rc;
     char* win = reinterpret_cast<char*>(rs->ws_full);
     char* x0 = win + chunk * 2 * ebr;
-    char* x1 = x0 + chunk * D * ebs;
-    char* dig = x1 + chunk * D * ebs;
+    char* x1 = x0 + chunk * D * ebx;
+    char* dig = x1 + chunk * D * ebx;
+    uint64_t s_eff[MAXL] = {0};
+    for (int j = dup; j < L; ++j) {
+        u64 v = s_pre ? s_pre[j] % rs->q[j] : 1;
+        for (int u = 0; u < dup; ++u) v = h_mulmod(v, rs->q[u] % rs->q[j], rs->q[j]);      // modSwitch up: times the added moduli
+        s_eff[j] = v;
+    }
+    const bool scale = s_pre != nullptr || dup > 0;
     Scal<W> sm;
-    scal_to_mont<W>(rs, s_pre, 1, sm);
+    scal_to_mont<W>(rs, s_eff, 1, sm);
     const bool dec_c0 = rr->gh.rad > 1 && t->linv_skip_mask != ((1u << rr->gh.nfact) - 1);
     for (size_t done = 0; done < batch; done += chunk) {
         const size_t now = std::min(chunk, batch - done);
         const char* src = reinterpret_cast<const char*>(in) + done * 2 * ebr;
         // Pow basis of R' (a copy: the caller's ciphertexts are left alone); c0 onto relative-Dec (x) Pow(E')
         if (flags & ALCH_POW_IN) HIP_TRY(hipMemcpyAsync(win, src, now * 2 * ebr, hipMemcpyDeviceToDevice, rs->stream));
-        else if ((rc = do_crt<W>(rr, win, 0, 2 * now, true, src, rs->stream)) != ALCH_OK) return rc;
+        else if ((rc = do_crt<W>(rin, win, 0, 2 * now, true, src, rs->stream)) != ALCH_OK) return rc;
         if (dec_c0) {
             GenCall<W> g{};
-            g.op = GEN_LINV; g.ring = &dev_ring<W>(rr); g.gen = &gen_dev<W>(rr); g.stream = rs->stream;
-            g.data = reinterpret_cast<W*>(win); g.elem_stride = 2; g.first_poly = 0; g.npoly = now * (size_t)L;
-            g.skip_mask = t->linv_skip_mask; g.fail_flag = rr->d_flag;
+            g.op = GEN_LINV; g.ring = &dev_ring<W>(rin); g.gen = &gen_dev<W>(rin); g.stream = rs->stream;
+            g.data = reinterpret_cast<W*>(win); g.elem_stride = 2; g.first_poly = 0; g.npoly = now * (size_t)rin->L;
+            g.skip_mask = t->linv_skip_mask; g.fail_flag = rin->d_flag;
             hipError_t e = gen_dispatch(g);
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("tunnel lInv launch: ") + hipGetErrorString(e));
         }
-        const size_t gw = now * 2 * (size_t)D * elem_words(rs);
+        const size_t gw = now * 2 * (size_t)D * Lx * rs->n;
         hipLaunchKernelGGL((k_tunnel_gather<W>), dim3(ew_grid(gw)), dim3(256), 0, rs->stream, dev_ring<W>(rs), (const W*)win, (W*)x0, (W*)x1,
-                           t->table, D, rr->n, now, sm, s_pre ? 1 : 0);
+                           t->table, D, rr->n, now, sm, scale ? 1 : 0, Lx, xoff, (u32)dup);
         HIP_TRY(hipGetLastError());
         // constant term: evalLin
-        if ((rc = do_crt<W>(rs, x0, 0, now * D, false)) != ALCH_OK) return rc;
+        if (compact) {
+            DevRing<W> dv; GenDev<W> gv;
+            gen_suffix_view<W>(rs, dup, dv, gv);
+            GenCall<W> g{};
+            g.op = GEN_CRT; g.ring = &dv; g.gen = &gv; g.stream = rs->stream;
+            g.data = reinterpret_cast<W*>(x0); g.first_poly = 0; g.npoly = now * (size_t)D * Lx;
+            hipError_t e = gen_dispatch(g);
+            if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("tunnel crt launch: ") + hipGetErrorString(e));
+        } else if ((rc = do_crt<W>(rs, x0, 0, now * D, false)) != ALCH_OK) return rc;
         W* po = reinterpret_cast<W*>(reinterpret_cast<char*>(out) + done * 2 * ebs);
         hipLaunchKernelGGL((k_tunnel_lin<W>), dim3(ew_grid(now * elem_words(rs))), dim3(256), 0, rs->stream, dev_ring<W>(rs), po, (const W*)x0,
-                           (const W*)t->lin, D, now);
+                           (const W*)t->lin, D, now, Lx, xoff);
         HIP_TRY(hipGetLastError());
         // linear term: decompose + reduce + crt of every embedded coefficient, inner product with the hints
         if (base2) {                                 // BaseBGad 2 (examples/Tunnel.hs:24): element-wise decompose, batched crt
@@ -2134,12 +2181,13 @@ static int do_tunnel(const alch_tunnel* t, const void* in, void* out, size_t bat
             GenCall<W> g{};
             g.op = GEN_CRT_DIGITS; g.ring = &dev_ring<W>(rs); g.gen = &gen_dev<W>(rs); g.stream = rs->stream;
             g.src = reinterpret_cast<const W*>(x1); g.data = reinterpret_cast<W*>(dig);
-            g.npoly = now * (size_t)D * (size_t)L * (size_t)L; g.balanced = rs->balanced; g.with_diag = true;
+            g.npoly = now * (size_t)D * (size_t)Lx * (size_t)L; g.balanced = rs->balanced; g.with_diag = true;
+            g.src_limbs = (int)Lx; g.src_first = (int)xoff;
             hipError_t e = gen_dispatch(g);
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("tunnel crt_digits launch: ") + hipGetErrorString(e));
         }
         hipLaunchKernelGGL((k_hint_mac<W>), dim3(ew_grid(now * elem_words(rs))), dim3(256), 0, rs->stream, dev_ring<W>(rs), po, (const W*)dig,
-                           (const W*)t->ks, now, D * GD, (const W*)nullptr);
+                           (const W*)t->ks, now, D * GD, (const W*)nullptr, Lx, compact ? (u32)dup : 0u);
         HIP_TRY(hipGetLastError());
     }
     return ALCH_OK;
@@ -2147,7 +2195,8 @@ static int do_tunnel(const alch_tunnel* t, const void* in, void* out, size_t bat
 
 extern "C" int alch_ct_tunnel(const alch_tunnel* t, const alch_buf* in, alch_buf* out, size_t batch, const uint64_t* s_pre, unsigned flags) {
     if (!t || !in || !out) return fail(ALCH_E_INVALID, "null argument");
-    if (in->ring != t->rr || out->ring != t->rs) return fail(ALCH_E_INVALID, "input / output buffers must belong to the tunnel's rings");
+    if ((in->ring != t->rr && !is_suffix_ring(in->ring, t->rr)) || out->ring != t->rs)
+        return fail(ALCH_E_INVALID, "input / output buffers must belong to the tunnel's rings (the input may live on the last limbs of the R' ring)");
     if (flags & ~(unsigned)(ALCH_POW_IN | ALCH_POW_OUT)) return fail(ALCH_E_INVALID, "unknown flag");
     if (batch == 0) return ALCH_OK;
     if (in->n_elems < 2 * batch || out->n_elems < 2 * batch) return fail(ALCH_E_INVALID, "buffers must hold 2*batch ring elements");
@@ -2159,12 +2208,22 @@ extern "C" int alch_ct_tunnel(const alch_tunnel* t, const alch_buf* in, alch_buf
         HIP_TRY(hipEventRecord(rs->ev_x, rr->stream));
         HIP_TRY(hipStreamWaitEvent(rs->stream, rs->ev_x, 0));
     }
-    int rc = rs->word == 4 ? do_tunnel<u32>(t, in->dptr, out->dptr, batch, s_pre, flags) : do_tunnel<u64>(t, in->dptr, out->dptr, batch, s_pre, flags);
+    alch_ring* rin = in->ring;
+    if (rin->stream != rs->stream && rin != rr) {
+        HIP_TRY(hipEventRecord(rs->ev_x, rin->stream));
+        HIP_TRY(hipStreamWaitEvent(rs->stream, rs->ev_x, 0));
+    }
+    int rc = rs->word == 4 ? do_tunnel<u32>(t, rin, in->dptr, out->dptr, batch, s_pre, flags)
+                           : do_tunnel<u64>(t, rin, in->dptr, out->dptr, batch, s_pre, flags);
     if (rc != ALCH_OK) return rc;
     if (flags & ALCH_POW_OUT) if ((rc = buf_crt(out, 0, 2 * batch, true)) != ALCH_OK) return rc;
     if (rr->stream != rs->stream) {
         HIP_TRY(hipEventRecord(rs->ev_x, rs->stream));
         HIP_TRY(hipStreamWaitEvent(rr->stream, rs->ev_x, 0));
+    }
+    if (rin != rr && rin->stream != rs->stream) {
+        HIP_TRY(hipEventRecord(rs->ev_x, rs->stream));
+        HIP_TRY(hipStreamWaitEvent(rin->stream, rs->ev_x, 0));
     }
     return ALCH_OK;
 }

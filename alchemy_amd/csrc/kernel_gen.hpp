@@ -89,6 +89,7 @@ struct GenCall {
     size_t elem_stride;        // GEN_L .. GEN_DIVG_*: process every elem_stride-th ring element (1 = all; 2 = the c0 of ciphertexts)
     bool balanced;
     bool with_diag;            // GEN_CRT_DIGITS: also transform the digits i == j (tunnel: no CRT copy of the source exists)
+    int src_limbs, src_first;  // GEN_CRT_DIGITS: the source elements hold limbs src_first .. src_first + src_limbs - 1 (0 = all L)
     u32 skip_mask;             // GEN_L .. GEN_DIVG_*: bit l set = leave prime-power factor l alone (tunnel: partial lInv)
     bool zdom;                 // the ring's "modulus" is 0: signed 64-bit integers (Pow / Dec operations only)
     int* fail_flag;            // device int, set when a divG is not possible (Lol's Nothing)
@@ -335,17 +336,20 @@ __global__ void __launch_bounds__(GEN_T) k_gen_crt(DevRing<W> R, GenDev<W> G, W*
 // workgroup = (ciphertext, source limb i, target limb j); the diagonal i == j is skipped (that digit is c2's own
 // limb j, which the caller kept in the CRT basis).
 template <typename W>
-__global__ void __launch_bounds__(GEN_T) k_gen_crt_digits(DevRing<W> R, GenDev<W> G, const W* __restrict__ c2pow, W* __restrict__ digits, int balanced, int with_diag) {
+__global__ void __launch_bounds__(GEN_T) k_gen_crt_digits(DevRing<W> R, GenDev<W> G, const W* __restrict__ c2pow, W* __restrict__ digits, int balanced, int with_diag,
+                 int Ls, int sfirst) {
+    // Ls, sfirst: the source elements hold the limbs sfirst .. sfirst + Ls - 1 only (tunnel behind a modSwitch up: the added
+    // limbs are zero and so are their digits); digits: [element][Ls][L][n].  Key switch: Ls = L, sfirst = 0.
     typedef typename Signed<W>::type SW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W* lds = reinterpret_cast<W*>(smem);
     const int L = R.L;
     const size_t p = blockIdx.x;
-    const int j = (int)(p % (size_t)L), i = (int)((p / (size_t)L) % (size_t)L);
+    const int j = (int)(p % (size_t)L), is = (int)((p / (size_t)L) % (size_t)Ls), i = is + sfirst;
     if (i == j && !with_diag) return;      // key switch: that digit is c2's own limb j, kept in the CRT basis by the caller
-    const size_t ct = p / ((size_t)L * L);
+    const size_t ct = p / ((size_t)L * Ls);
     const u32 n = G.n;
-    const W* src = c2pow + (ct * (size_t)L + i) * (size_t)n;
+    const W* src = c2pow + (ct * (size_t)Ls + is) * (size_t)n;
     W* dst = digits + p * (size_t)n;
     const W q = R.mod[j].q, qni = R.mod[j].qni, qi = R.mod[i].q, hqi = (qi - 1) >> 1;
     for (u32 k = threadIdx.x; k < n; k += GEN_T) {
@@ -740,7 +744,8 @@ inline hipError_t gen_run(const GenCall<W>& c) {
     case GEN_CRT_DIGITS: {
         auto k = k_gen_crt_digits<W>;
         if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(GEN_T), lds_bytes, c.stream, *c.ring, *c.gen, c.src, c.data, c.balanced ? 1 : 0, c.with_diag ? 1 : 0);
+        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(GEN_T), lds_bytes, c.stream, *c.ring, *c.gen, c.src, c.data, c.balanced ? 1 : 0, c.with_diag ? 1 : 0,
+                           c.src_limbs ? c.src_limbs : c.ring->L, c.src_first);
         break;
     }
     // npoly = number of (element, limb) workgroups; first_poly = first ELEMENT here

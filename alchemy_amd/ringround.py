@@ -105,11 +105,9 @@ class RingRound:
             rr, rs, ro = ring(HP[k], lh_), ring(HP[k + 1], lh_), ring(HP[k + 1], lout_)
 
             def hop(cur=cur, rr=rr, rs=rs, ro=ro, k=k, lin_=lin_, lh_=lh_, lout_=lout_):
-                src = cur
-                if lh_ > lin_:
-                    up = scratch(rr, 2 * B); capi.ct_mod_switch(src, up, B); src = up
+                # modSwitch_ (up) .: tunnel_ hint as one call: the ciphertexts stay on their lin_ limbs
                 mid = scratch(rs, 2 * B)
-                self.tunnels[k].apply(src, mid, B)
+                self.tunnels[k].apply(cur, mid, B)
                 if lout_ < lh_:
                     dn = scratch(ro, 2 * B); capi.ct_mod_switch(mid, dn, B); mid = dn
                 return mid

@@ -263,7 +263,11 @@ int alch_ct_mul_full(const alch_hint *hint, const alch_buf *a, const alch_buf *b
  *             (b, a) with b + a s_out = g_t f'(s_in p_i) + e   (p_i = relative powerful basis of R'/E'); order i, t, (b, a)
  * alch_ct_tunnel: out[b] = (f'(c0), 0) + sum_i switch(hint_i, embed(coeffsPow(c1)_i)) for linear ciphertexts with k = 0
  * (elements (2b, 2b+1)); s_pre = toMSD's per-limb scalar (NULL = 1).  CRT basis in and out unless ALCH_POW_IN /
- * ALCH_POW_OUT.  Runs on ring_s's stream; the input is not modified. */
+ * ALCH_POW_OUT.  Runs on ring_s's stream; the input is not modified.
+ * `in` may also belong to a ring holding only the LAST limbs of ring_r (same index): PT2CT emits
+ * modSwitch_ .: tunnel_ hint .: modSwitch_ (PT2CT.hs:224-229) and the leading modSwitch up, x -> (0, q_a x), is then part of
+ * this call -- the added limbs are zero, so their transforms, digits and hint products are skipped (same results as
+ * alch_ct_mod_switch followed by alch_ct_tunnel; s_pre is indexed by ring_s's limbs either way). */
 int alch_tunnel_info(const alch_ring *ring_r, const alch_ring *ring_s, uint32_t *e_prime, uint32_t *d_rel);
 int alch_tunnel_create(alch_ring *ring_r, alch_ring *ring_s, int gadget, const alch_buf *lin_crt, const alch_buf *ks_crt,
                        alch_tunnel **out);

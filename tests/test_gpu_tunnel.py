@@ -58,6 +58,36 @@ def test_tunnel_hop_matches_the_oracle(oracle_lib, rp, sp, L, batch):
         assert np.array_equal(got[2 * ct], w0) and np.array_equal(got[2 * ct + 1], w1), ct
 
 
+@pytest.mark.parametrize("rp,sp,L,dup,gadget", [(40, 60, 3, 1, "triv"), (63, 105, 4, 2, "triv"), (11648, 29120, 6, 1, "triv"),
+                                                (43680, 54600, 6, 1, "triv"), (40, 60, 3, 1, "base2")])
+def test_tunnel_below_the_hint_ring_equals_mod_switch_then_tunnel(oracle_lib, rp, sp, L, dup, gadget):
+    """PT2CT's modSwitch_ .: tunnel_ hint (PT2CT.hs:224-229) as one call: ciphertexts on the last L - dup limbs of the tunnel's
+    ring go straight into alch_ct_tunnel (zero limbs skipped); same residues as alch_ct_mod_switch (up) + alch_ct_tunnel, and
+    as the oracle's composition."""
+    qs = RLWR_QS[:L] if rp > 1000 else primes_1_mod(rp * sp // math.gcd(rp, sp), L, 1 << 29)
+    gr, gs, gsmall = A.Ring(rp, qs), A.Ring(sp, qs), A.Ring(rp, qs[dup:])
+    _, d_rel = A.Tunnel.info(gr, gs)
+    rng = np.random.default_rng(rp + dup)
+    D = gs.gadget_digits(capi.ALCH_GAD_BASE2) if gadget == "base2" else L
+    lin, ks = rand_elems(rng, d_rel, gs.n, qs), rand_elems(rng, 2 * d_rel * D, gs.n, qs)
+    batch = 2
+    cts = rand_elems(rng, 2 * batch, gr.n, qs[dup:])
+    s_pre = [int(rng.integers(1, q)) for q in qs]
+    tun = A.Tunnel(gr, gs, gs.upload(lin), gs.upload(ks), gadget=capi.ALCH_GAD_BASE2 if gadget == "base2" else capi.ALCH_GAD_TRIV)
+    gin, gup, g1, g2 = gsmall.upload(cts), gr.alloc(2 * batch), gs.alloc(2 * batch), gs.alloc(2 * batch)
+    capi.ct_mod_switch(gin, gup, batch)
+    tun.apply(gup, g1, batch, s_pre=s_pre)
+    tun.apply(gin, g2, batch, s_pre=s_pre)
+    two_calls, one_call = g1.download(), g2.download()
+    assert np.array_equal(one_call, two_calls)
+    assert np.array_equal(gin.download(), cts)               # input untouched
+    if gadget == "triv":
+        up = gup.download()
+        for ct in range(batch):
+            w0, w1 = oracle_tunnel(oracle_lib, rp, sp, qs, list(lin), list(ks), up[2 * ct], up[2 * ct + 1], s_pre)
+            assert np.array_equal(one_call[2 * ct], w0) and np.array_equal(one_call[2 * ct + 1], w1), ct
+
+
 def test_tunnel_with_base2_hints_decrypts_to_f_of_pt():
     """BaseBGad 2 tunnel hints (the gadget of examples/Tunnel.hs:24) with its moduli (examples/Tunnel.hs:34-39) on a small tower:
     a valid model instance through the device, compared bit for bit with the model and decrypted by it."""
