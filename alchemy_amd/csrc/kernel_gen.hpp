@@ -298,8 +298,9 @@ __device__ __forceinline__ void gen_transform(W* lds, const GenDev<W>& G, int j,
 // ------------------------------------------------------------------------------------------------------
 // batched crt / crtInv: one workgroup per limb-polynomial
 // ------------------------------------------------------------------------------------------------------
+// (second launch bound: four waves per SIMD = at most 128 VGPRs, so that rings of up to 36 KiB run four workgroups per CU)
 template <typename W, bool INV>
-__global__ void __launch_bounds__(GEN_T) k_gen_crt(DevRing<W> R, GenDev<W> G, W* data, const W* src, size_t first_poly) {
+__global__ void __launch_bounds__(GEN_T, 4) k_gen_crt(DevRing<W> R, GenDev<W> G, W* data, const W* src, size_t first_poly) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W* lds = reinterpret_cast<W*>(smem);
     const size_t p = first_poly + blockIdx.x;
@@ -628,7 +629,7 @@ __global__ void __launch_bounds__(GEN_T) k_gen_columns(DevRing<W> R, GenDev<W> G
 //                       the combination into LDS, (l,) crt, epilogue x_t C_t - . from the CRT-basis input
 // ------------------------------------------------------------------------------------------------------
 template <typename W>
-__global__ void __launch_bounds__(GEN_T) k_gen_rescale_drop(DevRing<W> R, GenDev<W> G, const W* __restrict__ in, W* __restrict__ res,
+__global__ void __launch_bounds__(GEN_T, 4) k_gen_rescale_drop(DevRing<W> R, GenDev<W> G, const W* __restrict__ in, W* __restrict__ res,
                                                             int ddn, int dec_c0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W* lds = reinterpret_cast<W*>(smem);
