@@ -94,27 +94,6 @@ inline bool gen_plan(u32 m, GenHost& g) {
     return true;
 }
 
-inline bool h_mat_inv(std::vector<u64>& M, int d, u64 q) {       // in place, Gauss-Jordan mod prime q
-    std::vector<u64> A((size_t)d * 2 * d, 0);
-    for (int i = 0; i < d; ++i) { for (int j = 0; j < d; ++j) A[(size_t)i * 2 * d + j] = M[(size_t)i * d + j]; A[(size_t)i * 2 * d + d + i] = 1; }
-    for (int c = 0; c < d; ++c) {
-        int piv = -1;
-        for (int r = c; r < d; ++r) if (A[(size_t)r * 2 * d + c]) { piv = r; break; }
-        if (piv < 0) return false;
-        for (int j = 0; j < 2 * d; ++j) std::swap(A[(size_t)c * 2 * d + j], A[(size_t)piv * 2 * d + j]);
-        const u64 inv = h_invmod(A[(size_t)c * 2 * d + c], q);
-        for (int j = 0; j < 2 * d; ++j) A[(size_t)c * 2 * d + j] = h_mulmod(A[(size_t)c * 2 * d + j], inv, q);
-        for (int r = 0; r < d; ++r) {
-            if (r == c || !A[(size_t)r * 2 * d + c]) continue;
-            const u64 f = A[(size_t)r * 2 * d + c];
-            for (int j = 0; j < 2 * d; ++j)
-                A[(size_t)r * 2 * d + j] = (A[(size_t)r * 2 * d + j] + q - h_mulmod(f, A[(size_t)c * 2 * d + j], q)) % q;
-        }
-    }
-    for (int i = 0; i < d; ++i) for (int j = 0; j < d; ++j) M[(size_t)i * d + j] = A[(size_t)i * 2 * d + d + j];
-    return true;
-}
-
 // Tables of one limb: forward and inverse blocks (plain residues; the caller converts to Montgomery form), the CRT
 // image of g and its inverse, and crtInv's closing scalar.
 inline bool gen_tables(const GenHost& g, u64 q, std::vector<u64>& fwd, std::vector<u64>& inv, std::vector<u64>& gcrt,
