@@ -38,16 +38,19 @@ class RingRound:
         muls.reverse(); tuns.reverse()                 # execution order: switch1..5, x(1+x), tree levels 1..3
         self.muls, self.tuns = muls, tuns
         # resident hints
-        self.tunnels = []
+        # (the seeded source buffers stay referenced so that a test can download them and replay the pass on the oracle)
+        self.tunnels, self.tunnel_src = [], []
         for k in range(5):
             _, lh_, _ = tuns[k]
             rr, rs = self.ring(HP[k], lh_), self.ring(HP[k + 1], lh_)
             _, d_rel = Tunnel.info(rr, rs)
-            self.tunnels.append(Tunnel(rr, rs, self.seeded(rs, d_rel, 100 + k), self.seeded(rs, 2 * d_rel * lh_, 200 + k)))
-        self.quads = []
+            self.tunnel_src.append((self.seeded(rs, d_rel, 100 + k), self.seeded(rs, 2 * d_rel * lh_, 200 + k)))
+            self.tunnels.append(Tunnel(rr, rs, *self.tunnel_src[k]))
+        self.quads, self.quad_src = [], []
         for _, lh_, _ in muls:
             rh = self.ring(HP[5], lh_)
-            self.quads.append(rh.hint_from_buf(self.seeded(rh, 2 * lh_, 300 + lh_)))
+            self.quad_src.append(self.seeded(rh, 2 * lh_, 300 + lh_))
+            self.quads.append(rh.hint_from_buf(self.quad_src[-1]))
 
     def ring(self, m, L):
         if (m, L) not in self.rings:
