@@ -143,11 +143,33 @@ def oracle_full_mul_general(oracle_lib, m, qs_h, l_in, l_out, hint_crt, a0, a1, 
     return out[0], out[1]
 
 
-def oracle_tunnel(oracle_lib, r_p, s_p, qs, lin_crt, ks_crt, c0, c1, s_pre=None, pow_out=False):
+def decompose_base2(elem, qs):
+    """BaseBGad 2 decompose + reduce of one Pow-basis element ((n, L) residues), index-agnostic: per limb i the centred lift is
+    split into ceil(log2 q_i) balanced binary digits (remainder 1 taken as -1, the top digit absorbs the rest), limb 0's digits
+    first; every digit is returned reduced into all limbs.  Checked against the C restatement (cref.Ring.decompose_base2) in
+    tests/test_oracle_general.py."""
+    out = []
+    qv = np.array(qs, dtype=np.int64)
+    for i, q in enumerate(qs):
+        v = elem[:, i].astype(np.int64)
+        v = np.where(v > (q - 1) // 2, v - q, v)
+        kd = (q - 1).bit_length()
+        for t in range(kd):
+            if t + 1 < kd:
+                d = -(v & 1)
+                v = (v - d) // 2
+            else:
+                d = v
+            out.append(np.ascontiguousarray(np.mod(d[:, None], qv[None, :])))
+    return out
+
+
+def oracle_tunnel(oracle_lib, r_p, s_p, qs, lin_crt, ks_crt, c0, c1, s_pre=None, pow_out=False, gadget="triv"):
     """SymmSHE.tunnel (Eval.hs:134) on one linear ciphertext (k = 0), composed from the general C restatement's primitives and
     the model's index maps -- following the definition literally: full lInv on R', Tensor `coeffs`, l on every E'-coefficient,
-    embedPow into S', crt, times f'(d_i); for c1: `coeffs` on the Pow basis, embedPow, TrivGad decompose, crt, hint products.
-    c0, c1: CRT basis over R' ((n_r, L)); lin_crt: d_rel CRT elements of S'; ks_crt: [(i * L + t) * 2 + {0: b, 1: a}]."""
+    embedPow into S', crt, times f'(d_i); for c1: `coeffs` on the Pow basis, embedPow, gadget decompose (TrivGad or BaseBGad 2,
+    D digits), crt, hint products.
+    c0, c1: CRT basis over R' ((n_r, L)); lin_crt: d_rel CRT elements of S'; ks_crt: [(i * D + t) * 2 + {0: b, 1: a}]."""
     import math
     from oracle import model_gen as G
     e_p = math.gcd(r_p, s_p)
@@ -165,8 +187,9 @@ def oracle_tunnel(oracle_lib, r_p, s_p, qs, lin_crt, ks_crt, c0, c1, s_pre=None,
         acc0 = Os.add(acc0, Os.mul(Os.crt(x), lin_crt[i]))
         x1 = np.zeros((isx.n, L), dtype=np.int64)
         x1[emb] = c1p[row]
-        for t, d in enumerate(Os.decompose_triv(x1)):
+        digs = Os.decompose_triv(x1) if gadget == "triv" else decompose_base2(x1, qs)
+        for t, d in enumerate(digs):
             dc = Os.crt(d)
-            acc0 = Os.add(acc0, Os.mul(dc, ks_crt[(i * L + t) * 2]))
-            acc1 = Os.add(acc1, Os.mul(dc, ks_crt[(i * L + t) * 2 + 1]))
+            acc0 = Os.add(acc0, Os.mul(dc, ks_crt[(i * len(digs) + t) * 2]))
+            acc1 = Os.add(acc1, Os.mul(dc, ks_crt[(i * len(digs) + t) * 2 + 1]))
     return (Os.crtinv(acc0), Os.crtinv(acc1)) if pow_out else (acc0, acc1)

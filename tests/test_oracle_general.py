@@ -167,3 +167,21 @@ def test_fixtures_mul(oracle_lib):
         a, b = [R2.crt(to_aos(c)) for c in f["a"]], [R2.crt(to_aos(c)) for c in f["b"]]
         w0, w1 = oracle_full_mul_general(oracle_lib, mp, qs, 2, 1, hint, a[0], a[1], b[0], b[1], f["s_pre"], pow_out=True)
         assert lm(w0) == f["out"][0] and lm(w1) == f["out"][1], mp
+
+
+def test_numpy_base2_decomposition_equals_the_c_restatement(oracle_lib):
+    """tests/helpers.decompose_base2 (used to compose BaseBGad 2 tunnels on general indices) against the C restatement's
+    decompose_base2 on a two-power ring -- the decomposition is coefficient-wise, so the index does not enter."""
+    from helpers import decompose_base2
+    n, qs = 64, [537264001, 539884801, 12289]
+    o = oracle_lib.Ring(n, qs)
+    rng = np.random.default_rng(17)
+    x = np.stack([rng.integers(0, q, size=n, dtype=np.int64) for q in qs], axis=1)
+    x[0] = [(q - 1) // 2 for q in qs]           # the extreme centred residues
+    x[1] = [(q + 1) // 2 for q in qs]
+    x[2] = 0
+    want = o.decompose_base2(x)
+    got = decompose_base2(x, qs)
+    assert len(got) == len(want) == sum((q - 1).bit_length() for q in qs)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
