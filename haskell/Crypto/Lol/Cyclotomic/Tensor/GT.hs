@@ -29,7 +29,7 @@
 -- Use: @import Crypto.Lol.Cyclotomic.Tensor.GT@ instead of @...Tensor.CPP@ and write @GT@ for @CT@ in the
 -- plaintext alias (reference examples/Arithmetic.hs:19,23; @haskell/examples/Arithmetic-GT.patch@).  Nothing in
 -- @Crypto.Alchemy.*@ changes.
-module Crypto.Lol.Cyclotomic.Tensor.GT ( GT, GTDispatch(..), mulRelinGT, mulFullGT ) where
+module Crypto.Lol.Cyclotomic.Tensor.GT ( GT, GTDispatch(..), mulRelinGT, mulFullGT, tunnelGT, modSwitchGT ) where
 
 import Control.Monad                          (when)
 import Data.Coerce                            (coerce)
@@ -217,3 +217,16 @@ mulRelinGT ring hint a b out batch spre =
 mulFullGT :: Ptr AlchHint -> Ptr AlchBuf -> Ptr AlchBuf -> Ptr AlchBuf -> Int -> [Word64] -> IO ()
 mulFullGT hint a b out batch spre =
   withArray spre $ \ps -> c_ctMulFull hint a b out (fromIntegral batch) ps 0 >>= check "alch_ct_mul_full"
+
+-- | @tunnel hint@ on device-resident batches of linear ciphertexts (SymmSHE tunnel as E runs it, reference Eval.hs:134): one
+-- 'c_ctTunnel' call.  PT2CT emits @modSwitch_ .: tunnel_ hint .: modSwitch_@ (PT2CT.hs:224-229): when the input buffer's ring holds
+-- only the last limbs of the tunnel's R' ring, the leading @modSwitch@ is part of this call (the added limbs are zero and skipped).
+-- Arguments: tunnel handle, input buffer (2*batch CRT-basis elements over R'), output buffer (over S'), batch, toMSD's per-limb scalar.
+tunnelGT :: Ptr AlchTunnel -> Ptr AlchBuf -> Ptr AlchBuf -> Int -> [Word64] -> IO ()
+tunnelGT t a out batch spre =
+  withArray spre $ \ps -> c_ctTunnel t a out (fromIntegral batch) ps 0 >>= check "alch_ct_tunnel"
+
+-- | SymmSHE @modSwitch@ on device-resident batches of linear ciphertexts (reference Eval.hs:130): up or down by whole limbs, the
+-- direction read off the two buffers' rings; the trailing @modSwitch_@ of @mul_@ and @tunnel_@ when they are not fused.
+modSwitchGT :: Ptr AlchBuf -> Ptr AlchBuf -> Int -> IO ()
+modSwitchGT a out batch = c_ctModSwitch a out (fromIntegral batch) 0 >>= check "alch_ct_mod_switch"
