@@ -840,6 +840,7 @@ extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) 
     else if (k == "ti_split") { if (value < 0) return fail(ALCH_E_INVALID, "ti_split must be >= 0"); r->opts.ti_split = (int)value; }
     else if (k == "rs_lin") r->opts.rs_lin = value != 0;
     else if (k == "crt_half") r->opts.crt_half = value != 0;
+    else if (k == "rs_half") r->opts.rs_half = value != 0;
     else if (k == "gen_fused") r->opts.gen_fused = value != 0;
     else if (k == "split_fused") r->opts.split_fused = value != 0;
     else if (k == "scratch_mib") { if (value < 1 || value > 65536) return fail(ALCH_E_INVALID, "scratch_mib must be 1 .. 65536"); r->scratch_mib = (size_t)value; }
@@ -1748,7 +1749,8 @@ static int do_mul_full(alch_ring* rh, alch_ring* rin, alch_ring* rout, const alc
     const unsigned slots = rh->rs_slots;       // resident workgroups of k_rescale_out (each owns a stash slot)
     const size_t dig_bytes = chunk * (size_t)rin->L * n * sizeof(SW);
     const size_t ks_bytes = chunk * 2 * (size_t)rh->L * n * sizeof(W);
-    const size_t stash_bytes = (size_t)slots * (size_t)ddn * n * sizeof(SW);
+    // stash: one slot per resident workgroup (k_rescale_out / _lin) or the lifted residues of the whole chunk (kernel_rescale_half.hpp)
+    const size_t stash_bytes = std::max<size_t>(slots, 2 * chunk) * (size_t)ddn * n * sizeof(SW);
     const size_t pipe_bytes = dig_bytes + ks_bytes + stash_bytes;
     int rc = ensure_ws(&rh->ws_full, &rh->ws_full_bytes, 2 * pipe_bytes);
     if (rc != ALCH_OK) return rc;

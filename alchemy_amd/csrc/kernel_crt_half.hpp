@@ -87,6 +87,7 @@ k_crt_half(DevRing<W> R, W* __restrict__ data, const W* __restrict__ src, size_t
 #pragma unroll
                 for (int e = 0; e < VL; ++e) v[e] = csub(v[e], q);
                 *reinterpret_cast<V*>(dst + idx) = v;
+                ALCH_STORE_GUARD(v);
             }
             lds_barrier();                      // LDS is refilled next
         }
@@ -131,7 +132,9 @@ k_crt_half(DevRing<W> R, W* __restrict__ data, const W* __restrict__ src, size_t
                         c1[e] = csub(mont_mul_lazy((W)(x - y + q), w1ninv, q, qni), q);
                     }
                     *reinterpret_cast<V*>(poly + idx) = c0;
+                    ALCH_STORE_GUARD(c0);
                     *reinterpret_cast<V*>(poly + M + idx) = c1;
+                    ALCH_STORE_GUARD(c1);
                 }
             }
             lds_barrier();                      // LDS is refilled next

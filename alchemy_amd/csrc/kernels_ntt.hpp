@@ -86,6 +86,10 @@ struct LaunchOpts {
     int gen_fused = 0;       // general index: 1 = fused tensor + key switch kernels (kernel_gen.hpp).  Measured 0.69-0.82x the composed
                              // path on H0'..H5' (48 accumulators + a CRT_13 pass spill at 128 VGPRs, 4-byte global accesses): off
     int crt_half = 1;        // crt / crtInv of a 128-KiB limb-polynomial: 1 = two half-size workgroups per CU (k_crt_half), 0 = k_crt
+    int rs_half = 0;         // closing modSwitch at n = 2^15 (32-bit): 1 = always the two launches of half-size workgroups (kernel_rescale_half.hpp);
+                             // 0 = only where k_rescale_out_lin cannot serve (three dropped limbs, unbalanced two-limb drops).  Measured on the
+                             // 4 -> 5 -> 3 mul_: 0.473 + 0.925 ms per 1024 ciphertexts against k_rescale_out_lin's 1.331 ms -- the combination is
+                             // recomputed from the stash per kept limb and costs what the second workgroup per CU gains
     int rs_lin = 1;          // closing modSwitch: 1 = kept limbs stay in the CRT basis (k_rescale_out_lin), 0 = every limb through the Pow basis
     unsigned ks_grid = 4096; // persistent workgroups of k_ks_accum_half (measured, 1024-ciphertext chunks: 2048 -> 511k, 4096 -> 517k, 8192 -> 513k op/s)
 };
@@ -484,6 +488,7 @@ k_ks_accum(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
 
 }  // namespace alch
 #include "kernel_rescale_out.hpp"
+#include "kernel_rescale_half.hpp"
 #include "kernel_tensor_split.hpp"
 namespace alch {
 
@@ -637,6 +642,23 @@ inline hipError_t run_call(const NttCall<W>& c) {
         break;
     }
     case OP_RESCALE_OUT: {
+        if constexpr (sizeof(W) == 4 && LOGN == 15) {
+            const bool lin_serves = c.drop.ddn == 1 || (c.drop.ddn == 2 && c.drop.balanced);
+            if (!c.pow_out && c.opts.rs_lin && (c.opts.rs_half || !lin_serves)) {
+                // two half-size workgroups per CU; c.stash holds [2 nct][ddn][n] lifted residues
+                const unsigned nitems = (unsigned)(c.nct * 2);
+                const size_t hb = (size_t)lds_words<LOGN - 1>() * sizeof(W);
+                auto k1 = k_rescale_drop_half<LOGN, W>;
+                auto k2 = k_rescale_keep_half<LOGN, W>;
+                if ((e = set_lds(k1, hb)) != hipSuccess) return e;
+                if ((e = set_lds(k2, hb)) != hipSuccess) return e;
+                hipLaunchKernelGGL(k1, dim3(nitems), dim3(1 << CrtHalfGeo<LOGN, W>::LT), hb, c.stream, R, c.a, (SW*)c.stash, c.drop);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+                hipLaunchKernelGGL(k2, dim3((nitems + 7u) / 8u * 8u * (unsigned)(R.L - c.drop.ddn)), dim3(1 << CrtHalfGeo<LOGN, W>::LT), hb, c.stream,
+                                   R, c.a, (const SW*)c.stash, c.out, c.drop, nitems);
+                break;
+            }
+        }
         if (!c.pow_out && c.opts.rs_lin && (c.drop.ddn == 1 || (c.drop.ddn == 2 && c.drop.balanced))) {   // (unbalanced two-limb drops would spill)
             // kept limbs stay in the CRT basis: ddn inverse + (L - ddn) forward transforms per component (kernel_rescale_out.hpp)
             const unsigned nitems = (unsigned)(c.nct * 2);

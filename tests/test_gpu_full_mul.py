@@ -67,6 +67,8 @@ def _case(oracle_lib, logn, qs_h, l_in, l_out, batch, seed, s_pre=None, pow_out=
     (13, SIX_QS[:5], 4, 3, 2),
     (15, CFG3_QS[:1] + SIX_QS[1:5], 4, 3, 2),
     (15, SIX_QS[:5], 4, 3, 9),
+    (15, SIX_QS, 4, 3, 2),                  # n = 2^15, three limbs dropped: the half-size rescale kernels (kernel_rescale_half.hpp)
+    (15, [2147352577, 65537, 786433, 2146959361], 3, 2, 2),   # n = 2^15, two dropped, unbalanced: same kernels, general reduce
     # n = 2^16 (split transforms): the same entry point composes the op from element-wise kernels and batched transforms
     (16, SIX_QS, 5, 4, 2), (16, SIX_QS[:4], 2, 1, 3),
 ])

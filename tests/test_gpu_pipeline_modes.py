@@ -86,6 +86,9 @@ WORKER_FULL = textwrap.dedent("""
     ({"chunk": 8, "one_stream": 1}, 11, 21),
     ({"chunk": 16, "ks_grid": 24, "rs_slots": 5}, 11, 40),   # persistent grids smaller than the item counts
     ({"chunk": 8, "rs_slots": 3, "ti_grid": 8}, 15, 9),
+    ({"rs_half": 1}, 15, 5),                                 # closing rescale as two launches of half-size workgroups (kernel_rescale_half.hpp)
+    ({"rs_half": 1, "chunk": 8}, 15, 11),                    # the same over two chunks + ragged tail
+    ({"rs_lin": 0, "rs_slots": 3}, 15, 3),                   # every limb through the Pow basis (k_rescale_out)
 ])
 def test_full_mul_launch_structure_does_not_change_results(opts, logn, batch):
     out = subprocess.run([sys.executable, "-c", WORKER_FULL, str(logn), str(batch), json.dumps(opts)], capture_output=True,
