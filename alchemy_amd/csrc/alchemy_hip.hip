@@ -2171,14 +2171,13 @@ static int do_tunnel(const alch_tunnel* t, alch_ring* rin, const void* in, void*
                            (const W*)t->lin, D, now, Lx, xoff);
         HIP_TRY(hipGetLastError());
         // linear term: decompose + reduce + crt of every embedded coefficient, inner product with the hints
-        if (base2) {                                 // BaseBGad 2 (examples/Tunnel.hs:24): element-wise decompose, batched crt
-            for (size_t y0 = 0; y0 < now * D; y0 += 32768) {
-                const unsigned ny = (unsigned)std::min<size_t>(32768, now * D - y0);
-                hipLaunchKernelGGL((k_decompose_base2<W>), dim3(ew_grid(elem_words(rs)), ny), dim3(256), 0, rs->stream, dev_ring<W>(rs),
-                                   reinterpret_cast<const W*>(x1 + y0 * ebs), reinterpret_cast<W*>(dig + y0 * GD * ebs), b2first, b2kd, GD);
-                HIP_TRY(hipGetLastError());
-            }
-            if ((rc = do_crt<W>(rs, dig, 0, now * D * GD, false)) != ALCH_OK) return rc;
+        if (base2) {                                 // BaseBGad 2 (examples/Tunnel.hs:24): decompose + reduce in the transforms' loader
+            GenCall<W> g{};
+            g.op = GEN_CRT_BASE2; g.ring = &dev_ring<W>(rs); g.gen = &gen_dev<W>(rs); g.stream = rs->stream;
+            g.src = reinterpret_cast<const W*>(x1); g.data = reinterpret_cast<W*>(dig);
+            g.npoly = now * (size_t)D * (size_t)GD * (size_t)L; g.b2_first = b2first; g.b2_kd = b2kd; g.b2_D = GD;
+            hipError_t e = gen_dispatch(g);
+            if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("tunnel base2 crt_digits launch: ") + hipGetErrorString(e));
         } else {
             GenCall<W> g{};
             g.op = GEN_CRT_DIGITS; g.ring = &dev_ring<W>(rs); g.gen = &gen_dev<W>(rs); g.stream = rs->stream;

@@ -72,6 +72,7 @@ struct GenDev {
 };
 
 enum GenOp {
+    GEN_CRT_BASE2 = -1,        // src = Pow elements [el][L][n]; data = digits [el][D][L][n]; BaseBGad 2 decompose + reduce in the loader
     GEN_CRT = 0, GEN_CRTINV = 1,
     GEN_CRT_DIGITS = 2,        // src = c2 (Pow) [ct][L][n]; data = digits [ct][L(i)][L(j)][n]; TrivGad decompose + reduce in the loader
     GEN_L = 3, GEN_LINV = 4, GEN_MULG_POW = 5, GEN_MULG_DEC = 6, GEN_DIVG_POW = 7, GEN_DIVG_DEC = 8
@@ -89,6 +90,8 @@ struct GenCall {
     size_t elem_stride;        // GEN_L .. GEN_DIVG_*: process every elem_stride-th ring element (1 = all; 2 = the c0 of ciphertexts)
     bool balanced;
     bool with_diag;            // GEN_CRT_DIGITS: also transform the digits i == j (tunnel: no CRT copy of the source exists)
+    Scal<u32> b2_first, b2_kd; // GEN_CRT_BASE2: first digit and digit count of every limb
+    u32 b2_D;                  // GEN_CRT_BASE2: digits per element
     int src_limbs, src_first;  // GEN_CRT_DIGITS: the source elements hold limbs src_first .. src_first + src_limbs - 1 (0 = all L)
     u32 skip_mask;             // GEN_L .. GEN_DIVG_*: bit l set = leave prime-power factor l alone (tunnel: partial lInv)
     bool zdom;                 // the ring's "modulus" is 0: signed 64-bit integers (Pow / Dec operations only)
@@ -360,6 +363,46 @@ __global__ void __launch_bounds__(GEN_T) k_gen_crt_digits(DevRing<W> R, GenDev<W
         if (balanced) r = z < 0 ? z + (SW)q : z;
         else { r = z % (SW)q; if (r < 0) r += (SW)q; }
         lds[k] = (W)r;
+    }
+    lds_barrier();
+    gen_transform<W, false>(lds, G, j, q, qni);
+    typedef typename Vec4<W>::type V;
+    constexpr u32 VL = Vec4<W>::LANES;
+    if (n % VL == 0) for (u32 k = threadIdx.x * VL; k < n; k += GEN_T * VL) *reinterpret_cast<V*>(dst + k) = *reinterpret_cast<const V*>(lds + k);
+    else for (u32 k = threadIdx.x; k < n; k += GEN_T) dst[k] = lds[k];
+}
+
+// crt of the reduced BaseBGad 2 digits with decompose + reduce in the loader (tunnels with the gadget of examples/Tunnel.hs:24):
+// workgroup p = (element, digit d, target limb j); digit d is bit t of source limb i.  With u = -(centred lift) the balanced
+// binary digits have the closed form  d_t = -((u >> t) & 1)  for t < k - 1 and the top digit is  -(u >> (k - 1))  (arithmetic
+// shifts), so no digit depends on the ones below it and the digits never exist in HBM untransformed (k_crt_base2_digits is the
+// two-power form).  digits: [element][D][L][n].
+template <typename W>
+__global__ void __launch_bounds__(GEN_T) k_gen_crt_base2_digits(DevRing<W> R, GenDev<W> G, const W* __restrict__ xpow, W* __restrict__ digits,
+                                                                Scal<u32> first_digit, Scal<u32> kd, u32 D) {
+    typedef typename Signed<W>::type SW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W* lds = reinterpret_cast<W*>(smem);
+    const int L = R.L;
+    const size_t p = blockIdx.x;
+    const int j = (int)(p % (size_t)L);
+    const u32 d = (u32)((p / (size_t)L) % D);
+    const size_t el = p / ((size_t)L * D);
+    int i = 0;
+    for (int c = 1; c < L; ++c) if (d >= first_digit.v[c]) i = c;
+    const u32 t = d - first_digit.v[i];
+    const bool top = t + 1 == kd.v[i];
+    const u32 n = G.n;
+    const W* src = xpow + (el * (size_t)L + i) * (size_t)n;
+    W* dst = digits + p * (size_t)n;
+    const W q = R.mod[j].q, qni = R.mod[j].qni, qi = R.mod[i].q, hqi = (qi - 1) >> 1;
+    for (u32 k = threadIdx.x; k < n; k += GEN_T) {
+        const W v = src[k];
+        const SW z = v > hqi ? (SW)v - (SW)qi : (SW)v;
+        const SW u = -z;
+        SW dg = top ? -(u >> t) : -((u >> t) & 1);
+        if (top) dg %= (SW)q;                               // the top digit is tiny but its size depends on q_i vs 2^k
+        lds[k] = dg < 0 ? (W)(dg + (SW)q) : (W)dg;
     }
     lds_barrier();
     gen_transform<W, false>(lds, G, j, q, qni);
@@ -740,6 +783,12 @@ inline hipError_t gen_run(const GenCall<W>& c) {
         auto k = k_gen_crt<W, true>;
         if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(GEN_T), lds_bytes, c.stream, *c.ring, *c.gen, c.data, c.src, c.first_poly);
+        break;
+    }
+    case GEN_CRT_BASE2: {
+        auto k = k_gen_crt_base2_digits<W>;
+        if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(GEN_T), lds_bytes, c.stream, *c.ring, *c.gen, c.src, c.data, c.b2_first, c.b2_kd, c.b2_D);
         break;
     }
     case GEN_CRT_DIGITS: {
