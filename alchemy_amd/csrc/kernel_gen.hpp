@@ -356,18 +356,27 @@ __global__ void __launch_bounds__(GEN_T) k_gen_crt_digits(DevRing<W> R, GenDev<W
     const W* src = c2pow + (ct * (size_t)Ls + is) * (size_t)n;
     W* dst = digits + p * (size_t)n;
     const W q = R.mod[j].q, qni = R.mod[j].qni, qi = R.mod[i].q, hqi = (qi - 1) >> 1;
-    for (u32 k = threadIdx.x; k < n; k += GEN_T) {
-        const W v = src[k];
+    typedef typename Vec4<W>::type V;
+    constexpr u32 VL = Vec4<W>::LANES;
+    auto digit = [&](W v) -> W {
         const SW z = v > hqi ? (SW)v - (SW)qi : (SW)v;
         SW r;
         if (balanced) r = z < 0 ? z + (SW)q : z;
         else { r = z % (SW)q; if (r < 0) r += (SW)q; }
-        lds[k] = (W)r;
+        return (W)r;
+    };
+    if (n % VL == 0) {
+        for (u32 k = threadIdx.x * VL; k < n; k += GEN_T * VL) {
+            V v = *reinterpret_cast<const V*>(src + k);
+#pragma unroll
+            for (u32 c = 0; c < VL; ++c) v[c] = digit(v[c]);
+            *reinterpret_cast<V*>(lds + k) = v;
+        }
+    } else {
+        for (u32 k = threadIdx.x; k < n; k += GEN_T) lds[k] = digit(src[k]);
     }
     lds_barrier();
     gen_transform<W, false>(lds, G, j, q, qni);
-    typedef typename Vec4<W>::type V;
-    constexpr u32 VL = Vec4<W>::LANES;
     if (n % VL == 0) for (u32 k = threadIdx.x * VL; k < n; k += GEN_T * VL) *reinterpret_cast<V*>(dst + k) = *reinterpret_cast<const V*>(lds + k);
     else for (u32 k = threadIdx.x; k < n; k += GEN_T) dst[k] = lds[k];
 }
@@ -683,7 +692,11 @@ __global__ void __launch_bounds__(GEN_T, 4) k_gen_rescale_drop(DevRing<W> R, Gen
     const W* src = in + (e * (size_t)L + u) * (size_t)n;
     W* dst = res + (size_t)blockIdx.x * (size_t)n;
     const W q = R.mod[u].q, qni = R.mod[u].qni;
-    for (u32 i = threadIdx.x; i < n; i += GEN_T) lds[i] = src[i];
+    typedef typename Vec4<W>::type V;
+    constexpr u32 VL = Vec4<W>::LANES;
+    const bool vec = n % VL == 0;                            // then every limb-polynomial starts 16-byte aligned
+    if (vec) for (u32 i = threadIdx.x * VL; i < n; i += GEN_T * VL) *reinterpret_cast<V*>(lds + i) = *reinterpret_cast<const V*>(src + i);
+    else for (u32 i = threadIdx.x; i < n; i += GEN_T) lds[i] = src[i];
     lds_barrier();
     gen_transform<W, true>(lds, G, u, q, qni);
     if (dec_c0 && (e & 1) == 0) {                            // c0 is rescaled on the Dec basis
@@ -691,7 +704,16 @@ __global__ void __launch_bounds__(GEN_T, 4) k_gen_rescale_drop(DevRing<W> R, Gen
         gen_columns_lds<W, false, GEN_LINV>(lds, G, A, 0u);
     }
     const W sc = G.iscale_m[u];                              // crtInv's closing scalar commutes with lInv
-    for (u32 i = threadIdx.x; i < n; i += GEN_T) dst[i] = csub(mont_mul_lazy(lds[i], sc, q, qni), q);
+    if (vec) {
+        for (u32 i = threadIdx.x * VL; i < n; i += GEN_T * VL) {
+            V v = *reinterpret_cast<const V*>(lds + i);
+#pragma unroll
+            for (u32 c = 0; c < VL; ++c) v[c] = csub(mont_mul_lazy(v[c], sc, q, qni), q);
+            *reinterpret_cast<V*>(dst + i) = v;
+        }
+    } else {
+        for (u32 i = threadIdx.x; i < n; i += GEN_T) dst[i] = csub(mont_mul_lazy(lds[i], sc, q, qni), q);
+    }
 }
 
 template <typename W>
@@ -711,21 +733,48 @@ __global__ void __launch_bounds__(GEN_T) k_gen_rescale_keep(DevRing<W> R, GenDev
         return r < 0 ? (W)(r + (SW)qq) : (W)r;
     };
     const W* r0 = res + (e * (size_t)ddn) * (size_t)n;
-    for (u32 k = threadIdx.x; k < n; k += GEN_T) {
+    typedef typename Vec4<W>::type V;
+    constexpr u32 VL = Vec4<W>::LANES;
+    const bool vec = n % VL == 0;
+    auto combine = [&](const W* y0, W* acc) {                 // one coefficient: y0[u] = residue of dropped limb u
         SW lifted[MAXDROP];
-        W acc = 0;
+        W a = 0;
 #pragma unroll
         for (int u = 0; u < MAXDROP; ++u) {
             if (u >= ddn) continue;
             const W qu = R.mod[u].q, qniu = R.mod[u].qni;
-            W y = r0[(size_t)u * n + k];
+            W y = y0[u];
 #pragma unroll
             for (int v = 0; v < u; ++v)                       // the drops of the limbs in front of u come first
                 y = csub(mont_mul_lazy((W)(y + (qu - reduce(lifted[v], qu))), D.qinv_m[v][u], qu, qniu), qu);
             lifted[u] = y > ((qu - 1) >> 1) ? (SW)y - (SW)qu : (SW)y;
-            acc = csub((W)(acc + csub(mont_mul_lazy(reduce(lifted[u], q), D.comb_m[u][t], q, qni), q)), q);
+            a = csub((W)(a + csub(mont_mul_lazy(reduce(lifted[u], q), D.comb_m[u][t], q, qni), q)), q);
         }
-        lds[k] = acc;
+        *acc = a;
+    };
+    if (vec) {
+        for (u32 k = threadIdx.x * VL; k < n; k += GEN_T * VL) {
+            V in[MAXDROP], o;
+#pragma unroll
+            for (int u = 0; u < MAXDROP; ++u) if (u < ddn) in[u] = *reinterpret_cast<const V*>(r0 + (size_t)u * n + k);
+#pragma unroll
+            for (u32 c = 0; c < VL; ++c) {
+                W y0[MAXDROP], a;
+#pragma unroll
+                for (int u = 0; u < MAXDROP; ++u) y0[u] = u < ddn ? in[u][c] : (W)0;
+                combine(y0, &a);
+                o[c] = a;
+            }
+            *reinterpret_cast<V*>(lds + k) = o;
+        }
+    } else {
+        for (u32 k = threadIdx.x; k < n; k += GEN_T) {
+            W y0[MAXDROP], a;
+#pragma unroll
+            for (int u = 0; u < MAXDROP; ++u) y0[u] = u < ddn ? r0[(size_t)u * n + k] : (W)0;
+            combine(y0, &a);
+            lds[k] = a;
+        }
     }
     lds_barrier();
     if (dec_c0 && (e & 1) == 0) {                            // Dec -> Pow
@@ -736,8 +785,18 @@ __global__ void __launch_bounds__(GEN_T) k_gen_rescale_keep(DevRing<W> R, GenDev
     const W Ct = D.comb_m[0][t];
     const W* x = in + (e * (size_t)L + t) * (size_t)n;
     W* o = out + (e * (size_t)Lo + (t - ddn)) * (size_t)n;
-    for (u32 k = threadIdx.x; k < n; k += GEN_T)
-        o[k] = csub((W)(csub(mont_mul_lazy(x[k], Ct, q, qni), q) + (q - lds[k])), q);
+    if (vec) {
+        for (u32 k = threadIdx.x * VL; k < n; k += GEN_T * VL) {
+            const V xv = *reinterpret_cast<const V*>(x + k), lv = *reinterpret_cast<const V*>(lds + k);
+            V r;
+#pragma unroll
+            for (u32 c = 0; c < VL; ++c) r[c] = csub((W)(csub(mont_mul_lazy(xv[c], Ct, q, qni), q) + (q - lv[c])), q);
+            *reinterpret_cast<V*>(o + k) = r;
+        }
+    } else {
+        for (u32 k = threadIdx.x; k < n; k += GEN_T)
+            o[k] = csub((W)(csub(mont_mul_lazy(x[k], Ct, q, qni), q) + (q - lds[k])), q);
+    }
 }
 
 template <typename W>
