@@ -170,6 +170,18 @@ struct Walk3 {
     for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < (total); w += (size_t)gridDim.x * blockDim.x, walk.step())
 #define ALCH_WALK_INIT(n_, M_) Walk3 wk(blockIdx.x * (size_t)blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x, (u32)(n_), (u32)(M_))
 
+// VW consecutive words moved with one access (VW = 16 bytes' worth when the ring dimension is a multiple of it, else 1): the
+// element-wise kernels of the general-index path are bound by the number of memory instructions long before HBM.
+template <typename W, int VW> struct alignas(sizeof(W) * VW) Pack { W v[VW]; };
+#define ALCH_LAUNCH_VW(kern, ringp, items, stream, ...)                                                                         \
+    do {                                                                                                                        \
+        constexpr int VL_ = Vec4<W>::LANES;                                                                                     \
+        if ((ringp)->n % VL_ == 0)                                                                                              \
+            hipLaunchKernelGGL((kern<W, VL_>), dim3(ew_grid((items) / VL_)), dim3(256), 0, stream, __VA_ARGS__);                \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((kern<W, 1>), dim3(ew_grid(items)), dim3(256), 0, stream, __VA_ARGS__);                          \
+    } while (0)
+
 enum PwOp { PW_MUL = 0, PW_ADD = 1, PW_SUB = 2 };
 
 // z mod q in [0, q) for a signed z.  |z| < q is the common case (a digit, or a centred residue of a modulus of q's
@@ -216,10 +228,16 @@ __global__ void k_pointwise_scalar(DevRing<W> R, W* dst, const W* a, const W* b,
 }
 
 // dst = src * s_j (mod q_j); sm[j] = s_j in Montgomery form.  TO_MONT callers pass sm = R^2 mod q.
-template <typename W>
+template <typename W, int VW = 1>
 __global__ void k_scale(DevRing<W> R, W* dst, const W* src, size_t words, Scal<W> sm) {
-    ALCH_WALK_INIT(R.n, R.L);
-    ALCH_WALK(w, words, wk) dst[w] = mont_mul(src[w], sm.v[wk.mid], R.mod[wk.mid]);
+    typedef Pack<W, VW> P;
+    ALCH_WALK_INIT(R.n / VW, R.L);
+    ALCH_WALK(w, words / VW, wk) {
+        P x = reinterpret_cast<const P*>(src)[w];
+#pragma unroll
+        for (int c = 0; c < VW; ++c) x.v[c] = mont_mul(x.v[c], sm.v[wk.mid], R.mod[wk.mid]);
+        reinterpret_cast<P*>(dst)[w] = x;
+    }
 }
 
 // TrivGad decompose + reduce on one Pow-basis element: digits[i] (limb-major element i) limb j =
@@ -279,7 +297,7 @@ __global__ void k_decompose_base2(DevRing<W> R, const W* c, W* digits, Scal<u32>
 // c2 = a1 b1 s -> c2buf (one element per ciphertext).  sr2 = s R^2 (Montgomery).  Used by the BaseBGad key switch.
 template <typename W> struct GTab { const W* p[MAXL]; };     // per limb: CRT image of g (Montgomery form), or null
 
-template <typename W>
+template <typename W, int VW = 1>
 __global__ void k_tensor_ew(DevRing<W> R, const W* a, const W* b, W* out, W* c2buf, size_t nct, Scal<W> sr2, int dup,
                             W* c2crt, GTab<W> gt) {
     // gt: general index -- SymmSHE's (*) applies mulG to every product coefficient (mulGCRT = pointwise product with the
@@ -287,33 +305,38 @@ __global__ void k_tensor_ew(DevRing<W> R, const W* a, const W* b, W* out, W* c2b
     // c2crt != null: a second copy of c2 that stays in the CRT basis (the diagonal digits of the key switch)
     // R: the ring of out / c2buf (L limbs); a, b live on its last L - dup limbs; the dup leading limbs of the
     // results are zero (modSwitch up: Rescale b -> (a,b), its q_a factor folded into sr2 by the host)
+    typedef Pack<W, VW> P;
     const size_t n = (size_t)R.n;
     const size_t Ln = (size_t)R.L * n, Lsn = (size_t)(R.L - dup) * n, off = (size_t)dup * n;
-    ALCH_WALK_INIT(R.n, R.L);
-    ALCH_WALK(w, nct * Ln, wk) {
-        const size_t ct = wk.outer, rem = (size_t)wk.mid * n + wk.k;
+    ALCH_WALK_INIT(R.n / VW, R.L);
+    ALCH_WALK(w, nct * Ln / VW, wk) {
+        const size_t ct = wk.outer, rem = (size_t)wk.mid * n + (size_t)wk.k * VW;
+        P c0, c1, c2;
         if (rem < off) {
-            out[2 * ct * Ln + rem] = 0; out[(2 * ct + 1) * Ln + rem] = 0; c2buf[ct * Ln + rem] = 0;
-            if (c2crt) c2crt[ct * Ln + rem] = 0;
-            continue;
+#pragma unroll
+            for (int c = 0; c < VW; ++c) { c0.v[c] = 0; c1.v[c] = 0; c2.v[c] = 0; }
+        } else {
+            const size_t rs = rem - off, js = wk.mid - (u32)dup;
+            const ModP<W> m = R.mod[wk.mid];
+            const P a0 = *reinterpret_cast<const P*>(a + 2 * ct * Lsn + rs), a1 = *reinterpret_cast<const P*>(a + (2 * ct + 1) * Lsn + rs);
+            const P b0 = *reinterpret_cast<const P*>(b + 2 * ct * Lsn + rs), b1 = *reinterpret_cast<const P*>(b + (2 * ct + 1) * Lsn + rs);
+            const W* g = gt.p[wk.mid];
+            P gv;
+            if (g) gv = *reinterpret_cast<const P*>(g + (size_t)wk.k * VW);
+#pragma unroll
+            for (int c = 0; c < VW; ++c) {
+                const W x0 = mont_mul(a0.v[c], sr2.v[js], m), x1 = mont_mul(a1.v[c], sr2.v[js], m);      // a s R
+                W c0v = mont_mul(b0.v[c], x0, m);
+                W c1v = add_mod(mont_mul(b1.v[c], x0, m), mont_mul(b0.v[c], x1, m), m.q);
+                W c2v = mont_mul(b1.v[c], x1, m);
+                if (g) { c0v = mont_mul(c0v, gv.v[c], m); c1v = mont_mul(c1v, gv.v[c], m); c2v = mont_mul(c2v, gv.v[c], m); }
+                c0.v[c] = c0v; c1.v[c] = c1v; c2.v[c] = c2v;
+            }
         }
-        const size_t rs = rem - off, js = wk.mid - (u32)dup;
-        const ModP<W> m = R.mod[wk.mid];
-        const W a0 = a[2 * ct * Lsn + rs], a1 = a[(2 * ct + 1) * Lsn + rs];
-        const W b0 = b[2 * ct * Lsn + rs], b1 = b[(2 * ct + 1) * Lsn + rs];
-        const W x0 = mont_mul(a0, sr2.v[js], m), x1 = mont_mul(a1, sr2.v[js], m);      // a s R
-        W c0v = mont_mul(b0, x0, m);
-        W c1v = add_mod(mont_mul(b1, x0, m), mont_mul(b0, x1, m), m.q);
-        W c2v = mont_mul(b1, x1, m);
-        const W* g = gt.p[wk.mid];
-        if (g) {
-            const W gv = g[wk.k];
-            c0v = mont_mul(c0v, gv, m); c1v = mont_mul(c1v, gv, m); c2v = mont_mul(c2v, gv, m);
-        }
-        out[2 * ct * Ln + rem] = c0v;
-        out[(2 * ct + 1) * Ln + rem] = c1v;
-        c2buf[ct * Ln + rem] = c2v;
-        if (c2crt) c2crt[ct * Ln + rem] = c2v;
+        *reinterpret_cast<P*>(out + 2 * ct * Ln + rem) = c0;
+        *reinterpret_cast<P*>(out + (2 * ct + 1) * Ln + rem) = c1;
+        *reinterpret_cast<P*>(c2buf + ct * Ln + rem) = c2;
+        if (c2crt) *reinterpret_cast<P*>(c2crt + ct * Ln + rem) = c2;
     }
 }
 
@@ -482,43 +505,57 @@ __global__ void k_add_bcast(DevRing<W> R, W* dst, const W* pub, size_t cts) {
 // per-limb scalar folded in).  in: [ct][2][L - dup][n_r] -- the ciphertexts may live `dup` limbs below the tunnel's ring
 // (PT2CT's modSwitch_ in front of tunnel_, PT2CT.hs:224-229: x -> (0, q_a x), the factor folded into s_m by the host);
 // x0 / x1: [ct][d_rel][Lx][n_s] holding the limbs xoff .. xoff + Lx - 1 (compact: the zero limbs are left out).
-template <typename W>
+template <typename W, int VW = 1>
 __global__ void k_tunnel_gather(DevRing<W> Rs, const W* in, W* x0, W* x1, const int32_t* table, u32 d_rel, u32 n_r, size_t nct, Scal<W> s_m,
                                 int scale, u32 Lx, u32 xoff, u32 dup) {
+    typedef Pack<W, VW> P;
+    typedef Pack<int32_t, VW> PI;
     const size_t n = (size_t)Rs.n, Lin = (size_t)Rs.L - dup;
     const size_t per_ct = (size_t)d_rel * Lx * n;
-    // words as [ct * 2 + comp][i * Lx + limb'][k]
-    ALCH_WALK_INIT(Rs.n, d_rel * Lx);
-    ALCH_WALK(w, nct * 2 * per_ct, wk) {
-        const size_t ct = wk.outer >> 1, comp = wk.outer & 1, k = wk.k;
+    // words as [ct * 2 + comp][i * Lx + limb'][k]; a thread gathers VW consecutive k and stores them as one piece
+    ALCH_WALK_INIT(Rs.n / VW, d_rel * Lx);
+    ALCH_WALK(w, nct * 2 * per_ct / VW, wk) {
+        const size_t ct = wk.outer >> 1, comp = wk.outer & 1, k = (size_t)wk.k * VW;
         const u32 i = wk.mid / Lx, limb = wk.mid - i * Lx + xoff;
         const size_t r2 = (size_t)wk.mid * n + k;
-        const int32_t src = table[i * n + k];
-        W v = 0;
-        if (src >= 0 && limb >= dup) {
-            v = in[((2 * ct + comp) * Lin + (limb - dup)) * (size_t)n_r + (size_t)src];
-            if (scale) v = mont_mul(v, s_m.v[limb], Rs.mod[limb]);
+        const PI src = *reinterpret_cast<const PI*>(table + i * n + k);
+        P v;
+#pragma unroll
+        for (int c = 0; c < VW; ++c) {
+            W x = 0;
+            if (src.v[c] >= 0 && limb >= dup) {
+                x = in[((2 * ct + comp) * Lin + (limb - dup)) * (size_t)n_r + (size_t)src.v[c]];
+                if (scale) x = mont_mul(x, s_m.v[limb], Rs.mod[limb]);
+            }
+            v.v[c] = x;
         }
-        (comp ? x1 : x0)[ct * per_ct + r2] = v;
+        *reinterpret_cast<P*>((comp ? x1 : x0) + ct * per_ct + r2) = v;
     }
 }
 
 // Tunnel, step 2: c0' = sum_i crt(x0_i) * y_i (evalLin on the constant term), c1' = 0.  out: [ct][2][L][n];
 // x0crt: [ct][d_rel][Lx][n] holding the limbs xoff .. (the limbs in front of xoff are zero).
-template <typename W>
+template <typename W, int VW = 1>
 __global__ void k_tunnel_lin(DevRing<W> Rs, W* out, const W* x0crt, const W* lin, u32 d_rel, size_t nct, u32 Lx, u32 xoff) {
+    typedef Pack<W, VW> P;
     const size_t n = (size_t)Rs.n, Ln = (size_t)Rs.L * n, Lxn = (size_t)Lx * n;
-    ALCH_WALK_INIT(Rs.n, Rs.L);
-    ALCH_WALK(w, nct * Ln, wk) {
-        const size_t ct = wk.outer, rem = (size_t)wk.mid * n + wk.k;
+    ALCH_WALK_INIT(Rs.n / VW, Rs.L);
+    ALCH_WALK(w, nct * Ln / VW, wk) {
+        const size_t ct = wk.outer, rem = (size_t)wk.mid * n + (size_t)wk.k * VW;
         const ModP<W> m = Rs.mod[wk.mid];
-        W acc = 0;
+        P acc, zero;
+#pragma unroll
+        for (int c = 0; c < VW; ++c) { acc.v[c] = 0; zero.v[c] = 0; }
         if (wk.mid >= xoff) {
-            const size_t xr = (size_t)(wk.mid - xoff) * n + wk.k;
-            for (u32 i = 0; i < d_rel; ++i) acc = add_mod(acc, mont_mul(x0crt[(ct * d_rel + i) * Lxn + xr], lin[(size_t)i * Ln + rem], m), m.q);
+            const size_t xr = (size_t)(wk.mid - xoff) * n + (size_t)wk.k * VW;
+            for (u32 i = 0; i < d_rel; ++i) {
+                const P x = *reinterpret_cast<const P*>(x0crt + (ct * d_rel + i) * Lxn + xr), y = *reinterpret_cast<const P*>(lin + (size_t)i * Ln + rem);
+#pragma unroll
+                for (int c = 0; c < VW; ++c) acc.v[c] = add_mod(acc.v[c], mont_mul(x.v[c], y.v[c], m), m.q);
+            }
         }
-        out[2 * ct * Ln + rem] = acc;
-        out[(2 * ct + 1) * Ln + rem] = 0;
+        *reinterpret_cast<P*>(out + 2 * ct * Ln + rem) = acc;
+        *reinterpret_cast<P*>(out + (2 * ct + 1) * Ln + rem) = zero;
     }
 }
 
@@ -1225,7 +1262,7 @@ static int do_scale(alch_ring* r, void* dst, const void* src, size_t count, cons
     Scal<W> sm;
     scal_to_mont<W>(r, s, 1, sm);
     const size_t words = count * elem_words(r);
-    hipLaunchKernelGGL((k_scale<W>), dim3(ew_grid(words)), dim3(256), 0, r->stream, dev_ring<W>(r), (W*)dst, (const W*)src, words, sm);
+    ALCH_LAUNCH_VW(k_scale, r, words, r->stream, dev_ring<W>(r), (W*)dst, (const W*)src, words, sm);
     HIP_TRY(hipGetLastError());
     return ALCH_OK;
 }
@@ -1588,7 +1625,7 @@ static int do_mul_relin_unfused(alch_ring* r, const alch_hint* hint, const void*
                 continue;
             }
         }
-        hipLaunchKernelGGL((k_tensor_ew<W>), dim3(ew_grid(words)), dim3(256), 0, r->stream, dev_ring<W>(r), pa, pb, po,
+        ALCH_LAUNCH_VW(k_tensor_ew, r, words, r->stream, dev_ring<W>(r), pa, pb, po,
                            (W*)c2, now, sr2, 0, fused_digits ? (W*)c2crt : (W*)nullptr, gt);
         HIP_TRY(hipGetLastError());
         if ((rc = do_crt<W>(r, c2, 0, now, true)) != ALCH_OK) return rc;
@@ -1927,7 +1964,7 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
             }
         }
         if (!fused_ks) {
-        hipLaunchKernelGGL((k_tensor_ew<W>), dim3(ew_grid(words)), dim3(256), 0, rh->stream, dev_ring<W>(rh), pa, pb, (W*)ks,
+        ALCH_LAUNCH_VW(k_tensor_ew, rh, words, rh->stream, dev_ring<W>(rh), pa, pb, (W*)ks,
                            (W*)c2, now, sr2, dup, (W*)c2crt, gt);
         HIP_TRY(hipGetLastError());
         // keySwitchQuadCirc on ring_h
@@ -2088,7 +2125,7 @@ static int tunnel_to_mont(alch_ring* rs, void* dst, const void* src, size_t elem
     Scal<W> sm;
     scal_to_mont<W>(rs, nullptr, 2, sm);
     const size_t words = elems * elem_words(rs);
-    hipLaunchKernelGGL((k_scale<W>), dim3(ew_grid(words)), dim3(256), 0, rs->stream, dev_ring<W>(rs), (W*)dst, (const W*)src, words, sm);
+    ALCH_LAUNCH_VW(k_scale, rs, words, rs->stream, dev_ring<W>(rs), (W*)dst, (const W*)src, words, sm);
     HIP_TRY(hipGetLastError());
     return ALCH_OK;
 }
@@ -2207,7 +2244,7 @@ static int do_tunnel(const alch_tunnel* t, alch_ring* rin, const void* in, void*
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("tunnel lInv launch: ") + hipGetErrorString(e));
         }
         const size_t gw = now * 2 * (size_t)D * Lx * rs->n;
-        hipLaunchKernelGGL((k_tunnel_gather<W>), dim3(ew_grid(gw)), dim3(256), 0, rs->stream, dev_ring<W>(rs), (const W*)win, (W*)x0, (W*)x1,
+        ALCH_LAUNCH_VW(k_tunnel_gather, rs, gw, rs->stream, dev_ring<W>(rs), (const W*)win, (W*)x0, (W*)x1,
                            t->table, D, rr->n, now, sm, scale ? 1 : 0, Lx, xoff, (u32)dup);
         HIP_TRY(hipGetLastError());
         // constant term: evalLin
@@ -2221,7 +2258,7 @@ static int do_tunnel(const alch_tunnel* t, alch_ring* rin, const void* in, void*
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("tunnel crt launch: ") + hipGetErrorString(e));
         } else if ((rc = do_crt<W>(rs, x0, 0, now * D, false)) != ALCH_OK) return rc;
         W* po = reinterpret_cast<W*>(reinterpret_cast<char*>(out) + done * 2 * ebs);
-        hipLaunchKernelGGL((k_tunnel_lin<W>), dim3(ew_grid(now * elem_words(rs))), dim3(256), 0, rs->stream, dev_ring<W>(rs), po, (const W*)x0,
+        ALCH_LAUNCH_VW(k_tunnel_lin, rs, now * elem_words(rs), rs->stream, dev_ring<W>(rs), po, (const W*)x0,
                            (const W*)t->lin, D, now, Lx, xoff);
         HIP_TRY(hipGetLastError());
         // linear term: decompose + reduce + crt of every embedded coefficient, inner product with the hints
