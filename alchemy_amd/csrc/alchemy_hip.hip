@@ -80,6 +80,12 @@ struct alch_tunnel {
     void* ks;                                  // device: [d_rel * D][2][L][n_s], CRT basis, Montgomery form (D gadget digits)
     int gadget;
     int digits;                                // D: L for TrivGad, sum_i ceil(log2 q_i) for BaseBGad 2
+    // E'-level form (null when E' = S' or E' has no general-index ring): an embedded E'-element's CRT over S' is its CRT over E'
+    // replicated (embedCRT), so the constant terms' and the digits' transforms run at dimension phi(e') and the products with
+    // the linear function / the hints read them through slot_e
+    alch_ring* re = nullptr;                   // E'_q, same moduli (owned)
+    int32_t* table_e = nullptr;                // device: [d_rel][n_e] source positions in R'
+    u32* slot_e = nullptr;                     // device: [n_s] CRT slot of E' behind every CRT slot of S'
 };
 
 struct alch_hint {
@@ -344,7 +350,9 @@ __global__ void k_tensor_ew(DevRing<W> R, const W* a, const W* b, W* out, W* c2b
 // digits: [ct][D][L][n]; hint: [D][2][L][n] in Montgomery form.
 template <typename W>
 __global__ void k_hint_mac(DevRing<W> R, W* out, const W* digits, const W* hint, size_t nct, u32 D, const W* diag = nullptr,
-                           u32 grp = 0, u32 hskip = 0) {
+                           u32 grp = 0, u32 hskip = 0, const u32* slot_e = nullptr, u32 n_d = 0) {
+    // slot_e != null (tunnel, E'-level transforms): the digits are CRT vectors of dimension n_d over E'; slot s of S' reads
+    // entry slot_e[s] (embedCRT replication).
     // hskip != 0 (tunnel on ciphertexts `hskip` limbs below the hint's ring): the digits come in groups of grp = L - hskip
     // source limbs per embedded coefficient and the hint rows of the absent (zero) limbs are skipped: digit d uses hint row
     // d + (d / grp + 1) * hskip.
@@ -375,7 +383,8 @@ __global__ void k_hint_mac(DevRing<W> R, W* out, const W* digits, const W* hint,
             for (int c = 0; c < TILE; ++c) {
                 if (ct0 + c >= nct) continue;
                 const size_t ct = ct0 + c;
-                const W x = (diag && d == limb) ? diag[ct * Ln + rem] : digits[(ct * (size_t)D + d) * Ln + rem];
+                const W x = slot_e ? digits[((ct * (size_t)D + d) * R.L + limb) * (size_t)n_d + slot_e[wk.k]]
+                                   : (diag && d == limb) ? diag[ct * Ln + rem] : digits[(ct * (size_t)D + d) * Ln + rem];
                 acc0[c] = add_mod(acc0[c], mont_mul(x, h0, m), m.q);
                 acc1[c] = add_mod(acc1[c], mont_mul(x, h1, m), m.q);
             }
@@ -392,7 +401,8 @@ __global__ void k_hint_mac(DevRing<W> R, W* out, const W* digits, const W* hint,
 // The same with 16-byte accesses: a thread owns one piece of VL consecutive slots of TILE ciphertexts (n a multiple of VL).
 // The one-word form moved 2.4 TB/s in the HomomRLWR pipeline -- bound by the number of memory instructions, not by HBM.
 template <typename W>
-__global__ void k_hint_mac_v(DevRing<W> R, W* out, const W* digits, const W* hint, size_t nct, u32 D, const W* diag, u32 grp, u32 hskip) {
+__global__ void k_hint_mac_v(DevRing<W> R, W* out, const W* digits, const W* hint, size_t nct, u32 D, const W* diag, u32 grp, u32 hskip,
+                             const u32* slot_e, u32 n_d) {
     typedef typename Vec4<W>::type V;
     constexpr int VL = Vec4<W>::LANES, TILE = 4;
     const size_t n = (size_t)R.n;
@@ -404,6 +414,18 @@ __global__ void k_hint_mac_v(DevRing<W> R, W* out, const W* digits, const W* hin
         const size_t ct0 = wk.outer * TILE, rem = (size_t)wk.mid * n + (size_t)wk.k * VL;
         const u32 limb = wk.mid;
         const W q = R.mod[limb].q, qni = R.mod[limb].qni;
+        // E'-level digits: the VL slots of this piece read entries se[0..VL) of the small CRT vector; they are consecutive and
+        // 16-byte aligned whenever the innermost prime-power factor of s' divides e' with the same exponent (every hop of the
+        // reference), else gathered one by one
+        u32 se[VL];
+        bool piece = false;
+        if (slot_e) {
+#pragma unroll
+            for (int e = 0; e < VL; ++e) se[e] = slot_e[(size_t)wk.k * VL + e];
+            piece = (se[0] % VL == 0);
+#pragma unroll
+            for (int e = 1; e < VL; ++e) piece = piece && se[e] == se[0] + (u32)e;
+        }
         V acc0[TILE], acc1[TILE];
 #pragma unroll
         for (int c = 0; c < TILE; ++c) {
@@ -419,8 +441,18 @@ __global__ void k_hint_mac_v(DevRing<W> R, W* out, const W* digits, const W* hin
 #pragma unroll
             for (int c = 0; c < TILE; ++c) {
                 const size_t ct = ct0 + c < nct ? ct0 + c : ct0;
-                const V x = dg ? *reinterpret_cast<const V*>(diag + ct * Ln + rem)
-                               : *reinterpret_cast<const V*>(digits + (ct * (size_t)D + d) * Ln + rem);
+                V x;
+                if (slot_e) {
+                    const W* dv = digits + ((ct * (size_t)D + d) * R.L + limb) * (size_t)n_d;
+                    if (piece) x = *reinterpret_cast<const V*>(dv + se[0]);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < VL; ++e) x[e] = dv[se[e]];
+                    }
+                } else {
+                    x = dg ? *reinterpret_cast<const V*>(diag + ct * Ln + rem)
+                           : *reinterpret_cast<const V*>(digits + (ct * (size_t)D + d) * Ln + rem);
+                }
 #pragma unroll
                 for (int e = 0; e < VL; ++e) {
                     acc0[c][e] = csub((W)(acc0[c][e] + csub(mont_mul_lazy(x[e], h0[e], q, qni), q)), q);
@@ -536,9 +568,11 @@ __global__ void k_tunnel_gather(DevRing<W> Rs, const W* in, W* x0, W* x1, const 
 // Tunnel, step 2: c0' = sum_i crt(x0_i) * y_i (evalLin on the constant term), c1' = 0.  out: [ct][2][L][n];
 // x0crt: [ct][d_rel][Lx][n] holding the limbs xoff .. (the limbs in front of xoff are zero).
 template <typename W, int VW = 1>
-__global__ void k_tunnel_lin(DevRing<W> Rs, W* out, const W* x0crt, const W* lin, u32 d_rel, size_t nct, u32 Lx, u32 xoff) {
+__global__ void k_tunnel_lin(DevRing<W> Rs, W* out, const W* x0crt, const W* lin, u32 d_rel, size_t nct, u32 Lx, u32 xoff,
+                             const u32* slot_e, u32 n_x) {
+    // slot_e != null: x0crt holds CRT vectors of dimension n_x over E' ([ct][d_rel][Lx][n_x]); slot s of S' reads entry slot_e[s]
     typedef Pack<W, VW> P;
-    const size_t n = (size_t)Rs.n, Ln = (size_t)Rs.L * n, Lxn = (size_t)Lx * n;
+    const size_t n = (size_t)Rs.n, Ln = (size_t)Rs.L * n, Lxn = (size_t)Lx * (slot_e ? (size_t)n_x : n);
     ALCH_WALK_INIT(Rs.n / VW, Rs.L);
     ALCH_WALK(w, nct * Ln / VW, wk) {
         const size_t ct = wk.outer, rem = (size_t)wk.mid * n + (size_t)wk.k * VW;
@@ -547,9 +581,16 @@ __global__ void k_tunnel_lin(DevRing<W> Rs, W* out, const W* x0crt, const W* lin
 #pragma unroll
         for (int c = 0; c < VW; ++c) { acc.v[c] = 0; zero.v[c] = 0; }
         if (wk.mid >= xoff) {
-            const size_t xr = (size_t)(wk.mid - xoff) * n + (size_t)wk.k * VW;
+            const size_t xr = slot_e ? (size_t)(wk.mid - xoff) * n_x : (size_t)(wk.mid - xoff) * n + (size_t)wk.k * VW;
             for (u32 i = 0; i < d_rel; ++i) {
-                const P x = *reinterpret_cast<const P*>(x0crt + (ct * d_rel + i) * Lxn + xr), y = *reinterpret_cast<const P*>(lin + (size_t)i * Ln + rem);
+                P x;
+                if (slot_e) {
+#pragma unroll
+                    for (int c = 0; c < VW; ++c) x.v[c] = x0crt[(ct * d_rel + i) * Lxn + xr + slot_e[(size_t)wk.k * VW + c]];
+                } else {
+                    x = *reinterpret_cast<const P*>(x0crt + (ct * d_rel + i) * Lxn + xr);
+                }
+                const P y = *reinterpret_cast<const P*>(lin + (size_t)i * Ln + rem);
 #pragma unroll
                 for (int c = 0; c < VW; ++c) acc.v[c] = add_mod(acc.v[c], mont_mul(x.v[c], y.v[c], m), m.q);
             }
@@ -926,6 +967,7 @@ extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) 
     else if (k == "rs_lin") r->opts.rs_lin = value != 0;
     else if (k == "crt_half") r->opts.crt_half = value != 0;
     else if (k == "rs_half") r->opts.rs_half = value != 0;
+    else if (k == "tunnel_ep") r->opts.tunnel_ep = value != 0;
     else if (k == "gen_fused") r->opts.gen_fused = value != 0;
     else if (k == "split_fused") r->opts.split_fused = value != 0;
     else if (k == "scratch_mib") { if (value < 1 || value > 65536) return fail(ALCH_E_INVALID, "scratch_mib must be 1 .. 65536"); r->scratch_mib = (size_t)value; }
@@ -1580,12 +1622,12 @@ static int launch_gen_ks(alch_ring* r, const alch_hint* hint, const u32* a, cons
 
 template <typename W>
 static void launch_hint_mac(alch_ring* r, hipStream_t stream, W* out, const W* digits, const W* hint, size_t nct, u32 D,
-                            const W* diag = nullptr, u32 grp = 0, u32 hskip = 0) {
+                            const W* diag = nullptr, u32 grp = 0, u32 hskip = 0, const u32* slot_e = nullptr, u32 n_d = 0) {
     if (r->n % Vec4<W>::LANES == 0) {
         const size_t pieces = (nct + 3) / 4 * (size_t)r->L * (r->n / Vec4<W>::LANES);
-        hipLaunchKernelGGL((k_hint_mac_v<W>), dim3(ew_grid(pieces)), dim3(256), 0, stream, dev_ring<W>(r), out, digits, hint, nct, D, diag, grp, hskip);
+        hipLaunchKernelGGL((k_hint_mac_v<W>), dim3(ew_grid(pieces)), dim3(256), 0, stream, dev_ring<W>(r), out, digits, hint, nct, D, diag, grp, hskip, slot_e, n_d);
     } else {
-        hipLaunchKernelGGL((k_hint_mac<W>), dim3(ew_grid(nct * elem_words(r))), dim3(256), 0, stream, dev_ring<W>(r), out, digits, hint, nct, D, diag, grp, hskip);
+        hipLaunchKernelGGL((k_hint_mac<W>), dim3(ew_grid(nct * elem_words(r))), dim3(256), 0, stream, dev_ring<W>(r), out, digits, hint, nct, D, diag, grp, hskip, slot_e, n_d);
     }
 }
 
@@ -2143,9 +2185,10 @@ extern "C" int alch_tunnel_create(alch_ring* rr, alch_ring* rs, int gadget, cons
     if (rc != ALCH_OK) return rc;
     GenHost ge;
     gen_plan(ep, ge);
-    std::vector<int32_t> tab;
+    std::vector<int32_t> tab, tab_e;
+    std::vector<u32> slot_e;
     u32 mask = 0;
-    if (!gen_tunnel_table(ge, rr->gh, rs->gh, d_rel, tab, mask)) return fail(ALCH_E_INVALID, "indices do not form a tunnel");
+    if (!gen_tunnel_table(ge, rr->gh, rs->gh, d_rel, tab, mask, &tab_e, &slot_e)) return fail(ALCH_E_INVALID, "indices do not form a tunnel");
     const int digits = gadget_digits(rs, gadget);
     const size_t nlin = d_rel, nks = (size_t)d_rel * (size_t)digits * 2;
     if (lin_crt->n_elems < nlin || ks_crt->n_elems < nks)
@@ -2158,6 +2201,22 @@ extern "C" int alch_tunnel_create(alch_ring* rr, alch_ring* rs, int gadget, cons
         return fail(ALCH_E_NOMEM, "hipMalloc(tunnel) failed");
     }
     if (hipMemcpy(t->table, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { alch_tunnel_free(t); return fail(ALCH_E_HIP, "tunnel table upload failed"); }
+    if (ep != rs->m && rs->opts.tunnel_ep) {           // E' smaller than S': run the transforms there when E' has a general-index ring
+        alch_ring* re = nullptr;
+        if (alch_ring_create(ep, rs->L, rs->q, &re) == ALCH_OK && re->gen && re->word == rs->word && re->n % 4 == 0 && rs->n % 4 == 0) {
+            t->re = re;
+            if (hipMalloc((void**)&t->table_e, tab_e.size() * sizeof(int32_t)) != hipSuccess ||
+                hipMalloc((void**)&t->slot_e, slot_e.size() * sizeof(u32)) != hipSuccess ||
+                hipMemcpy(t->table_e, tab_e.data(), tab_e.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(t->slot_e, slot_e.data(), slot_e.size() * sizeof(u32), hipMemcpyHostToDevice) != hipSuccess) {
+                alch_tunnel_free(t);
+                return fail(ALCH_E_NOMEM, "hipMalloc(tunnel, E' tables) failed");
+            }
+        } else if (re) {
+            alch_ring_destroy(re);
+        }
+        BIND(rs);
+    }
     rc = rs->word == 4 ? tunnel_to_mont<u32>(rs, t->lin, lin_crt->dptr, nlin) : tunnel_to_mont<u64>(rs, t->lin, lin_crt->dptr, nlin);
     if (rc == ALCH_OK) rc = rs->word == 4 ? tunnel_to_mont<u32>(rs, t->ks, ks_crt->dptr, nks) : tunnel_to_mont<u64>(rs, t->ks, ks_crt->dptr, nks);
     if (rc != ALCH_OK) { alch_tunnel_free(t); return rc; }
@@ -2173,6 +2232,9 @@ extern "C" int alch_tunnel_free(alch_tunnel* t) {
     if (t->table) (void)hipFree(t->table);
     if (t->lin) (void)hipFree(t->lin);
     if (t->ks) (void)hipFree(t->ks);
+    if (t->table_e) (void)hipFree(t->table_e);
+    if (t->slot_e) (void)hipFree(t->slot_e);
+    if (t->re) alch_ring_destroy(t->re);
     delete t;
     return ALCH_OK;
 }
@@ -2208,9 +2270,13 @@ static int do_tunnel(const alch_tunnel* t, alch_ring* rin, const void* in, void*
     const u32 GD = base2 ? (u32)t->digits : Lx;     // gadget digits per embedded coefficient
     Scal<u32> b2first, b2kd;
     if (base2) base2_layout(rs, b2first, b2kd);
-    const size_t ebr = elem_bytes(rin), ebs = elem_bytes(rs), ebx = ebs / (size_t)L * Lx;
-    // scratch per ciphertext: Pow copy of the input (2 R'-elements), x0, x1 (D embedded coefficients each), digits (D * GD S'-elements)
-    const size_t per_ct = 2 * ebr + 2 * (size_t)D * ebx + (size_t)D * GD * ebs;
+    // rx: the ring the E'-coefficients are transformed in -- E' itself when the tunnel has its ring (the CRT over S' of an embedded
+    // element is its CRT over E' replicated: k_tunnel_lin / k_hint_mac read it through slot_e), else S' with the coefficients embedded
+    alch_ring* rx = t->re ? t->re : rs;
+    const u32* slot_e = t->re ? t->slot_e : nullptr;
+    const size_t ebr = elem_bytes(rin), ebs = elem_bytes(rs), ebd = elem_bytes(rx), ebx = ebd / (size_t)L * Lx;
+    // scratch per ciphertext: Pow copy of the input (2 R'-elements), x0, x1 (D coefficients each), digits (D * GD elements of rx)
+    const size_t per_ct = 2 * ebr + 2 * (size_t)D * ebx + (size_t)D * GD * ebd;
     size_t chunk = std::max<size_t>(1, (rs->scratch_mib << 20) / per_ct);
     chunk = std::min(chunk, batch);
     int rc = ensure_ws(&rs->ws_full, &rs->ws_full_bytes, chunk * per_ct);
@@ -2243,42 +2309,43 @@ static int do_tunnel(const alch_tunnel* t, alch_ring* rin, const void* in, void*
             hipError_t e = gen_dispatch(g);
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("tunnel lInv launch: ") + hipGetErrorString(e));
         }
-        const size_t gw = now * 2 * (size_t)D * Lx * rs->n;
-        ALCH_LAUNCH_VW(k_tunnel_gather, rs, gw, rs->stream, dev_ring<W>(rs), (const W*)win, (W*)x0, (W*)x1,
-                           t->table, D, rr->n, now, sm, scale ? 1 : 0, Lx, xoff, (u32)dup);
+        const size_t gw = now * 2 * (size_t)D * Lx * rx->n;
+        ALCH_LAUNCH_VW(k_tunnel_gather, rx, gw, rs->stream, dev_ring<W>(rx), (const W*)win, (W*)x0, (W*)x1,
+                           t->re ? t->table_e : t->table, D, rr->n, now, sm, scale ? 1 : 0, Lx, xoff, (u32)dup);
         HIP_TRY(hipGetLastError());
         // constant term: evalLin
         if (compact) {
             DevRing<W> dv; GenDev<W> gv;
-            gen_suffix_view<W>(rs, dup, dv, gv);
+            gen_suffix_view<W>(rx, dup, dv, gv);
             GenCall<W> g{};
             g.op = GEN_CRT; g.ring = &dv; g.gen = &gv; g.stream = rs->stream;
             g.data = reinterpret_cast<W*>(x0); g.first_poly = 0; g.npoly = now * (size_t)D * Lx;
             hipError_t e = gen_dispatch(g);
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("tunnel crt launch: ") + hipGetErrorString(e));
-        } else if ((rc = do_crt<W>(rs, x0, 0, now * D, false)) != ALCH_OK) return rc;
+        } else if ((rc = do_crt<W>(rx, x0, 0, now * D, false, nullptr, rs->stream)) != ALCH_OK) return rc;
         W* po = reinterpret_cast<W*>(reinterpret_cast<char*>(out) + done * 2 * ebs);
         ALCH_LAUNCH_VW(k_tunnel_lin, rs, now * elem_words(rs), rs->stream, dev_ring<W>(rs), po, (const W*)x0,
-                           (const W*)t->lin, D, now, Lx, xoff);
+                           (const W*)t->lin, D, now, Lx, xoff, slot_e, rx->n);
         HIP_TRY(hipGetLastError());
         // linear term: decompose + reduce + crt of every embedded coefficient, inner product with the hints
         if (base2) {                                 // BaseBGad 2 (examples/Tunnel.hs:24): decompose + reduce in the transforms' loader
             GenCall<W> g{};
-            g.op = GEN_CRT_BASE2; g.ring = &dev_ring<W>(rs); g.gen = &gen_dev<W>(rs); g.stream = rs->stream;
+            g.op = GEN_CRT_BASE2; g.ring = &dev_ring<W>(rx); g.gen = &gen_dev<W>(rx); g.stream = rs->stream;
             g.src = reinterpret_cast<const W*>(x1); g.data = reinterpret_cast<W*>(dig);
             g.npoly = now * (size_t)D * (size_t)GD * (size_t)L; g.b2_first = b2first; g.b2_kd = b2kd; g.b2_D = GD;
             hipError_t e = gen_dispatch(g);
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("tunnel base2 crt_digits launch: ") + hipGetErrorString(e));
         } else {
             GenCall<W> g{};
-            g.op = GEN_CRT_DIGITS; g.ring = &dev_ring<W>(rs); g.gen = &gen_dev<W>(rs); g.stream = rs->stream;
+            g.op = GEN_CRT_DIGITS; g.ring = &dev_ring<W>(rx); g.gen = &gen_dev<W>(rx); g.stream = rs->stream;
             g.src = reinterpret_cast<const W*>(x1); g.data = reinterpret_cast<W*>(dig);
             g.npoly = now * (size_t)D * (size_t)Lx * (size_t)L; g.balanced = rs->balanced; g.with_diag = true;
             g.src_limbs = (int)Lx; g.src_first = (int)xoff;
             hipError_t e = gen_dispatch(g);
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("tunnel crt_digits launch: ") + hipGetErrorString(e));
         }
-        launch_hint_mac<W>(rs, rs->stream, po, (const W*)dig, (const W*)t->ks, now, D * GD, (const W*)nullptr, Lx, compact ? (u32)dup : 0u);
+        launch_hint_mac<W>(rs, rs->stream, po, (const W*)dig, (const W*)t->ks, now, D * GD, (const W*)nullptr, Lx, compact ? (u32)dup : 0u,
+                           slot_e, rx->n);
         HIP_TRY(hipGetLastError());
     }
     return ALCH_OK;

@@ -211,8 +211,14 @@ inline bool gen_tables(const GenHost& g, u64 q, std::vector<u64>& fwd, std::vect
 // table[i * n_s + k] = the position in R' whose coefficient lands there -- coeffs (R' -> E', relative index i) followed by
 // embedPow (E' -> S') -- or -1 where embedPow leaves a zero.  ep = gcd(r', s'); relative indices in mixed radix, first
 // prime outermost (the order of oracle/model_gen.py coeffs_indices).
+// table_e (optional): the same gather BEFORE embedPow, [d_rel][n_e] positions in R' of the Pow coefficients of E'-coefficient i.
+// slot_e (optional): for every CRT slot of S' the CRT slot of E' that holds the same value for an element of E' embedded into S'
+//   (Tensor embedCRT): crt_S'(embed d)[s] = crt_E'(d)[slot_e[s]].  With the slot rule of include/alchemy_hip.h (first factor
+//   outermost, within a factor s = (i0 - 1) p^(e-1) + digitrev(i1) for the unit i0 + p i1) reducing a unit mod p^ee keeps i0 and
+//   the low digits of i1, i.e. the HIGH digits of the reversed index: the factor's slot index is divided by p^(es - ee); a prime
+//   that does not divide e' drops out.  Checked against the by-definition model in tests/test_oracle_tunnel.py.
 inline bool gen_tunnel_table(const GenHost& ep, const GenHost& rp, const GenHost& sp, u32& d_rel, std::vector<int32_t>& table,
-                             u32& linv_skip_mask) {
+                             u32& linv_skip_mask, std::vector<int32_t>* table_e = nullptr, std::vector<u32>* slot_e = nullptr) {
     if (rp.m % ep.m || sp.m % ep.m) return false;
     auto expo = [](const GenHost& g, int p) { for (int l = 0; l < g.nfact; ++l) if (g.fact[l].p == p) return g.fact[l].e; return 0; };
     auto ipow = [](u32 b, int e) { u32 r = 1; while (e-- > 0) r *= b; return r; };
@@ -229,6 +235,20 @@ inline bool gen_tunnel_table(const GenHost& ep, const GenHost& rp, const GenHost
     }
     if ((u64)d_rel * ep.n != rp.n) return false;
     table.assign((size_t)d_rel * sp.n, -1);
+    if (table_e) table_e->assign((size_t)d_rel * ep.n, -1);
+    if (slot_e) {
+        slot_e->assign(sp.n, 0);
+        for (u32 s = 0; s < sp.n; ++s) {
+            u32 se = 0;
+            for (int l = 0; l < sp.nfact; ++l) {
+                const int p = sp.fact[l].p, es = sp.fact[l].e, ee = expo(ep, p);
+                if (!ee) continue;
+                const u32 sf = (s / sp.fact[l].rts) % sp.fact[l].dim;
+                for (int le = 0; le < ep.nfact; ++le) if (ep.fact[le].p == p) se += (sf / ipow((u32)p, es - ee)) * ep.fact[le].rts;
+            }
+            (*slot_e)[s] = se;
+        }
+    }
     for (u32 i = 0; i < d_rel; ++i) {
         u32 rel[GEN_MAXFACT], t = i;
         for (int l = rp.nfact - 1; l >= 0; --l) { rel[l] = t % rel_dim[l]; t /= rel_dim[l]; }
@@ -248,6 +268,7 @@ inline bool gen_tunnel_table(const GenHost& ep, const GenHost& rp, const GenHost
                 poss += jp * ipow((u32)p, es - ee) * sp.fact[l].rts;
             }
             table[(size_t)i * sp.n + poss] = (int32_t)posr;
+            if (table_e) (*table_e)[(size_t)i * ep.n + j] = (int32_t)posr;
         }
     }
     return true;

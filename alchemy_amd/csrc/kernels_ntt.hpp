@@ -90,6 +90,7 @@ struct LaunchOpts {
                              // 0 = only where k_rescale_out_lin cannot serve (three dropped limbs, unbalanced two-limb drops).  Measured on the
                              // 4 -> 5 -> 3 mul_: 0.473 + 0.925 ms per 1024 ciphertexts against k_rescale_out_lin's 1.331 ms -- the combination is
                              // recomputed from the stash per kept limb and costs what the second workgroup per CU gains
+    int tunnel_ep = 1;       // alch_tunnel_create: 1 = transforms of the embedded E'-coefficients at dimension phi(e') (embedCRT replication), 0 = at phi(s')
     int rs_lin = 1;          // closing modSwitch: 1 = kept limbs stay in the CRT basis (k_rescale_out_lin), 0 = every limb through the Pow basis
     unsigned ks_grid = 4096; // persistent workgroups of k_ks_accum_half (measured, 1024-ciphertext chunks: 2048 -> 511k, 4096 -> 517k, 8192 -> 513k op/s)
 };

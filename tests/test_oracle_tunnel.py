@@ -76,3 +76,34 @@ def test_c_restatement_composition_reproduces_the_fixture(oracle_lib):
         c0, c1 = Or.crt(to_aos(rec["ct_in"][0])), Or.crt(to_aos(rec["ct_in"][1]))
         w0, w1 = oracle_tunnel(oracle_lib, rec["rp"], rec["sp"], qs, lin, ks, c0, c1, pow_out=True)
         assert lm(w0) == rec["ct_out"][0] and lm(w1) == rec["ct_out"][1], (rec["rp"], rec["sp"])
+
+
+def _slot_of_the_subring(ie, isx):
+    """The embedCRT slot rule the device's E'-level tunnel path relies on (alchemy_amd/csrc/gen_host.hpp, gen_tunnel_table):
+    per prime-power factor the slot index is divided by p^(e_s - e_e); primes that do not divide e' drop out."""
+    exp_e = {p: e for p, e in ie.pps}
+    out = []
+    for s in range(isx.n):
+        se = 0
+        for (p, es), sf in zip(isx.pps, isx.unravel(s)):
+            if p in exp_e:
+                ee = exp_e[p]
+                se = se * ((p - 1) * p ** (ee - 1)) + sf // p ** (es - ee)
+        out.append(se)
+    return out
+
+
+@pytest.mark.parametrize("e_m,s_m", [(20, 60), (8, 24), (9, 45), (12, 36), (40, 120), (28, 364), (16, 32), (5, 25), (50, 100), (21, 63), (24, 360)])
+def test_crt_of_an_embedded_element_is_the_small_crt_replicated(e_m, s_m):
+    """crt_S'(embedPow d)[s] = crt_E'(d)[slot(s)] by direct evaluation of both sides (Tensor embedCRT): the identity that lets a
+    tunnel run the transforms of its embedded E'-coefficients at dimension phi(e')."""
+    import random
+    from helpers import primes_1_mod
+    ie, isx = G.Index(e_m), G.Index(s_m)
+    q = primes_1_mod(s_m, 1, 1 << 20)[0]
+    rng = random.Random(e_m * 1000 + s_m)
+    d = [rng.randrange(q) for _ in range(ie.n)]
+    big = G.crt_def(G.embed_pow(d, ie, isx), isx, q)
+    small = G.crt_def(d, ie, q)
+    slot = _slot_of_the_subring(ie, isx)
+    assert all(big[s] == small[slot[s]] for s in range(isx.n))
