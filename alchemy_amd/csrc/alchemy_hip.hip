@@ -400,11 +400,13 @@ __global__ void k_hint_mac(DevRing<W> R, W* out, const W* digits, const W* hint,
 
 // The same with 16-byte accesses: a thread owns one piece of VL consecutive slots of TILE ciphertexts (n a multiple of VL).
 // The one-word form moved 2.4 TB/s in the HomomRLWR pipeline -- bound by the number of memory instructions, not by HBM.
-template <typename W>
+template <typename W, int TILE>
 __global__ void k_hint_mac_v(DevRing<W> R, W* out, const W* digits, const W* hint, size_t nct, u32 D, const W* diag, u32 grp, u32 hskip,
                              const u32* slot_e, u32 n_d) {
     typedef typename Vec4<W>::type V;
-    constexpr int VL = Vec4<W>::LANES, TILE = 4;
+    // TILE ciphertexts share every hint piece.  Measured on the HomomRLWR pipeline with E'-level digits (small vectors served by
+    // L2, the hint rows being what comes from HBM): TILE 2 -> 29.3 k, 4 -> 29.5 k, 8 -> 23.5 k ringRounds/s
+    constexpr int VL = Vec4<W>::LANES;
     const size_t n = (size_t)R.n;
     const size_t Ln = (size_t)R.L * n;
     const size_t ntile = (nct + TILE - 1) / TILE;
@@ -1625,7 +1627,7 @@ static void launch_hint_mac(alch_ring* r, hipStream_t stream, W* out, const W* d
                             const W* diag = nullptr, u32 grp = 0, u32 hskip = 0, const u32* slot_e = nullptr, u32 n_d = 0) {
     if (r->n % Vec4<W>::LANES == 0) {
         const size_t pieces = (nct + 3) / 4 * (size_t)r->L * (r->n / Vec4<W>::LANES);
-        hipLaunchKernelGGL((k_hint_mac_v<W>), dim3(ew_grid(pieces)), dim3(256), 0, stream, dev_ring<W>(r), out, digits, hint, nct, D, diag, grp, hskip, slot_e, n_d);
+        hipLaunchKernelGGL((k_hint_mac_v<W, 4>), dim3(ew_grid(pieces)), dim3(256), 0, stream, dev_ring<W>(r), out, digits, hint, nct, D, diag, grp, hskip, slot_e, n_d);
     } else {
         hipLaunchKernelGGL((k_hint_mac<W>), dim3(ew_grid(nct * elem_words(r))), dim3(256), 0, stream, dev_ring<W>(r), out, digits, hint, nct, D, diag, grp, hskip, slot_e, n_d);
     }
