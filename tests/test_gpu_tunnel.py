@@ -49,13 +49,17 @@ def test_tunnel_hop_matches_the_oracle(oracle_lib, rp, sp, L, batch):
     lin, ks = rand_elems(rng, d_rel, gs.n, qs), rand_elems(rng, 2 * d_rel * L, gs.n, qs)
     cts = rand_elems(rng, 2 * batch, gr.n, qs)
     s_pre = [int(rng.integers(1, q)) for q in qs]
-    tun = A.Tunnel(gr, gs, gs.upload(lin), gs.upload(ks))
+    want = [oracle_tunnel(oracle_lib, rp, sp, qs, list(lin), list(ks), cts[2 * ct], cts[2 * ct + 1], s_pre) for ct in range(batch)]
     gin, gout = gr.upload(cts), gs.alloc(2 * batch)
-    tun.apply(gin, gout, batch, s_pre=s_pre)
-    got = gout.download()
-    for ct in range(batch):
-        w0, w1 = oracle_tunnel(oracle_lib, rp, sp, qs, list(lin), list(ks), cts[2 * ct], cts[2 * ct + 1], s_pre)
-        assert np.array_equal(got[2 * ct], w0) and np.array_equal(got[2 * ct + 1], w1), ct
+    # tunnel_ep = 1 (default): the embedded E'-coefficients are transformed at dimension phi(e') and read through the embedCRT slot
+    # table; 0: embedded into S' first and transformed there
+    for ep_level in (1, 0):
+        gs.set_option("tunnel_ep", ep_level)
+        tun = A.Tunnel(gr, gs, gs.upload(lin), gs.upload(ks))
+        tun.apply(gin, gout, batch, s_pre=s_pre)
+        got = gout.download()
+        for ct in range(batch):
+            assert np.array_equal(got[2 * ct], want[ct][0]) and np.array_equal(got[2 * ct + 1], want[ct][1]), (ct, ep_level)
 
 
 @pytest.mark.parametrize("rp,sp,L,dup,gadget", [(40, 60, 3, 1, "triv"), (63, 105, 4, 2, "triv"), (11648, 29120, 6, 1, "triv"),
