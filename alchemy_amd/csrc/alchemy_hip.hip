@@ -2414,7 +2414,7 @@ static int do_mod_switch(alch_ring* rin, alch_ring* rout, const void* in, void* 
     const int L = rin->L, ddn = L - rout->L;
     const size_t eb = elem_bytes(rin);
     const bool dec_c0 = rin->gen && rin->gh.rad > 1;
-    if (rin->gen && rin->opts.rs_lin && ddn <= MAXDROP && !(flags & (ALCH_POW_IN | ALCH_POW_OUT))) {
+    if (rin->gen && rin->opts.rs_lin && ddn <= MAXDROP && !(flags & ALCH_POW_IN)) {
         // kept limbs stay in the CRT basis (k_gen_rescale_drop / k_gen_rescale_keep)
         DropTab<W> dt;
         fill_drop_tab<W>(rin, ddn, dt);
@@ -2428,7 +2428,7 @@ static int do_mod_switch(alch_ring* rin, alch_ring* rout, const void* in, void* 
                                                     reinterpret_cast<const W*>(reinterpret_cast<const char*>(in) + done * 2 * eb),
                                                     reinterpret_cast<W*>(rin->ws_full),
                                                     reinterpret_cast<W*>(reinterpret_cast<char*>(out) + done * 2 * elem_bytes(rout)), dt,
-                                                    dec_c0 ? 1 : 0, 2 * now, rin->stream);
+                                                    dec_c0 ? 1 : 0, 2 * now, rin->stream, (flags & ALCH_POW_OUT) != 0);
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("rescale launch: ") + hipGetErrorString(e));
         }
         return ALCH_OK;

@@ -101,8 +101,8 @@ struct GenCall {
 hipError_t gen_dispatch(const GenCall<u32>& c);
 hipError_t gen_dispatch(const GenCall<u64>& c);
 template <typename W> struct GenKsArgs;
-hipError_t gen_rescale_lin_dispatch(const DevRing<u32>& R, const GenDev<u32>& G, const u32* in, u32* res, u32* out, const DropTab<u32>& D, int dec_c0, size_t nelem, hipStream_t stream);
-hipError_t gen_rescale_lin_dispatch(const DevRing<u64>& R, const GenDev<u64>& G, const u64* in, u64* res, u64* out, const DropTab<u64>& D, int dec_c0, size_t nelem, hipStream_t stream);
+hipError_t gen_rescale_lin_dispatch(const DevRing<u32>& R, const GenDev<u32>& G, const u32* in, u32* res, u32* out, const DropTab<u32>& D, int dec_c0, size_t nelem, hipStream_t stream, bool pow_out = false);
+hipError_t gen_rescale_lin_dispatch(const DevRing<u64>& R, const GenDev<u64>& G, const u64* in, u64* res, u64* out, const DropTab<u64>& D, int dec_c0, size_t nelem, hipStream_t stream, bool pow_out = false);
 hipError_t gen_ks_dispatch(const DevRing<u32>& R, const GenDev<u32>& G, const GenKsArgs<u32>& A, size_t nct, hipStream_t stream);
 hipError_t gen_ks_dispatch(const DevRing<u64>& R, const GenDev<u64>& G, const GenKsArgs<u64>& A, size_t nct, hipStream_t stream);
 
@@ -799,12 +799,68 @@ __global__ void __launch_bounds__(GEN_T) k_gen_rescale_keep(DevRing<W> R, GenDev
     }
 }
 
+// The same modSwitch with the result left in the Pow basis (what Lol's rescale returns, and what the next tunnel reads: a hop
+// handed over in the Pow basis saves that tunnel's crtInv): per (element, kept limb) crtInv of the limb itself (+ lInv for c0),
+// z = x C_t - sum_u reduce_t(R_u) c_{u,t} coefficient-wise (crtInv's closing scalar folded into C_t), (l,) store.  Same number
+// of transforms as k_gen_rescale_keep (one per kept limb-polynomial), inverse instead of forward.
+template <typename W>
+__global__ void __launch_bounds__(GEN_T, 4) k_gen_rescale_keep_pow(DevRing<W> R, GenDev<W> G, const W* __restrict__ in, const W* __restrict__ res,
+                                                                   W* __restrict__ out, DropTab<W> D, int dec_c0) {
+    typedef typename Signed<W>::type SW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W* lds = reinterpret_cast<W*>(smem);
+    const int L = R.L, ddn = D.ddn, Lo = L - ddn;
+    const size_t e = blockIdx.x / (unsigned)Lo;
+    const int t = ddn + (int)(blockIdx.x % (unsigned)Lo);
+    const u32 n = G.n;
+    const W q = R.mod[t].q, qni = R.mod[t].qni;
+    auto reduce = [](SW z, W qq) -> W {
+        if (z < (SW)qq && z > -(SW)qq) return z < 0 ? (W)(z + (SW)qq) : (W)z;
+        SW r = z % (SW)qq;
+        return r < 0 ? (W)(r + (SW)qq) : (W)r;
+    };
+    typedef typename Vec4<W>::type V;
+    constexpr u32 VL = Vec4<W>::LANES;
+    const bool vec = n % VL == 0;
+    const W* x = in + (e * (size_t)L + t) * (size_t)n;
+    if (vec) for (u32 i = threadIdx.x * VL; i < n; i += GEN_T * VL) *reinterpret_cast<V*>(lds + i) = *reinterpret_cast<const V*>(x + i);
+    else for (u32 i = threadIdx.x; i < n; i += GEN_T) lds[i] = x[i];
+    lds_barrier();
+    gen_transform<W, true>(lds, G, t, q, qni);
+    const bool dec = dec_c0 && (e & 1) == 0;
+    ColArith<W, false> A{q, qni, R.mod[t].r2, 0};
+    if (dec) gen_columns_lds<W, false, GEN_LINV>(lds, G, A, 0u);
+    const W scCt = csub(mont_mul_lazy(G.iscale_m[t], D.comb_m[0][t], q, qni), q);      // crtInv's closing scalar times C_t (Montgomery form)
+    const W* r0 = res + (e * (size_t)ddn) * (size_t)n;
+    for (u32 k = threadIdx.x; k < n; k += GEN_T) {
+        SW lifted[MAXDROP];
+        W a = 0;
+#pragma unroll
+        for (int u = 0; u < MAXDROP; ++u) {
+            if (u >= ddn) continue;
+            const W qu = R.mod[u].q, qniu = R.mod[u].qni;
+            W y = r0[(size_t)u * n + k];
+#pragma unroll
+            for (int v = 0; v < u; ++v)
+                y = csub(mont_mul_lazy((W)(y + (qu - reduce(lifted[v], qu))), D.qinv_m[v][u], qu, qniu), qu);
+            lifted[u] = y > ((qu - 1) >> 1) ? (SW)y - (SW)qu : (SW)y;
+            a = csub((W)(a + csub(mont_mul_lazy(reduce(lifted[u], q), D.comb_m[u][t], q, qni), q)), q);
+        }
+        lds[k] = csub((W)(csub(mont_mul_lazy(lds[k], scCt, q, qni), q) + (q - a)), q);   // every lane rewrites the words it read
+    }
+    lds_barrier();
+    if (dec) gen_columns_lds<W, false, GEN_L>(lds, G, A, 0u);
+    W* o = out + (e * (size_t)Lo + (t - ddn)) * (size_t)n;
+    if (vec) for (u32 i = threadIdx.x * VL; i < n; i += GEN_T * VL) *reinterpret_cast<V*>(o + i) = *reinterpret_cast<const V*>(lds + i);
+    else for (u32 i = threadIdx.x; i < n; i += GEN_T) o[i] = lds[i];
+}
+
 template <typename W>
 inline hipError_t gen_launch_rescale_lin(const DevRing<W>& R, const GenDev<W>& G, const W* in, W* res, W* out, const DropTab<W>& D,
-                                         int dec_c0, size_t nelem, hipStream_t stream) {
+                                         int dec_c0, size_t nelem, hipStream_t stream, bool pow_out = false) {
     const size_t lds_bytes = (size_t)G.n * sizeof(W);
     auto k1 = k_gen_rescale_drop<W>;
-    auto k2 = k_gen_rescale_keep<W>;
+    auto k2 = pow_out ? k_gen_rescale_keep_pow<W> : k_gen_rescale_keep<W>;
     hipError_t e;
     if ((e = set_lds(k1, lds_bytes)) != hipSuccess) return e;
     if ((e = set_lds(k2, lds_bytes)) != hipSuccess) return e;

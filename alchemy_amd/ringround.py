@@ -23,8 +23,9 @@ def moduli(L):
 
 
 class RingRound:
-    def __init__(self, batch, ring_opts=()):
+    def __init__(self, batch, ring_opts=(), pow_handoff=True):
         self.B = batch
+        self.pow_handoff = pow_handoff
         self.rings, self.pool, self.cursor, self.pubs, self.stages = {}, [], 0, {}, {}
         self.ring_opts = tuple(ring_opts)
         # PT2CT's limb counts, resolved backwards from the output pNoise 0
@@ -108,11 +109,17 @@ class RingRound:
             rr, rs, ro = ring(HP[k], lh_), ring(HP[k + 1], lh_), ring(HP[k + 1], lout_)
 
             def hop(cur=cur, rr=rr, rs=rs, ro=ro, k=k, lin_=lin_, lh_=lh_, lout_=lout_):
-                # modSwitch_ (up) .: tunnel_ hint as one call: the ciphertexts stay on their lin_ limbs
+                # modSwitch_ (up) .: tunnel_ hint as one call: the ciphertexts stay on their lin_ limbs.  Between two hops the
+                # ciphertexts are handed over in the Pow basis (what Lol's rescale leaves them in and its tunnel reads): the
+                # closing modSwitch then needs no forward transforms and the next tunnel no inverse ones.
+                pow_in = capi.ALCH_POW_IN if (k > 0 and self.pow_handoff) else 0
+                pow_out = capi.ALCH_POW_OUT if (k < 4 and self.pow_handoff) else 0
                 mid = scratch(rs, 2 * B)
-                self.tunnels[k].apply(cur, mid, B)
                 if lout_ < lh_:
-                    dn = scratch(ro, 2 * B); capi.ct_mod_switch(mid, dn, B); mid = dn
+                    self.tunnels[k].apply(cur, mid, B, flags=pow_in)
+                    dn = scratch(ro, 2 * B); capi.ct_mod_switch(mid, dn, B, flags=pow_out); mid = dn
+                else:
+                    self.tunnels[k].apply(cur, mid, B, flags=pow_in | pow_out)
                 return mid
             cur = timed(f"tunnel{k + 1}", rs, hop)
         # rescale tree on H5'

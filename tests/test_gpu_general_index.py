@@ -174,6 +174,12 @@ def test_ct_mod_switch_down_and_up(oracle_lib, m, L, drop):
         got = gy.download()
         for e in range(2 * batch):
             assert np.array_equal(got[e], want[e]), (e, lin)
+        if gen:                                 # Pow-basis output (the hand-over between two tunnel hops)
+            capi.ct_mod_switch(gx, gy, batch, flags=capi.ALCH_POW_OUT)
+            gotp = gy.download()
+            for e in range(2 * batch):
+                assert np.array_equal(gotp[e], mk(qs[drop:]).crtinv(want[e])), (e, lin, "pow")
+            capi.ct_mod_switch(gx, gy, batch)   # back to the CRT-basis result for the checks below
     assert np.array_equal(gx.download(), x)                   # input untouched
     # and up again: (0, .., 0, q_a x)
     gz = Rb.alloc(2 * batch)
