@@ -540,8 +540,10 @@ __global__ void k_add_bcast(DevRing<W> R, W* dst, const W* pub, size_t cts) {
 // (PT2CT's modSwitch_ in front of tunnel_, PT2CT.hs:224-229: x -> (0, q_a x), the factor folded into s_m by the host);
 // x0 / x1: [ct][d_rel][Lx][n_s] holding the limbs xoff .. xoff + Lx - 1 (compact: the zero limbs are left out).
 template <typename W, int VW = 1>
-__global__ void k_tunnel_gather(DevRing<W> Rs, const W* in, W* x0, W* x1, const int32_t* table, u32 d_rel, u32 n_r, size_t nct, Scal<W> s_m,
-                                int scale, u32 Lx, u32 xoff, u32 dup) {
+__global__ void k_tunnel_gather(DevRing<W> Rs, const W* in0, const W* in1, W* x0, W* x1, const int32_t* table, u32 d_rel, u32 n_r, size_t nct,
+                                Scal<W> s_m, int scale, u32 Lx, u32 xoff, u32 dup) {
+    // in0 / in1: where the c0 / c1 components are read from (same [ct][2][..] layout: c0 may come from a scratch copy that went
+    // through lInv while c1 is read in place)
     typedef Pack<W, VW> P;
     typedef Pack<int32_t, VW> PI;
     const size_t n = (size_t)Rs.n, Lin = (size_t)Rs.L - dup;
@@ -558,7 +560,7 @@ __global__ void k_tunnel_gather(DevRing<W> Rs, const W* in, W* x0, W* x1, const 
         for (int c = 0; c < VW; ++c) {
             W x = 0;
             if (src.v[c] >= 0 && limb >= dup) {
-                x = in[((2 * ct + comp) * Lin + (limb - dup)) * (size_t)n_r + (size_t)src.v[c]];
+                x = (comp ? in1 : in0)[((2 * ct + comp) * Lin + (limb - dup)) * (size_t)n_r + (size_t)src.v[c]];
                 if (scale) x = mont_mul(x, s_m.v[limb], Rs.mod[limb]);
             }
             v.v[c] = x;
@@ -2301,18 +2303,22 @@ static int do_tunnel(const alch_tunnel* t, alch_ring* rin, const void* in, void*
         const size_t now = std::min(chunk, batch - done);
         const char* src = reinterpret_cast<const char*>(in) + done * 2 * ebr;
         // Pow basis of R' (a copy: the caller's ciphertexts are left alone); c0 onto relative-Dec (x) Pow(E')
-        if (flags & ALCH_POW_IN) HIP_TRY(hipMemcpyAsync(win, src, now * 2 * ebr, hipMemcpyDeviceToDevice, rs->stream));
-        else if ((rc = do_crt<W>(rin, win, 0, 2 * now, true, src, rs->stream)) != ALCH_OK) return rc;
+        // Pow-basis input is read in place (c1 always; c0 through an out-of-place lInv into the scratch when the tunnel needs one)
+        const bool pin = (flags & ALCH_POW_IN) != 0;
+        if (!pin && (rc = do_crt<W>(rin, win, 0, 2 * now, true, src, rs->stream)) != ALCH_OK) return rc;
         if (dec_c0) {
             GenCall<W> g{};
             g.op = GEN_LINV; g.ring = &dev_ring<W>(rin); g.gen = &gen_dev<W>(rin); g.stream = rs->stream;
-            g.data = reinterpret_cast<W*>(win); g.elem_stride = 2; g.first_poly = 0; g.npoly = now * (size_t)rin->L;
+            g.data = reinterpret_cast<W*>(win); g.src = pin ? reinterpret_cast<const W*>(src) : nullptr;
+            g.elem_stride = 2; g.first_poly = 0; g.npoly = now * (size_t)rin->L;
             g.skip_mask = t->linv_skip_mask; g.fail_flag = rin->d_flag;
             hipError_t e = gen_dispatch(g);
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("tunnel lInv launch: ") + hipGetErrorString(e));
         }
+        const W* in0 = (pin && !dec_c0) ? reinterpret_cast<const W*>(src) : reinterpret_cast<const W*>(win);
+        const W* in1 = pin ? reinterpret_cast<const W*>(src) : reinterpret_cast<const W*>(win);
         const size_t gw = now * 2 * (size_t)D * Lx * rx->n;
-        ALCH_LAUNCH_VW(k_tunnel_gather, rx, gw, rs->stream, dev_ring<W>(rx), (const W*)win, (W*)x0, (W*)x1,
+        ALCH_LAUNCH_VW(k_tunnel_gather, rx, gw, rs->stream, dev_ring<W>(rx), in0, in1, (W*)x0, (W*)x1,
                            t->re ? t->table_e : t->table, D, rr->n, now, sm, scale ? 1 : 0, Lx, xoff, (u32)dup);
         HIP_TRY(hipGetLastError());
         // constant term: evalLin

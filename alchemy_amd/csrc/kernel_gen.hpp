@@ -635,7 +635,8 @@ __device__ __forceinline__ void gen_columns_lds(W* lds, const GenDev<W>& G, cons
 }
 
 template <typename W, bool ZDOM, int OP>
-__global__ void __launch_bounds__(GEN_T) k_gen_columns(DevRing<W> R, GenDev<W> G, W* data, size_t first_elem, size_t elem_stride, int* fail_flag, u32 skip_mask) {
+__global__ void __launch_bounds__(GEN_T) k_gen_columns(DevRing<W> R, GenDev<W> G, W* data, size_t first_elem, size_t elem_stride, int* fail_flag, u32 skip_mask,
+                                                       const W* src) {
     typedef typename Signed<W>::type SW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W* lds = reinterpret_cast<W*>(smem);
@@ -645,7 +646,8 @@ __global__ void __launch_bounds__(GEN_T) k_gen_columns(DevRing<W> R, GenDev<W> G
     const u32 n = G.n;
     W* poly = data + (e * (size_t)L + j) * (size_t)n;
     ColArith<W, ZDOM> A{R.mod[j].q, R.mod[j].qni, R.mod[j].r2, G.plain};
-    for (u32 i = threadIdx.x; i < n; i += GEN_T) lds[i] = poly[i];
+    const W* from = src ? src + (e * (size_t)L + j) * (size_t)n : poly;       // src != null: out of place (same element layout)
+    for (u32 i = threadIdx.x; i < n; i += GEN_T) lds[i] = from[i];
     lds_barrier();
     gen_columns_lds<W, ZDOM, OP>(lds, G, A, skip_mask);
     if (OP == GEN_DIVG_POW || OP == GEN_DIVG_DEC) {      // divide by the odd radical of m (lol-cpp: Z_q multiplies by rad^-1, Z checks)
@@ -832,21 +834,44 @@ __global__ void __launch_bounds__(GEN_T, 4) k_gen_rescale_keep_pow(DevRing<W> R,
     if (dec) gen_columns_lds<W, false, GEN_LINV>(lds, G, A, 0u);
     const W scCt = csub(mont_mul_lazy(G.iscale_m[t], D.comb_m[0][t], q, qni), q);      // crtInv's closing scalar times C_t (Montgomery form)
     const W* r0 = res + (e * (size_t)ddn) * (size_t)n;
-    for (u32 k = threadIdx.x; k < n; k += GEN_T) {
+    auto combine = [&](const W* y0) -> W {                     // one coefficient: y0[u] = residue of dropped limb u
         SW lifted[MAXDROP];
         W a = 0;
 #pragma unroll
         for (int u = 0; u < MAXDROP; ++u) {
             if (u >= ddn) continue;
             const W qu = R.mod[u].q, qniu = R.mod[u].qni;
-            W y = r0[(size_t)u * n + k];
+            W y = y0[u];
 #pragma unroll
             for (int v = 0; v < u; ++v)
                 y = csub(mont_mul_lazy((W)(y + (qu - reduce(lifted[v], qu))), D.qinv_m[v][u], qu, qniu), qu);
             lifted[u] = y > ((qu - 1) >> 1) ? (SW)y - (SW)qu : (SW)y;
             a = csub((W)(a + csub(mont_mul_lazy(reduce(lifted[u], q), D.comb_m[u][t], q, qni), q)), q);
         }
-        lds[k] = csub((W)(csub(mont_mul_lazy(lds[k], scCt, q, qni), q) + (q - a)), q);   // every lane rewrites the words it read
+        return a;
+    };
+    // every lane rewrites the words it read: no barrier between the column pass above and this loop is needed beyond the one it ends with
+    if (vec) {
+        for (u32 k = threadIdx.x * VL; k < n; k += GEN_T * VL) {
+            V rin[MAXDROP], z = *reinterpret_cast<const V*>(lds + k);
+#pragma unroll
+            for (int u = 0; u < MAXDROP; ++u) if (u < ddn) rin[u] = *reinterpret_cast<const V*>(r0 + (size_t)u * n + k);
+#pragma unroll
+            for (u32 c = 0; c < VL; ++c) {
+                W y0[MAXDROP];
+#pragma unroll
+                for (int u = 0; u < MAXDROP; ++u) y0[u] = u < ddn ? rin[u][c] : (W)0;
+                z[c] = csub((W)(csub(mont_mul_lazy(z[c], scCt, q, qni), q) + (q - combine(y0))), q);
+            }
+            *reinterpret_cast<V*>(lds + k) = z;
+        }
+    } else {
+        for (u32 k = threadIdx.x; k < n; k += GEN_T) {
+            W y0[MAXDROP];
+#pragma unroll
+            for (int u = 0; u < MAXDROP; ++u) y0[u] = u < ddn ? r0[(size_t)u * n + k] : (W)0;
+            lds[k] = csub((W)(csub(mont_mul_lazy(lds[k], scCt, q, qni), q) + (q - combine(y0))), q);
+        }
     }
     lds_barrier();
     if (dec) gen_columns_lds<W, false, GEN_L>(lds, G, A, 0u);
@@ -879,7 +904,7 @@ inline hipError_t gen_launch_columns(const GenCall<W>& c, size_t lds_bytes) {
     hipError_t e = set_lds(k, lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(GEN_T), lds_bytes, c.stream, *c.ring, *c.gen, c.data, c.first_poly,
-                       c.elem_stride ? c.elem_stride : (size_t)1, c.fail_flag, c.skip_mask);
+                       c.elem_stride ? c.elem_stride : (size_t)1, c.fail_flag, c.skip_mask, c.src);
     return hipGetLastError();
 }
 
