@@ -305,7 +305,9 @@ template <typename W> struct GTab { const W* p[MAXL]; };     // per limb: CRT im
 
 template <typename W, int VW = 1>
 __global__ void k_tensor_ew(DevRing<W> R, const W* a, const W* b, W* out, W* c2buf, size_t nct, Scal<W> sr2, int dup,
-                            W* c2crt, GTab<W> gt) {
+                            W* c2crt, GTab<W> gt, int c2_compact = 0) {
+    // c2_compact: c2buf holds the L - dup limbs of the operands' ring only ([ct][L - dup][n]): the added limbs of c2 are zero and
+    // neither their crtInv nor their digits are ever computed
     // gt: general index -- SymmSHE's (*) applies mulG to every product coefficient (mulGCRT = pointwise product with the
     // CRT image of g); all-null for a two-power index, where g = 1
     // c2crt != null: a second copy of c2 that stays in the CRT basis (the diagonal digits of the key switch)
@@ -341,7 +343,8 @@ __global__ void k_tensor_ew(DevRing<W> R, const W* a, const W* b, W* out, W* c2b
         }
         *reinterpret_cast<P*>(out + 2 * ct * Ln + rem) = c0;
         *reinterpret_cast<P*>(out + (2 * ct + 1) * Ln + rem) = c1;
-        *reinterpret_cast<P*>(c2buf + ct * Ln + rem) = c2;
+        if (!c2_compact) *reinterpret_cast<P*>(c2buf + ct * Ln + rem) = c2;
+        else if (rem >= off) *reinterpret_cast<P*>(c2buf + ct * Lsn + (rem - off)) = c2;
         if (c2crt) *reinterpret_cast<P*>(c2crt + ct * Ln + rem) = c2;
     }
 }
@@ -384,7 +387,7 @@ __global__ void k_hint_mac(DevRing<W> R, W* out, const W* digits, const W* hint,
                 if (ct0 + c >= nct) continue;
                 const size_t ct = ct0 + c;
                 const W x = slot_e ? digits[((ct * (size_t)D + d) * R.L + limb) * (size_t)n_d + slot_e[wk.k]]
-                                   : (diag && d == limb) ? diag[ct * Ln + rem] : digits[(ct * (size_t)D + d) * Ln + rem];
+                                   : (diag && hd == limb) ? diag[ct * Ln + rem] : digits[(ct * (size_t)D + d) * Ln + rem];
                 acc0[c] = add_mod(acc0[c], mont_mul(x, h0, m), m.q);
                 acc1[c] = add_mod(acc1[c], mont_mul(x, h1, m), m.q);
             }
@@ -439,7 +442,7 @@ __global__ void k_hint_mac_v(DevRing<W> R, W* out, const W* digits, const W* hin
             const u32 hd = hskip ? d + (d / grp + 1) * hskip : d;
             const V h0 = *reinterpret_cast<const V*>(hint + (size_t)(2 * hd) * Ln + rem);
             const V h1 = *reinterpret_cast<const V*>(hint + (size_t)(2 * hd + 1) * Ln + rem);
-            const bool dg = diag && d == limb;
+            const bool dg = diag && hd == limb;
 #pragma unroll
             for (int c = 0; c < TILE; ++c) {
                 const size_t ct = ct0 + c < nct ? ct0 + c : ct0;
@@ -1952,6 +1955,8 @@ static int do_mul_full(alch_ring* rh, alch_ring* rin, alch_ring* rout, const alc
     return ALCH_OK;
 }
 
+template <typename W> static void gen_suffix_view(alch_ring* r, int u, DevRing<W>& d, GenDev<W>& g);
+
 // The same mul_ for rings whose polynomial does not fit one LDS-resident transform (split crt, n = 2^16 / 2^15):
 // composed from the element-wise kernels and batched transforms, one ciphertext chunk at a time.
 template <typename W>
@@ -2010,11 +2015,23 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
             }
         }
         if (!fused_ks) {
+        // general index below the hint's ring: the limbs the first modSwitch adds are zero in c2, so c2, its crtInv and its digits
+        // are kept on the operands' L - dup limbs only (a fifth to a half of the digit transforms of PT2CT's products)
+        const bool c2_compact = rh->gen && dup > 0;
+        const int Ls = L - dup;
         ALCH_LAUNCH_VW(k_tensor_ew, rh, words, rh->stream, dev_ring<W>(rh), pa, pb, (W*)ks,
-                           (W*)c2, now, sr2, dup, (W*)c2crt, gt);
+                           (W*)c2, now, sr2, dup, (W*)c2crt, gt, c2_compact ? 1 : 0);
         HIP_TRY(hipGetLastError());
         // keySwitchQuadCirc on ring_h
-        if ((rc = do_crt<W>(rh, c2, 0, now, true)) != ALCH_OK) return rc;
+        if (c2_compact) {
+            DevRing<W> dv; GenDev<W> gv;
+            gen_suffix_view<W>(rh, dup, dv, gv);
+            GenCall<W> g{};
+            g.op = GEN_CRTINV; g.ring = &dv; g.gen = &gv; g.stream = rh->stream;
+            g.data = reinterpret_cast<W*>(c2); g.first_poly = 0; g.npoly = now * (size_t)Ls;
+            hipError_t e = gen_dispatch(g);
+            if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("general-index crtInv launch: ") + hipGetErrorString(e));
+        } else if ((rc = do_crt<W>(rh, c2, 0, now, true)) != ALCH_OK) return rc;
         if (rh->gen) {
             GenCall<W> g{};
             g.op = GEN_CRT_DIGITS;
@@ -2023,8 +2040,9 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
             g.stream = rh->stream;
             g.src = reinterpret_cast<const W*>(c2);
             g.data = reinterpret_cast<W*>(dig);
-            g.npoly = now * (size_t)L * (size_t)L;
+            g.npoly = now * (size_t)(c2_compact ? Ls : L) * (size_t)L;
             g.balanced = rh->balanced;
+            if (c2_compact) { g.src_limbs = Ls; g.src_first = dup; }
             hipError_t e = gen_dispatch(g);
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("general-index crt_digits launch: ") + hipGetErrorString(e));
         } else if (rh->opts.split_fused) {   // digit transforms + hint products in one kernel (k_ks_accum_split)
@@ -2055,7 +2073,8 @@ static int do_mul_full_unfused(alch_ring* rh, alch_ring* rin, alch_ring* rout, c
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("crt_digits launch: ") + hipGetErrorString(e));
         }
         if (!split_done) {
-        launch_hint_mac<W>(rh, rh->stream, (W*)ks, (const W*)dig, (const W*)hint->dptr, now, (u32)L, (const W*)c2crt);
+        if (c2_compact) launch_hint_mac<W>(rh, rh->stream, (W*)ks, (const W*)dig, (const W*)hint->dptr, now, (u32)Ls, (const W*)c2crt, (u32)Ls, (u32)dup);
+        else launch_hint_mac<W>(rh, rh->stream, (W*)ks, (const W*)dig, (const W*)hint->dptr, now, (u32)L, (const W*)c2crt);
         HIP_TRY(hipGetLastError());
         }
         }
