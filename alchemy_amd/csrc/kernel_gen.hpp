@@ -28,6 +28,7 @@ namespace alch {
 
 constexpr int GEN_MAXPASS = 24;
 constexpr int GEN_MAXFACT = 8;
+constexpr int GEN_T_SMALL = 128;            // the transform kernels on rings of at most 18 KiB (gen_run)
 constexpr int GEN_T = 256;                  // threads per workgroup of every kernel in this file
 
 enum GenKind : int {
@@ -302,8 +303,8 @@ __device__ __forceinline__ void gen_transform(W* lds, const GenDev<W>& G, int j,
 // batched crt / crtInv: one workgroup per limb-polynomial
 // ------------------------------------------------------------------------------------------------------
 // (second launch bound: four waves per SIMD = at most 128 VGPRs, so that rings of up to 36 KiB run four workgroups per CU)
-template <typename W, bool INV>
-__global__ void __launch_bounds__(GEN_T, 4) k_gen_crt(DevRing<W> R, GenDev<W> G, W* data, const W* src, size_t first_poly) {
+template <typename W, bool INV, int NT = GEN_T>
+__global__ void __launch_bounds__(NT, 4) k_gen_crt(DevRing<W> R, GenDev<W> G, W* data, const W* src, size_t first_poly) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W* lds = reinterpret_cast<W*>(smem);
     const size_t p = first_poly + blockIdx.x;
@@ -315,13 +316,13 @@ __global__ void __launch_bounds__(GEN_T, 4) k_gen_crt(DevRing<W> R, GenDev<W> G,
     typedef typename Vec4<W>::type V;
     constexpr u32 VL = Vec4<W>::LANES;
     const bool vec = n % VL == 0;                 // then every limb-polynomial starts 16-byte aligned
-    if (vec) for (u32 i = threadIdx.x * VL; i < n; i += GEN_T * VL) *reinterpret_cast<V*>(lds + i) = *reinterpret_cast<const V*>(in + i);
-    else for (u32 i = threadIdx.x; i < n; i += GEN_T) lds[i] = in[i];
+    if (vec) for (u32 i = threadIdx.x * VL; i < n; i += NT * VL) *reinterpret_cast<V*>(lds + i) = *reinterpret_cast<const V*>(in + i);
+    else for (u32 i = threadIdx.x; i < n; i += NT) lds[i] = in[i];
     lds_barrier();
-    gen_transform<W, INV>(lds, G, j, q, qni);
+    gen_transform<W, INV, NT>(lds, G, j, q, qni);
     const W sc = G.iscale_m[j];
     if (vec) {
-        for (u32 i = threadIdx.x * VL; i < n; i += GEN_T * VL) {
+        for (u32 i = threadIdx.x * VL; i < n; i += NT * VL) {
             V v = *reinterpret_cast<const V*>(lds + i);
             if (INV) {
 #pragma unroll
@@ -330,17 +331,17 @@ __global__ void __launch_bounds__(GEN_T, 4) k_gen_crt(DevRing<W> R, GenDev<W> G,
             *reinterpret_cast<V*>(poly + i) = v;
         }
     } else if (INV) {
-        for (u32 i = threadIdx.x; i < n; i += GEN_T) poly[i] = csub(mont_mul_lazy(lds[i], sc, q, qni), q);
+        for (u32 i = threadIdx.x; i < n; i += NT) poly[i] = csub(mont_mul_lazy(lds[i], sc, q, qni), q);
     } else {
-        for (u32 i = threadIdx.x; i < n; i += GEN_T) poly[i] = lds[i];
+        for (u32 i = threadIdx.x; i < n; i += NT) poly[i] = lds[i];
     }
 }
 
 // crt of the reduced TrivGad digits with decompose + reduce in the loader (keySwitchQuadCirc, Eval.hs:133):
 // workgroup = (ciphertext, source limb i, target limb j); the diagonal i == j is skipped (that digit is c2's own
 // limb j, which the caller kept in the CRT basis).
-template <typename W>
-__global__ void __launch_bounds__(GEN_T) k_gen_crt_digits(DevRing<W> R, GenDev<W> G, const W* __restrict__ c2pow, W* __restrict__ digits, int balanced, int with_diag,
+template <typename W, int NT = GEN_T>
+__global__ void __launch_bounds__(NT) k_gen_crt_digits(DevRing<W> R, GenDev<W> G, const W* __restrict__ c2pow, W* __restrict__ digits, int balanced, int with_diag,
                  int Ls, int sfirst) {
     // Ls, sfirst: the source elements hold the limbs sfirst .. sfirst + Ls - 1 only (tunnel behind a modSwitch up: the added
     // limbs are zero and so are their digits); digits: [element][Ls][L][n].  Key switch: Ls = L, sfirst = 0.
@@ -366,19 +367,19 @@ __global__ void __launch_bounds__(GEN_T) k_gen_crt_digits(DevRing<W> R, GenDev<W
         return (W)r;
     };
     if (n % VL == 0) {
-        for (u32 k = threadIdx.x * VL; k < n; k += GEN_T * VL) {
+        for (u32 k = threadIdx.x * VL; k < n; k += NT * VL) {
             V v = *reinterpret_cast<const V*>(src + k);
 #pragma unroll
             for (u32 c = 0; c < VL; ++c) v[c] = digit(v[c]);
             *reinterpret_cast<V*>(lds + k) = v;
         }
     } else {
-        for (u32 k = threadIdx.x; k < n; k += GEN_T) lds[k] = digit(src[k]);
+        for (u32 k = threadIdx.x; k < n; k += NT) lds[k] = digit(src[k]);
     }
     lds_barrier();
-    gen_transform<W, false>(lds, G, j, q, qni);
-    if (n % VL == 0) for (u32 k = threadIdx.x * VL; k < n; k += GEN_T * VL) *reinterpret_cast<V*>(dst + k) = *reinterpret_cast<const V*>(lds + k);
-    else for (u32 k = threadIdx.x; k < n; k += GEN_T) dst[k] = lds[k];
+    gen_transform<W, false, NT>(lds, G, j, q, qni);
+    if (n % VL == 0) for (u32 k = threadIdx.x * VL; k < n; k += NT * VL) *reinterpret_cast<V*>(dst + k) = *reinterpret_cast<const V*>(lds + k);
+    else for (u32 k = threadIdx.x; k < n; k += NT) dst[k] = lds[k];
 }
 
 // crt of the reduced BaseBGad 2 digits with decompose + reduce in the loader (tunnels with the gadget of examples/Tunnel.hs:24):
@@ -386,8 +387,8 @@ __global__ void __launch_bounds__(GEN_T) k_gen_crt_digits(DevRing<W> R, GenDev<W
 // binary digits have the closed form  d_t = -((u >> t) & 1)  for t < k - 1 and the top digit is  -(u >> (k - 1))  (arithmetic
 // shifts), so no digit depends on the ones below it and the digits never exist in HBM untransformed (k_crt_base2_digits is the
 // two-power form).  digits: [element][D][L][n].
-template <typename W>
-__global__ void __launch_bounds__(GEN_T) k_gen_crt_base2_digits(DevRing<W> R, GenDev<W> G, const W* __restrict__ xpow, W* __restrict__ digits,
+template <typename W, int NT = GEN_T>
+__global__ void __launch_bounds__(NT) k_gen_crt_base2_digits(DevRing<W> R, GenDev<W> G, const W* __restrict__ xpow, W* __restrict__ digits,
                                                                 Scal<u32> first_digit, Scal<u32> kd, u32 D) {
     typedef typename Signed<W>::type SW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -405,7 +406,7 @@ __global__ void __launch_bounds__(GEN_T) k_gen_crt_base2_digits(DevRing<W> R, Ge
     const W* src = xpow + (el * (size_t)L + i) * (size_t)n;
     W* dst = digits + p * (size_t)n;
     const W q = R.mod[j].q, qni = R.mod[j].qni, qi = R.mod[i].q, hqi = (qi - 1) >> 1;
-    for (u32 k = threadIdx.x; k < n; k += GEN_T) {
+    for (u32 k = threadIdx.x; k < n; k += NT) {
         const W v = src[k];
         const SW z = v > hqi ? (SW)v - (SW)qi : (SW)v;
         const SW u = -z;
@@ -414,11 +415,11 @@ __global__ void __launch_bounds__(GEN_T) k_gen_crt_base2_digits(DevRing<W> R, Ge
         lds[k] = dg < 0 ? (W)(dg + (SW)q) : (W)dg;
     }
     lds_barrier();
-    gen_transform<W, false>(lds, G, j, q, qni);
+    gen_transform<W, false, NT>(lds, G, j, q, qni);
     typedef typename Vec4<W>::type V;
     constexpr u32 VL = Vec4<W>::LANES;
-    if (n % VL == 0) for (u32 k = threadIdx.x * VL; k < n; k += GEN_T * VL) *reinterpret_cast<V*>(dst + k) = *reinterpret_cast<const V*>(lds + k);
-    else for (u32 k = threadIdx.x; k < n; k += GEN_T) dst[k] = lds[k];
+    if (n % VL == 0) for (u32 k = threadIdx.x * VL; k < n; k += NT * VL) *reinterpret_cast<V*>(dst + k) = *reinterpret_cast<const V*>(lds + k);
+    else for (u32 k = threadIdx.x; k < n; k += NT) dst[k] = lds[k];
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -911,30 +912,34 @@ inline hipError_t gen_launch_columns(const GenCall<W>& c, size_t lds_bytes) {
 template <typename W>
 inline hipError_t gen_run(const GenCall<W>& c) {
     const size_t lds_bytes = (size_t)c.gen->n * sizeof(W);
+    // small rings (<= 18 KiB of LDS: E' of the reference's hops, H0') run 2-wave workgroups, eight to a CU: measured on H0' (phi = 4608)
+    // 18.6 against 20.7 ns per limb-polynomial; from phi = 5760 on the 4-wave form is faster (34 against 37 ns)
+    const bool small = (size_t)c.gen->n * sizeof(W) <= 18432;
+    const unsigned nt = small ? GEN_T_SMALL : GEN_T;
     hipError_t e;
     switch (c.op) {
     case GEN_CRT: {
-        auto k = k_gen_crt<W, false>;
+        auto k = small ? k_gen_crt<W, false, GEN_T_SMALL> : k_gen_crt<W, false, GEN_T>;
         if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(GEN_T), lds_bytes, c.stream, *c.ring, *c.gen, c.data, c.src, c.first_poly);
+        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(nt), lds_bytes, c.stream, *c.ring, *c.gen, c.data, c.src, c.first_poly);
         break;
     }
     case GEN_CRTINV: {
-        auto k = k_gen_crt<W, true>;
+        auto k = small ? k_gen_crt<W, true, GEN_T_SMALL> : k_gen_crt<W, true, GEN_T>;
         if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(GEN_T), lds_bytes, c.stream, *c.ring, *c.gen, c.data, c.src, c.first_poly);
+        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(nt), lds_bytes, c.stream, *c.ring, *c.gen, c.data, c.src, c.first_poly);
         break;
     }
     case GEN_CRT_BASE2: {
-        auto k = k_gen_crt_base2_digits<W>;
+        auto k = small ? k_gen_crt_base2_digits<W, GEN_T_SMALL> : k_gen_crt_base2_digits<W, GEN_T>;
         if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(GEN_T), lds_bytes, c.stream, *c.ring, *c.gen, c.src, c.data, c.b2_first, c.b2_kd, c.b2_D);
+        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(nt), lds_bytes, c.stream, *c.ring, *c.gen, c.src, c.data, c.b2_first, c.b2_kd, c.b2_D);
         break;
     }
     case GEN_CRT_DIGITS: {
-        auto k = k_gen_crt_digits<W>;
+        auto k = small ? k_gen_crt_digits<W, GEN_T_SMALL> : k_gen_crt_digits<W, GEN_T>;
         if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(GEN_T), lds_bytes, c.stream, *c.ring, *c.gen, c.src, c.data, c.balanced ? 1 : 0, c.with_diag ? 1 : 0,
+        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(nt), lds_bytes, c.stream, *c.ring, *c.gen, c.src, c.data, c.balanced ? 1 : 0, c.with_diag ? 1 : 0,
                            c.src_limbs ? c.src_limbs : c.ring->L, c.src_first);
         break;
     }
