@@ -30,6 +30,8 @@ SYMBOLS = [
     "alch_ring_set_option", "alch_ring_create_nocrt", "alch_l", "alch_linv", "alch_buf_l", "alch_buf_linv", "alch_buf_mulg",
     "alch_buf_divg", "alch_buf_mul_public", "alch_buf_add_public", "alch_select_limbs", "alch_modulus_units",
     "alch_tunnel_info", "alch_tunnel_create", "alch_tunnel_free", "alch_ct_tunnel", "alch_ct_mod_switch",
+    "alch_buf_embed", "alch_buf_twace", "alch_buf_coeffs", "alch_embed_pow", "alch_embed_dec", "alch_embed_crt",
+    "alch_twace_pow_dec", "alch_twace_crt", "alch_coeffs", "alch_ext_table", "alch_crt_set_dec",
 ]
 
 
@@ -136,6 +138,12 @@ def load_library():
         "alch_buf_sub": [VP, VP, VP, C.c_size_t],
         "alch_buf_scale": [VP, VP, C.c_size_t, PU64],
         "alch_buf_decompose_triv": [VP, C.c_size_t, VP, C.c_size_t],
+        "alch_buf_embed": [VP, VP, C.c_size_t, C.c_int], "alch_buf_twace": [VP, VP, C.c_size_t, C.c_int],
+        "alch_buf_coeffs": [VP, VP, C.c_size_t],
+        "alch_embed_pow": [VP, VP, P64, P64], "alch_embed_dec": [VP, VP, P64, P64], "alch_embed_crt": [VP, VP, P64, P64],
+        "alch_twace_pow_dec": [VP, VP, P64, P64], "alch_twace_crt": [VP, VP, P64, P64], "alch_coeffs": [VP, VP, P64, P64],
+        "alch_ext_table": [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)],
+        "alch_crt_set_dec": [C.c_uint32, C.c_uint32, C.c_uint32, P64, C.POINTER(C.c_size_t)],
     }
     for name, args in sig.items():
         fn = getattr(l, name)
@@ -177,6 +185,27 @@ def host_root(m: int, q: int):
     psi, g = C.c_uint64(), C.c_uint64()
     _check(load_library().alch_host_root(m, q, C.byref(psi), C.byref(g)))
     return int(psi.value), int(g.value)
+
+
+ALCH_EXT_POW_POS, ALCH_EXT_COEFFS, ALCH_EXT_CRT_SLOT = 0, 1, 2
+
+
+def ext_table(m_small: int, m_big: int, which: int) -> np.ndarray:
+    """Host-only index table of the Tensor methods between two indices (alch_ext_table); needs no GPU."""
+    n = C.c_size_t(0)
+    _check(load_library().alch_ext_table(m_small, m_big, which, None, C.byref(n)))
+    out = np.zeros(n.value, dtype=np.int32)
+    _check(load_library().alch_ext_table(m_small, m_big, which, out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n)))
+    return out
+
+
+def crt_set_dec(m_small: int, m_big: int, p: int, n_big: int) -> np.ndarray:
+    """Tensor crtSetDec (host-only): array (count, n_big) of residues mod p on the decoding basis of index m_big."""
+    c = C.c_size_t(0)
+    _check(load_library().alch_crt_set_dec(m_small, m_big, p, None, C.byref(c)))
+    out = np.zeros((c.value, n_big), dtype=np.int64)
+    _check(load_library().alch_crt_set_dec(m_small, m_big, p, _p64(out), C.byref(c)))
+    return out
 
 
 class Ring:
@@ -277,6 +306,20 @@ class Ring:
         out = np.zeros((nd.value, self.n, self.L), dtype=np.int64)
         _check(self._l.alch_decompose_base2(self._h, _p64(c), _p64(out), C.byref(nd)))
         return [out[i] for i in range(nd.value)]
+
+    # --- Tensor methods towards a ring of a multiple index (self = the small ring), host buffers
+    def _ext(self, fn, big: "Ring", a, out_shape):
+        a = np.ascontiguousarray(a, dtype=np.int64)
+        out = np.zeros(out_shape, dtype=np.int64)
+        _check(fn(self._h, big._h, _p64(a), _p64(out)))
+        return out
+
+    def embed_pow(self, big, a): return self._ext(self._l.alch_embed_pow, big, a, (big.n, big.L))
+    def embed_dec(self, big, a): return self._ext(self._l.alch_embed_dec, big, a, (big.n, big.L))
+    def embed_crt(self, big, a): return self._ext(self._l.alch_embed_crt, big, a, (big.n, big.L))
+    def twace_pow_dec(self, big, a): return self._ext(self._l.alch_twace_pow_dec, big, a, (self.n, self.L))
+    def twace_crt(self, big, a): return self._ext(self._l.alch_twace_crt, big, a, (self.n, self.L))
+    def coeffs(self, big, a): return self._ext(self._l.alch_coeffs, big, a, (big.n // self.n, self.n, self.L))
 
     # --- device-resident
     def alloc(self, n_elems: int) -> "Buf":
@@ -444,6 +487,15 @@ class Buf:
 
     def add_public(self, pub: "Buf", pub_index: int, batch: int):
         _check(self.ring._l.alch_buf_add_public(self._h, pub._h, pub_index, batch))
+
+    def embed_from(self, src_small: "Buf", count: int, basis: int):
+        _check(self.ring._l.alch_buf_embed(self._h, src_small._h, count, basis))
+
+    def twace_from(self, src_big: "Buf", count: int, basis: int):
+        _check(self.ring._l.alch_buf_twace(self._h, src_big._h, count, basis))
+
+    def coeffs_from(self, src_big: "Buf", count: int):
+        _check(self.ring._l.alch_buf_coeffs(self._h, src_big._h, count))
 
     def checksum(self, first: int = 0, count: int | None = None) -> int:
         s = C.c_uint64()

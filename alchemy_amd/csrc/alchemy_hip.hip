@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -21,6 +22,15 @@ using namespace alch;
 // ------------------------------------------------------------------------------------------------------
 // handles
 // ------------------------------------------------------------------------------------------------------
+// Device tables of the Tensor methods between two indices m | m' (tensor_ext.inc.hpp), cached in the bigger ring.
+struct ExtTab {
+    u32 d_rel = 0, fibre = 0;
+    int32_t* pow_gather = nullptr;     // [n_big]: source position in the small ring, or -1 (embedPow)
+    int32_t* coeffs = nullptr;         // [d_rel][n_small]: source position in the big ring (coeffs; row 0 = twacePowDec)
+    int32_t* slot_small = nullptr;     // [n_big]: CRT slot of the small ring (embedCRT)
+    int32_t* fibres = nullptr;         // [n_small][fibre]: CRT slots of the big ring above a slot of the small ring (twaceCRT)
+};
+
 struct alch_ring {
     u32 m = 0, n = 0;
     int logn = 0, L = 0, word = 0;            // word = 4 or 8 bytes per residue on the device
@@ -62,6 +72,7 @@ struct alch_ring {
     GenDev<u64> g64;
     void* gen_tables = nullptr;
     int* d_flag = nullptr;                     // divG failure flag
+    std::deque<std::pair<u32, ExtTab>> ext;    // extension tables towards sub-rings of index .first (same moduli)
 };
 
 struct alch_buf {
@@ -928,6 +939,12 @@ extern "C" int alch_ring_destroy(alch_ring* r) {
     if (r->tables) (void)hipFree(r->tables);
     if (r->gen_tables) (void)hipFree(r->gen_tables);
     if (r->d_flag) (void)hipFree(r->d_flag);
+    for (auto& e : r->ext) {
+        if (e.second.pow_gather) (void)hipFree(e.second.pow_gather);
+        if (e.second.coeffs) (void)hipFree(e.second.coeffs);
+        if (e.second.slot_small) (void)hipFree(e.second.slot_small);
+        if (e.second.fibres) (void)hipFree(e.second.fibres);
+    }
     if (r->tables_p) (void)hipFree(r->tables_p);
     if (r->ws_digits) (void)hipFree(r->ws_digits);
     if (r->ws_in) (void)hipFree(r->ws_in);
@@ -2582,3 +2599,5 @@ extern "C" int alch_buf_rescale_add0(const alch_buf* src, alch_buf* dst, size_t 
     HIP_TRY(hipStreamSynchronize(rd->stream));
     return ALCH_OK;
 }
+
+#include "tensor_ext.inc.hpp"

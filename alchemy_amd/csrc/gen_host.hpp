@@ -28,8 +28,8 @@ inline u32 h_digitrev(u32 x, u32 p, int digits) {
     return r;
 }
 
-// Factor m and lay out the passes.  Returns false (with g.error) for an index this backend does not serve.
-inline bool gen_plan(u32 m, GenHost& g) {
+// Factor m: prime powers ascending, per-axis dimension and stride of the mixed-radix index (first factor outermost), odd radical.
+inline bool gen_factor(u32 m, GenHost& g) {
     g = GenHost();
     g.m = m;
     u32 rem = m;
@@ -48,15 +48,23 @@ inline bool gen_plan(u32 m, GenHost& g) {
     u64 n = 1;
     for (int l = 0; l < g.nfact; ++l) {
         GenFact& f = g.fact[l];
-        if (f.p > 13) { g.error = "odd prime factors of the index must be <= 13 (the reference's indices use 3, 5, 7, 13)"; return false; }
         if (f.p != 2) g.rad *= (u32)f.p;
         f.dim = (u32)(f.p - 1) * f.mp;
         n *= f.dim;
     }
-    if (n > 65535) { g.error = "ring dimension too large (the pass engine indexes with 16-bit quantities)"; return false; }
+    if (n > 0x7fffffffull) { g.error = "ring dimension too large"; return false; }
     g.n = (u32)n;
     u32 s = g.n;
     for (int l = 0; l < g.nfact; ++l) { s /= g.fact[l].dim; g.fact[l].rts = s; }
+    return true;
+}
+
+// Factor m and lay out the passes.  Returns false (with g.error) for an index this backend does not serve.
+inline bool gen_plan(u32 m, GenHost& g) {
+    if (!gen_factor(m, g)) return false;
+    for (int l = 0; l < g.nfact; ++l)
+        if (g.fact[l].p > 13) { g.error = "odd prime factors of the index must be <= 13 (the reference's indices use 3, 5, 7, 13)"; return false; }
+    if (g.n > 65535) { g.error = "ring dimension too large (the pass engine indexes with 16-bit quantities)"; return false; }
     u32 off = 0;
     auto rcp = [](u32 d) { return d <= 1 ? 0u : (u32)(((u64)1 << 32) / d) + 1u; };
     // mat_words: size of the pass's own table; tw_off: 0xffffffff = no twiddles, 0xfffffffe = allocate f.dim words, else shared
@@ -270,6 +278,63 @@ inline bool gen_tunnel_table(const GenHost& ep, const GenHost& rp, const GenHost
             table[(size_t)i * sp.n + poss] = (int32_t)posr;
             if (table_e) (*table_e)[(size_t)i * ep.n + j] = (int32_t)posr;
         }
+    }
+    return true;
+}
+
+// Index tables of the Tensor methods between two indices m | m' (Lol: embedPow / embedDec / twacePowDec / coeffs / powBasisPow and
+// crtExtFuncs = (twaceCRT, embedCRT)).  small = index m, big = index m'.
+//   pow_pos[j]   (n_small)          position in the big ring's Pow (or Dec, for twace / coeffs) vector of the small ring's basis element j
+//                                   (oracle/model_gen.py embed_indices)
+//   coeffs[i][j] ([d_rel][n_small]) position in the big ring of coefficient j of the i-th E-coefficient w.r.t. the relative
+//                                   powerful / decoding basis (coeffs_indices; relative indices mixed radix, first prime outermost);
+//                                   coeffs[0] == pow_pos
+//   slot_small[s] (n_big)           CRT slot of the small ring whose unit is the reduction mod m of the unit of the big ring's slot s:
+//                                   crt_big(embed x)[s] = crt_small(x)[slot_small[s]]   (embedCRT), and twaceCRT sums over the fibres
+//                                   {s : slot_small[s] = t}.  With the slot rule of include/alchemy_hip.h reducing a unit mod p^es keeps
+//                                   i0 and the low digits of i1 = the HIGH digits of the reversed index: the factor's slot index is
+//                                   divided by p^(eb - es); a prime that does not divide m drops out.
+inline bool gen_ext_tables(const GenHost& sm, const GenHost& bg, u32& d_rel, std::vector<int32_t>& pow_pos, std::vector<int32_t>& coeffs,
+                           std::vector<u32>& slot_small) {
+    if (sm.m == 0 || bg.m % sm.m) return false;
+    auto expo = [](const GenHost& g, int p) { for (int l = 0; l < g.nfact; ++l) if (g.fact[l].p == p) return g.fact[l].e; return 0; };
+    auto ipow = [](u32 b, int e) { u32 r = 1; while (e-- > 0) r *= b; return r; };
+    auto comp = [](const GenHost& g, int p, u32 lin) -> u32 {            // index of the factor with prime p inside the linear index
+        for (int l = 0; l < g.nfact; ++l) if (g.fact[l].p == p) return (lin / g.fact[l].rts) % g.fact[l].dim;
+        return 0;
+    };
+    u32 rel_dim[GEN_MAXFACT];
+    d_rel = 1;
+    for (int l = 0; l < bg.nfact; ++l) {
+        const int p = bg.fact[l].p, es = expo(sm, p);
+        rel_dim[l] = es ? ipow((u32)p, bg.fact[l].e - es) : bg.fact[l].dim;
+        d_rel *= rel_dim[l];
+    }
+    if ((u64)d_rel * sm.n != bg.n) return false;
+    coeffs.assign((size_t)d_rel * sm.n, -1);
+    for (u32 i = 0; i < d_rel; ++i) {
+        u32 rel[GEN_MAXFACT], t = i;
+        for (int l = bg.nfact - 1; l >= 0; --l) { rel[l] = t % rel_dim[l]; t /= rel_dim[l]; }
+        for (u32 j = 0; j < sm.n; ++j) {
+            u32 pos = 0;
+            for (int l = 0; l < bg.nfact; ++l) {
+                const int p = bg.fact[l].p, es = expo(sm, p);
+                pos += (es ? rel[l] + ipow((u32)p, bg.fact[l].e - es) * comp(sm, p, j) : rel[l]) * bg.fact[l].rts;
+            }
+            coeffs[(size_t)i * sm.n + j] = (int32_t)pos;
+        }
+    }
+    pow_pos.assign(coeffs.begin(), coeffs.begin() + sm.n);
+    slot_small.assign(bg.n, 0);
+    for (u32 s = 0; s < bg.n; ++s) {
+        u32 t = 0;
+        for (int l = 0; l < bg.nfact; ++l) {
+            const int p = bg.fact[l].p, es = expo(sm, p);
+            if (!es) continue;
+            const u32 sf = (s / bg.fact[l].rts) % bg.fact[l].dim;
+            for (int ls = 0; ls < sm.nfact; ++ls) if (sm.fact[ls].p == p) t += (sf / ipow((u32)p, bg.fact[l].e - es)) * sm.fact[ls].rts;
+        }
+        slot_small[s] = t;
     }
     return true;
 }

@@ -19,17 +19,28 @@
 -- foreign symbol used exists in @GT/Backend.hs@ with the header's signature).  The same call sequence, compiled
 -- and tested, is @alchemy_amd/host/symmshe.hpp@ (C++).
 --
--- Design.  @GT m r@ is a newtype over lol-cpp's @CT m r@: every method that is not on ALCHEMY's hot path is
--- lol-cpp's, reached by 'coerce'.  The hot methods -- @crt@, @crtInv@, @mulG*@, @divG*@, @l@, @lInv@ and
--- @zipWithT@ for @(*)@ / @(+)@ (reference call sites: @(*)@ on @CT@, @modSwitch@, @keySwitchQuadCirc@,
--- Crypto/Alchemy/Interpreter/Eval.hs:65-67,130,133) -- cross into the library whenever the element type is a
--- (nested pair of) @ZqBasic q Int64@, any cyclotomic index; other element types (@Double@, @Complex Double@,
--- @Int64@, @RRq@) stay on lol-cpp.
+-- Design.  @GT m r@ is a newtype over lol-cpp's @CT m r@ (same storable vector).  Whenever the element type is a (nested pair
+-- of) @ZqBasic q Int64@ -- any cyclotomic index -- EVERY method whose result depends on the order of a basis crosses into the
+-- library: @crt@, @crtInv@, @mulGCRT@, @divGCRT@ (@crtFuncs@), @twaceCRT@, @embedCRT@ (@crtExtFuncs@), and, so that the relative
+-- bases agree with them, @twacePowDec@, @embedPow@, @embedDec@, @coeffs@, @powBasisPow@, @crtSetDec@, plus @mulGPow/Dec@,
+-- @divGPow/Dec@, @l@, @lInv@.  The CRT slot order of an instance is internal to it (only @crtInv . crt = id@ and the ring
+-- homomorphism are observable), but it must be ONE order: the instance is sound because none of these methods is delegated to
+-- lol-cpp for such element types (@tests/test_haskell_shim.py@ enforces it; the identities @crt . embedPow = embedCRT . crt@ and
+-- @crt . twacePowDec = twaceCRT . crt@ are GPU tests, @tests/test_tensor_ext.py@).  Order-free methods (@scalarPow@,
+-- @tGaussianDec@, @gSqNormDec@, @fmapT@, @zipWithT@, @unzipT@, the entailments) and all other element types (@Double@,
+-- @Complex Double@, @Int64@, @RRq@; for those the whole instance is lol-cpp's, consistently) stay on lol-cpp under 'coerce'.
+--
+-- Pointwise ring operations: Lol's @UCyc@ multiplies CRT-basis elements with @zipWithT (*)@, a higher-order method -- an arbitrary
+-- function cannot be shipped to the GPU, and GHC rewrite rules on class methods do not fire at Lol's polymorphic call sites, so
+-- @zipWithT@ (and with it the per-element @(*)@ / @(+)@ of @Cyc@) runs on lol-cpp.  That is correct in any slot order (pointwise)
+-- and is not the fast path: the fast path are the batched entry points at the end of this module ('mulRelinGT', 'mulFullGT',
+-- 'tunnelGT', 'modSwitchGT'), which take device-resident buffers; 'mulGT' / 'addGT' / 'subGT' are exported for callers that hold
+-- @GT@ values and want the product on the device explicitly.
 --
 -- Use: @import Crypto.Lol.Cyclotomic.Tensor.GT@ instead of @...Tensor.CPP@ and write @GT@ for @CT@ in the
 -- plaintext alias (reference examples/Arithmetic.hs:19,23; @haskell/examples/Arithmetic-GT.patch@).  Nothing in
 -- @Crypto.Alchemy.*@ changes.
-module Crypto.Lol.Cyclotomic.Tensor.GT ( GT, GTDispatch(..), mulRelinGT, mulFullGT, tunnelGT, modSwitchGT ) where
+module Crypto.Lol.Cyclotomic.Tensor.GT ( GT, GTDispatch(..), mulGT, addGT, subGT, mulRelinGT, mulFullGT, tunnelGT, modSwitchGT ) where
 
 import Control.Monad                          (when)
 import Data.Coerce                            (coerce)
@@ -140,7 +151,7 @@ onDevice t dev host = maybe host dev (powRing (Just t))
 instance Tensor GT where
   type TElt GT r = (TElt CT r, GTDispatch r, SV.Storable r)
 
-  -- ---- hot subset: crosses into the library ------------------------------------------------------------
+  -- ---- every basis-order-dependent method: crosses into the library ------------------------------------------------------------
   l       t = onDevice t (\ring -> inPlace "l"       c_l       ring t) (coerce (l       :: CT m r -> CT m r) t)
   lInv    t = onDevice t (\ring -> inPlace "lInv"    c_lInv    ring t) (coerce (lInv    :: CT m r -> CT m r) t)
   mulGPow t = onDevice t (\ring -> inPlace "mulGPow" c_mulGPow ring t) (coerce (mulGPow :: CT m r -> CT m r) t)
@@ -148,21 +159,27 @@ instance Tensor GT where
   divGPow t = onDevice t (\ring -> inPlaceMaybe "divGPow" c_divGPow ring t) (coerce (divGPow :: CT m r -> Maybe (CT m r)) t)
   divGDec t = onDevice t (\ring -> inPlaceMaybe "divGDec" c_divGDec ring t) (coerce (divGDec :: CT m r -> Maybe (CT m r)) t)
   crtFuncs = crtFuncsGT
-  -- (*) / (+) / (-) on ring elements reach the device through the rewrite rules at the end of this file;
-  -- an arbitrary function cannot be shipped to the GPU
+  crtExtFuncs = crtExtFuncsGT
+  -- relative bases of an extension m | m': the same index rule as the CRT-slot maps above (include/alchemy_hip.h)
+  twacePowDec t = between2 t (\sm bg -> outOfPlace "twacePowDec" c_twacePowDec sm bg (totOf (Proxy :: Proxy m)) t)
+                             (coerce (twacePowDec :: CT m' r -> CT m r) t)
+  embedPow    t = between2' t (\sm bg -> outOfPlace "embedPow" c_embedPow sm bg (totOf (Proxy :: Proxy m')) t)
+                              (coerce (embedPow :: CT m r -> CT m' r) t)
+  embedDec    t = between2' t (\sm bg -> outOfPlace "embedDec" c_embedDec sm bg (totOf (Proxy :: Proxy m')) t)
+                              (coerce (embedDec :: CT m r -> CT m' r) t)
+  coeffs      t = between2 t (\sm bg -> let n = totOf (Proxy :: Proxy m); d = totOf (Proxy :: Proxy m') `div` n
+                                             v = toVector (outOfPlace "coeffs" c_coeffs sm bg (d * n) t :: GT m r)
+                                         in [ fromVector (SV.slice (i * n) n v) | i <- [0 .. d - 1] ])
+                             (map GT (coeffs (coerce t :: CT m' r)))
+  powBasisPow   = powBasisPowGT
+  crtSetDec     = crtSetDecGT
+  -- zipWithT takes an arbitrary function: it cannot be shipped to the GPU (see the module header)
   zipWithT f a b = coerce (zipWithT f (coerce a :: CT m a') (coerce b :: CT m b'))
 
-  -- ---- off the hot path (SURVEY 8b): lol-cpp's implementation under the newtype ---------------------------
+  -- ---- order-free methods: lol-cpp's implementation under the newtype -------------------------------------
   scalarPow     = coerce (scalarPow   :: r -> CT m r)
   tGaussianDec  = fmap GT . tGaussianDec
   gSqNormDec    = gSqNormDec . (coerce :: GT m r -> CT m r)
-  twacePowDec   = coerce (twacePowDec :: CT m' r -> CT m r)
-  embedPow      = coerce (embedPow    :: CT m r -> CT m' r)
-  embedDec      = coerce (embedDec    :: CT m r -> CT m' r)
-  crtExtFuncs   = (\(tw, em) -> (coerce tw, coerce em)) <$> (crtExtFuncs :: mon (CT m' r -> CT m r, CT m r -> CT m' r))
-  coeffs        = map GT . coeffs . (coerce :: GT m' r -> CT m' r)
-  powBasisPow   = fmap (map GT) powBasisPow
-  crtSetDec     = fmap (map GT) crtSetDec
   fmapT f       = GT . fmapT f . (coerce :: GT m a -> CT m a)
   unzipT        = (\(a, b) -> (GT a, GT b)) . unzipT . (coerce :: GT m (a, b) -> CT m (a, b))
   entailIndexT  = tag $ Sub Dict
@@ -172,6 +189,82 @@ instance Tensor GT where
   entailRandomT = tag $ Sub Dict
   entailShowT   = tag $ Sub Dict
   entailModuleT = tag $ Sub Dict
+
+-- | phi(m) as an Int.
+totOf :: forall m proxy . Fact m => proxy m -> Int
+totOf _ = proxy totientFact (Proxy :: Proxy m)
+
+-- | Both Pow / Dec rings of an extension m | m' over @r@ (small, big), or @Nothing@ when @r@ stays on lol-cpp.
+extRings :: forall m m' r . (Fact m, Fact m', GTDispatch r) => Proxy m -> Proxy m' -> Proxy r -> Maybe (Ptr AlchRing, Ptr AlchRing)
+extRings _ _ _ = (,) <$> powRing (Proxy :: Proxy (GT m r)) <*> powRing (Proxy :: Proxy (GT m' r))
+
+-- | Dispatch of a method @GT m' r -> a@ (big to small) / @GT m r -> a@ (small to big) on the two rings of the extension.
+between2 :: forall m m' r a . (m `Divides` m', GTDispatch r) => GT m' r -> (Ptr AlchRing -> Ptr AlchRing -> a) -> a -> a
+between2 _ dev host = maybe host (uncurry dev) (extRings (Proxy :: Proxy m) (Proxy :: Proxy m') (Proxy :: Proxy r))
+
+between2' :: forall m m' r a . (m `Divides` m', GTDispatch r) => GT m r -> (Ptr AlchRing -> Ptr AlchRing -> a) -> a -> a
+between2' _ dev host = maybe host (uncurry dev) (extRings (Proxy :: Proxy m) (Proxy :: Proxy m') (Proxy :: Proxy r))
+
+-- | Out-of-place call between the two rings of an extension: the callee reads the input vector and fills a fresh vector of
+-- @len@ ring-element words (nothing is retained; lol-cpp's discipline).
+outOfPlace :: (SV.Storable r) => String -> (Ptr AlchRing -> Ptr AlchRing -> Ptr Int64 -> Ptr Int64 -> IO CInt)
+           -> Ptr AlchRing -> Ptr AlchRing -> Int -> GT i r -> GT o r
+outOfPlace what f small big len t = unsafePerformIO $ do
+  out <- SM.new len
+  SV.unsafeWith (toVector t) $ \pin -> SM.unsafeWith out $ \pout -> f small big (castPtr pin) (castPtr pout) >>= check what
+  fromVector <$> SV.unsafeFreeze out
+
+-- | @crtExtFuncs@ = (twaceCRT, embedCRT).  On the device exactly when 'crtFuncsGT' is (moduli present and every q = 1 mod m'):
+-- both act on CRT slots and must follow the slot order of @crt@ / @crtInv@, so they are never lol-cpp's for such element types.
+crtExtFuncsGT :: forall mon m m' r . (m `Divides` m', CRTrans mon r, TElt GT r) => mon (GT m' r -> GT m r, GT m r -> GT m' r)
+crtExtFuncsGT =
+  let m     = fromIntegral (proxy valueFact (Proxy :: Proxy m))  :: Word32
+      m'    = fromIntegral (proxy valueFact (Proxy :: Proxy m')) :: Word32
+      rings = unsafePerformIO $ case gtModuli (Proxy :: Proxy r) of
+                Nothing -> return Nothing
+                Just qs -> do big <- ringFor False m' qs             -- q = 1 mod m' implies q = 1 mod m
+                              small <- maybe (return Nothing) (const (ringFor False m qs)) big
+                              return ((,) <$> small <*> big)
+      host  = (\(tw, em) -> (coerce tw, coerce em)) <$> (crtExtFuncs :: mon (CT m' r -> CT m r, CT m r -> CT m' r))
+  in case rings of
+       Nothing           -> host
+       Just (small, big) -> (\_ -> ( outOfPlace "twaceCRT" c_twaceCRT small big (totOf (Proxy :: Proxy m))
+                                   , outOfPlace "embedCRT" c_embedCRT small big (totOf (Proxy :: Proxy m')) )) <$> host
+
+-- | @powBasisPow@: the relative powerful basis of m'/m as Pow-basis tensors -- unit vectors at the positions the library's
+-- @coeffs@ reads first (table ALCH_EXT_COEFFS, entries [i][0]), so that @x = sum_i embed (coeffs x !! i) * powBasisPow !! i@.
+powBasisPowGT :: forall m m' r . (m `Divides` m', TElt GT r, Ring r) => Tagged m [GT m' r]
+powBasisPowGT = tag $ case gtModuli (Proxy :: Proxy r) of
+  Nothing -> map GT (proxy powBasisPow (Proxy :: Proxy m) :: [CT m' r])
+  Just _  -> unsafePerformIO $ do
+    let m  = fromIntegral (proxy valueFact (Proxy :: Proxy m))  :: Word32
+        m' = fromIntegral (proxy valueFact (Proxy :: Proxy m')) :: Word32
+        n  = totOf (Proxy :: Proxy m)
+        n' = totOf (Proxy :: Proxy m')
+        d  = n' `div` n
+    tab <- alloca $ \plen -> allocaArray (d * n) $ \pt -> do
+             poke plen (fromIntegral (d * n))
+             c_extTable m m' 1 pt plen >>= check "alch_ext_table"            -- ALCH_EXT_COEFFS
+             peekArray (d * n) pt
+    return [ fromVector (SV.generate n' (\k -> if k == fromIntegral (tab !! (i * n)) then one else zero)) | i <- [0 .. d - 1] ]
+
+-- | @crtSetDec@: the relative mod-p CRT set of O_m' / O_m over the prime field @fp@ on the decoding basis, from the library's
+-- host-side construction (@alch_crt_set_dec@) when @fp@ is a @ZqBasic p Int64@; lol-cpp's otherwise.  (The SET is canonical; its
+-- order is the library's documented rule.  It is a list of decoding-basis vectors, not slot-indexed data, so either source would be
+-- sound; the library's is used so that @decToCRT@ of reference examples/Common.hs:65-75 is reproducible from the C ABI alone.)
+crtSetDecGT :: forall m m' fp . (m `Divides` m', PrimeField fp, Coprime (PToF (CharOf fp)) m', TElt GT fp) => Tagged m [GT m' fp]
+crtSetDecGT = tag $ case gtModuli (Proxy :: Proxy fp) of
+  Just [p] -> unsafePerformIO $ do
+    let m  = fromIntegral (proxy valueFact (Proxy :: Proxy m))  :: Word32
+        m' = fromIntegral (proxy valueFact (Proxy :: Proxy m')) :: Word32
+        n' = totOf (Proxy :: Proxy m')
+    cnt <- alloca $ \pc -> poke pc 0 >> c_crtSetDec m m' (fromIntegral p) nullPtr pc >>= check "alch_crt_set_dec" >> peek pc
+    let c = fromIntegral cnt :: Int
+    mv <- SM.new (c * n')
+    SM.unsafeWith mv $ \pv -> alloca $ \pc -> poke pc cnt >> c_crtSetDec m m' (fromIntegral p) (castPtr pv) pc >>= check "alch_crt_set_dec"
+    v <- SV.unsafeFreeze mv
+    return [ fromVector (SV.slice (i * n') n' v) | i <- [0 .. c - 1] ]
+  _        -> map GT (proxy crtSetDec (Proxy :: Proxy m) :: [CT m' fp])
 
 -- | The CRTrans-monad tuple Lol asks for: (scalarCRT, mulGCRT, divGCRT, crt, crtInv).  On the device when the
 -- element type has moduli AND every modulus is 1 mod m (else @alch_ring_create@ answers ALCH_E_NO_CRT, Lol's
@@ -192,18 +285,13 @@ crtFuncsGT =
                        , inPlace "crt"     c_crt     ring
                        , inPlace "crtInv"  c_crtInv  ring )) <$> host
 
--- | Pointwise product / sum / difference of two tensors of the same basis on the device (Cyc's ring operations
--- on the CRT basis arrive here through the rules below).
+-- | Pointwise product / sum / difference of two tensors of the same basis on the device, for callers that hold @GT@ values
+-- (Lol's own @zipWithT (*)@ stays on lol-cpp: module header).
 mulGT, addGT, subGT :: forall m r . (Fact m, TElt GT r, Ring r) => GT m r -> GT m r -> GT m r
 mulGT a b = onDevice a (\ring -> inPlace2 "mul" c_mul ring a b) (coerce (zipWithT (*) (coerce a :: CT m r) (coerce b :: CT m r)))
 addGT a b = onDevice a (\ring -> inPlace2 "add" c_add ring a b) (coerce (zipWithT (+) (coerce a :: CT m r) (coerce b :: CT m r)))
 subGT a b = onDevice a (\ring -> inPlace2 "sub" c_sub ring a b) (coerce (zipWithT (-) (coerce a :: CT m r) (coerce b :: CT m r)))
 
-{-# RULES
-"zipWithT/GT/mul" forall (a :: GT m r) b . zipWithT (*) a b = mulGT a b
-"zipWithT/GT/add" forall (a :: GT m r) b . zipWithT (+) a b = addGT a b
-"zipWithT/GT/sub" forall (a :: GT m r) b . zipWithT (-) a b = subGT a b
-  #-}
 
 -- | @keySwitchQuadCirc hint (x * y)@ on device-resident batches: one 'c_ctMulRelin' call.
 -- Arguments: ring, hint, operand buffers (2*batch CRT-basis elements each), output buffer, batch,

@@ -59,6 +59,17 @@ foreign import ccall safe   "alch_divg_crt"            c_divGCRT         :: Ptr 
 foreign import ccall safe   "alch_l"                   c_l               :: Ptr AlchRing -> Ptr Int64 -> IO CInt
 foreign import ccall safe   "alch_linv"                c_lInv            :: Ptr AlchRing -> Ptr Int64 -> IO CInt
 
+-- Tensor methods between two indices m | m': embedPow / embedDec / twacePowDec / coeffs and crtExtFuncs = (twaceCRT, embedCRT);
+-- host-only index tables (powBasisPow) and crtSetDec
+foreign import ccall safe   "alch_embed_pow"           c_embedPow        :: Ptr AlchRing -> Ptr AlchRing -> Ptr Int64 -> Ptr Int64 -> IO CInt
+foreign import ccall safe   "alch_embed_dec"           c_embedDec        :: Ptr AlchRing -> Ptr AlchRing -> Ptr Int64 -> Ptr Int64 -> IO CInt
+foreign import ccall safe   "alch_embed_crt"           c_embedCRT        :: Ptr AlchRing -> Ptr AlchRing -> Ptr Int64 -> Ptr Int64 -> IO CInt
+foreign import ccall safe   "alch_twace_pow_dec"       c_twacePowDec     :: Ptr AlchRing -> Ptr AlchRing -> Ptr Int64 -> Ptr Int64 -> IO CInt
+foreign import ccall safe   "alch_twace_crt"           c_twaceCRT        :: Ptr AlchRing -> Ptr AlchRing -> Ptr Int64 -> Ptr Int64 -> IO CInt
+foreign import ccall safe   "alch_coeffs"              c_coeffs          :: Ptr AlchRing -> Ptr AlchRing -> Ptr Int64 -> Ptr Int64 -> IO CInt
+foreign import ccall unsafe "alch_ext_table"           c_extTable        :: Word32 -> Word32 -> CInt -> Ptr Int32 -> Ptr CSize -> IO CInt
+foreign import ccall safe   "alch_crt_set_dec"         c_crtSetDec       :: Word32 -> Word32 -> Word32 -> Ptr Int64 -> Ptr CSize -> IO CInt
+
 -- decompose + reduce (Gadget / Decompose instances of TrivGad and BaseBGad 2)
 foreign import ccall safe   "alch_decompose_triv"      c_decomposeTriv   :: Ptr AlchRing -> Ptr Int64 -> Ptr Int64 -> IO CInt
 foreign import ccall safe   "alch_decompose_base2"     c_decomposeBase2  :: Ptr AlchRing -> Ptr Int64 -> Ptr Int64 -> Ptr CInt -> IO CInt
@@ -84,6 +95,9 @@ foreign import ccall safe   "alch_buf_mulg"            c_bufMulG         :: Ptr 
 foreign import ccall safe   "alch_buf_divg"            c_bufDivG         :: Ptr AlchBuf -> CSize -> CSize -> CInt -> IO CInt
 foreign import ccall safe   "alch_buf_mul_public"      c_bufMulPublic    :: Ptr AlchBuf -> Ptr AlchBuf -> Ptr AlchBuf -> CSize -> CSize -> IO CInt
 foreign import ccall safe   "alch_buf_add_public"      c_bufAddPublic    :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> CSize -> IO CInt
+foreign import ccall safe   "alch_buf_embed"           c_bufEmbed        :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> CInt -> IO CInt
+foreign import ccall safe   "alch_buf_twace"           c_bufTwace        :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> CInt -> IO CInt
+foreign import ccall safe   "alch_buf_coeffs"          c_bufCoeffs       :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> IO CInt
 foreign import ccall safe   "alch_buf_checksum"        c_bufChecksum     :: Ptr AlchBuf -> CSize -> CSize -> Ptr Word64 -> IO CInt
 foreign import ccall safe   "alch_buf_rescale_drop0"   c_bufRescaleDrop0 :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> IO CInt
 foreign import ccall safe   "alch_buf_rescale_add0"    c_bufRescaleAdd0  :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> IO CInt

@@ -212,6 +212,51 @@ int alch_buf_decompose_triv(const alch_buf *src, size_t src_index, alch_buf *dst
  * splitmix64(position ^ value<<20) -- used by the full-size parity tests. */
 int alch_buf_checksum(const alch_buf *buf, size_t first, size_t count, uint64_t *sum);
 
+/* ---- Tensor methods between two indices m | m'  ----------------------------------------------------
+ * Lol's embedPow / embedDec / twacePowDec / coeffs and crtExtFuncs = (twaceCRT, embedCRT): what Cyc `embed`, `twace` and `coeffsCyc`
+ * run, e.g. under SymmSHE encrypt / decrypt (Crypto/Alchemy/Interpreter/PT2CT.hs:84-99), mulPublic / addPublic (Eval.hs:131-132) and
+ * tunnel (Eval.hs:134).  twaceCRT and embedCRT act on CRT SLOTS, so they must come from the same instance as crt / crtInv /
+ * mulGCRT: they are computed from the slot rule at the top of this file (embedCRT: slot s of the big ring <- the slot of the small
+ * ring whose unit is the unit of s reduced mod m; twaceCRT[t] = (mhat/mhat') g(t)^-1 sum over that fibre of g'(s) y[s], the
+ * tweaked trace Tw(y) = (mhat/mhat') Tr(y g'/g)).  `small` has index m, `big` index m' (m | m'), same moduli (or both rings
+ * without CRT over the same moduli: Pow / Dec forms only).
+ *   embed   basis Pow: coefficient j of the small ring lands at its position in the big ring's powerful basis, zeros elsewhere;
+ *           Dec: lInv_big . embedPow . l_small;  CRT: slot replication
+ *   twace   basis Pow or Dec (Tensor twacePowDec: the same positions read back on either basis), or CRT
+ *   coeffs  Tensor `coeffs`: the d_rel = phi(m')/phi(m) coefficient vectors over the small ring w.r.t. the relative powerful (or
+ *           decoding: same positions) basis, relative indices in mixed radix, first prime outermost; dst holds d_rel * count elements,
+ *           element e's coefficients at [e * d_rel, (e + 1) * d_rel).
+ * Work is queued on the destination ring's stream, ordered after the source ring's. */
+int alch_buf_embed(alch_buf *dst_big, const alch_buf *src_small, size_t count, int basis);
+int alch_buf_twace(alch_buf *dst_small, const alch_buf *src_big, size_t count, int basis);
+int alch_buf_coeffs(alch_buf *dst_small, const alch_buf *src_big, size_t count);
+/* The same on host buffers (one ring element, Lol layout; `out` is distinct from `in`). */
+int alch_embed_pow(alch_ring *small, alch_ring *big, const int64_t *in_small, int64_t *out_big);
+int alch_embed_dec(alch_ring *small, alch_ring *big, const int64_t *in_small, int64_t *out_big);
+int alch_embed_crt(alch_ring *small, alch_ring *big, const int64_t *in_small, int64_t *out_big);
+int alch_twace_pow_dec(alch_ring *small, alch_ring *big, const int64_t *in_big, int64_t *out_small);
+int alch_twace_crt(alch_ring *small, alch_ring *big, const int64_t *in_big, int64_t *out_small);
+int alch_coeffs(alch_ring *small, alch_ring *big, const int64_t *in_big, int64_t *out_small_d_rel);
+/* Host-only index tables of an index pair (no GPU needed; Lol computes the corresponding `baseIndicesPow` / `extIndicesCoeffs` in
+ * Haskell): *len in = capacity of out (entries), out = entries written; out == NULL queries the length.
+ *   ALCH_EXT_POW_POS   phi(m) entries: position in the big ring of the small ring's powerful-basis element j (Tensor powBasisPow:
+ *                      the relative powerful basis element i is the unit vector at entry [i][0] of ALCH_EXT_COEFFS)
+ *   ALCH_EXT_COEFFS    d_rel * phi(m) entries, [i][j]: position in the big ring of coefficient j of E-coefficient i
+ *   ALCH_EXT_CRT_SLOT  phi(m') entries: the small ring's CRT slot behind every CRT slot of the big ring */
+#define ALCH_EXT_POW_POS 0
+#define ALCH_EXT_COEFFS 1
+#define ALCH_EXT_CRT_SLOT 2
+int alch_ext_table(uint32_t m_small, uint32_t m_big, int which, int32_t *out, size_t *len);
+/* Tensor crtSetDec (host-only table construction, like the twiddle tables): the relative mod-p CRT set of O_m' / O_m for a prime p
+ * not dividing m', as coefficient vectors over F_p on the decoding basis of index m' -- what Cyc's `crtSet` lifts to Z_{p^e} and
+ * embeds, and `decToCRT` (examples/Common.hs:65-75) turns into the linear functions of the ring switches.  out: *count vectors of
+ * phi(m') residues each, consecutive; *count in = capacity (vectors); out == NULL queries the number of CRT-set elements
+ * (#<p>-cosets of Z_m'^* / #<p>-cosets of Z_m^*).  c_k is the idempotent that is 1 exactly at the primes above p indexed by I_k;
+ * the I_k take one <p>-coset of Z_m'^* above every <p>-coset of Z_m^* (groups ordered by the smallest element of the coset below,
+ * cosets inside a group by their smallest element, I_k = every group's k-th coset).  The set is canonical; its ORDER is this
+ * library's rule (Lol's is not observable in the reference). */
+int alch_crt_set_dec(uint32_t m_small, uint32_t m_big, uint32_t p, int64_t *out, size_t *count);
+
 /* ---- key-switch hint ----------------------------------------------------------------------------
  * KSQuadCircHint gad (Cyc t m' zq) as produced by ksQuadCircHint
  * (Crypto/Alchemy/Interpreter/KeysHints.hs:101-113): one degree-1 polynomial (h0_i, h1_i) per gadget

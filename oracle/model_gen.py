@@ -697,3 +697,248 @@ def g_tunnel(lin_q, hints, ct: GCT, T: TunnelInfo, gadget: str = "triv") -> GCT:
             c0 = [[(u + v) % q for u, v in zip(cl, pl)] for cl, pl, q in zip(c0, rns_ring_mul(dr, b, T.sp, qs), qs)]
             c1 = [[(u + v) % q for u, v in zip(cl, pl)] for cl, pl, q in zip(c1, rns_ring_mul(dr, a, T.sp, qs), qs)]
     return GCT(MSD, 0, ct.l, [c0, c1], ct.p, qs, T.sp, T.s)
+
+
+# --------------------------------------------------------------------------------------
+# The CRT-order-dependent Tensor methods between two indices m | m' (`crtExtFuncs` = (twaceCRT, embedCRT)),
+# embedDec, and the mod-p CRT set `crtSetDec` (used by Cyc's `crtSet`, examples/Common.hs:65-75 `decToCRT`).
+# By definition only:
+#   embedCRT   sigma_{u'}(embed x) = sigma_{u' mod m}(x)      (omega_m = omega_{m'}^(m'/m) under the root rule)
+#   twace      Tw_{m'/m}(y) = (mhat / mhat') Tr_{m'/m}(y g' / g)   (toolkit 2.x / Lol "tweaked trace"), so on the CRT basis
+#              Tw(y)[u] = (mhat/mhat') g(omega^u)^-1 sum_{u' = u mod m} g'(omega'^u') y[u']
+#   crtSetDec  the idempotents c_k of R_{m'} / p R_{m'} with sigma_i(c_k) = [i in I_k] over GF(p^d), d = ord_{m'}(p), where the
+#              I_k partition Z_{m'}^* into unions of <p>-cosets with exactly one coset above every <p>-coset of Z_m^*;
+#              returned as coefficient vectors over F_p in the decoding basis.
+# --------------------------------------------------------------------------------------
+
+def mhat(m: int) -> int:
+    return m // 2 if m % 2 == 0 else m
+
+
+def slot_of_unit(idx: Index) -> dict:
+    return {idx.slot_unit(s): s for s in range(idx.n)}
+
+
+def embed_crt_def(v: Sequence[int], small: Index, big: Index) -> List[int]:
+    su = slot_of_unit(small)
+    return [v[su[big.slot_unit(s) % small.m]] for s in range(big.n)]
+
+
+def twace_crt_def(v: Sequence[int], small: Index, big: Index, q: int) -> List[int]:
+    su = slot_of_unit(small)
+    gs, gb = g_crt(small, q), g_crt(big, q)
+    acc = [0] * small.n
+    for s in range(big.n):
+        t = su[big.slot_unit(s) % small.m]
+        acc[t] = (acc[t] + gb[s] * v[s]) % q
+    scale = pow(mhat(big.m) // mhat(small.m), -1, q)
+    return [a * pow(g, -1, q) * scale % q for a, g in zip(acc, gs)]
+
+
+def embed_dec_def(c: Sequence[int], small: Index, big: Index, q: Optional[int]) -> List[int]:
+    """embedDec: the Dec coefficients over the big index of an element given by its Dec coefficients over the small one."""
+    return linv_def(embed_pow(l_def(c, small, q), small, big), big, q)
+
+
+class GF:
+    """GF(p^d) = F_p[t] / (f), f the lexicographically first monic irreducible polynomial of degree d; elements are tuples of
+    d residues (constant term first)."""
+
+    def __init__(self, p: int, d: int):
+        assert is_prime(p) and d >= 1
+        self.p, self.d = p, d
+        self.f = self._first_irreducible()
+        self.zero, self.one = tuple([0] * d), tuple([1] + [0] * (d - 1))
+
+    # -- polynomial helpers over F_p (lists, constant term first, no trailing zeros except [0]) --
+    def _trim(self, a):
+        while len(a) > 1 and a[-1] == 0:
+            a.pop()
+        return a
+
+    def _pmod(self, a, f):
+        a, p = list(a), self.p
+        df = len(f) - 1
+        inv = pow(f[-1], -1, p)
+        while len(a) - 1 >= df and any(a):
+            self._trim(a)
+            if len(a) - 1 < df:
+                break
+            c = a[-1] * inv % p
+            sh = len(a) - 1 - df
+            for i, fi in enumerate(f):
+                a[sh + i] = (a[sh + i] - c * fi) % p
+            self._trim(a)
+        return self._trim(a)
+
+    def _pmul(self, a, b):
+        out = [0] * (len(a) + len(b) - 1)
+        for i, x in enumerate(a):
+            if x:
+                for j, y in enumerate(b):
+                    out[i + j] = (out[i + j] + x * y) % self.p
+        return out
+
+    def _pgcd(self, a, b):
+        a, b = self._trim(list(a)), self._trim(list(b))
+        while any(b):
+            a, b = b, self._pmod(a, b)
+        return a
+
+    def _powx(self, e, f):
+        """t^e mod f."""
+        r, b = [1], [0, 1]
+        while e:
+            if e & 1:
+                r = self._pmod(self._pmul(r, b), f)
+            b = self._pmod(self._pmul(b, b), f)
+            e >>= 1
+        return r
+
+    def _irreducible(self, f):
+        """Rabin's test."""
+        d, p = len(f) - 1, self.p
+        x = [0, 1]
+        diff = self._powx(p ** d, f)
+        diff = self._trim([(u - v) % p for u, v in zip(diff + [0] * 2, x + [0] * len(diff))][:max(len(diff), 2)])
+        if any(diff):
+            return False
+        for r, _ in factor(d):
+            h = self._powx(p ** (d // r), f)
+            h = self._trim([(u - v) % p for u, v in zip(h + [0] * 2, x + [0] * len(h))][:max(len(h), 2)])
+            if len(self._pgcd(f, h)) != 1:
+                return False
+        return True
+
+    def _first_irreducible(self):
+        p, d = self.p, self.d
+        if d == 1:
+            return [0, 1]
+        for code in range(p ** d):
+            low = [(code // p ** i) % p for i in range(d)]
+            f = low + [1]
+            if low[0] and self._irreducible(f):
+                return f
+        raise AssertionError
+
+    # -- field operations --
+    def add(self, a, b):
+        return tuple((x + y) % self.p for x, y in zip(a, b))
+
+    def neg(self, a):
+        return tuple((-x) % self.p for x in a)
+
+    def mul(self, a, b):
+        r = self._pmod(self._pmul(list(a), list(b)), self.f)
+        return tuple(r + [0] * (self.d - len(r)))
+
+    def pow(self, a, e):
+        r, b = self.one, a
+        while e:
+            if e & 1:
+                r = self.mul(r, b)
+            b = self.mul(b, b)
+            e >>= 1
+        return r
+
+    def from_int(self, x):
+        return tuple([x % self.p] + [0] * (self.d - 1))
+
+    def root_of_unity(self, m: int):
+        """The m-th root rule over GF(p^d): x^((p^d - 1)/m) for the first field element x (counting in base p, constant
+        term least significant) for which that power has order exactly m."""
+        N = self.p ** self.d - 1
+        assert N % m == 0
+        if m == 1:
+            return self.one
+        rs = [r for r, _ in factor(m)]
+        for code in range(2, self.p ** self.d):
+            x = tuple((code // self.p ** i) % self.p for i in range(self.d))
+            w = self.pow(x, N // m)
+            if all(self.pow(w, m // r) != self.one for r in rs):
+                return w
+        raise AssertionError
+
+
+def mult_order(p: int, m: int) -> int:
+    if m == 1:
+        return 1
+    d, x = 1, p % m
+    while x != 1:
+        x = x * p % m
+        d += 1
+    return d
+
+
+def crt_set_cosets(small: Index, big: Index, p: int) -> List[List[int]]:
+    """The index sets I_k (k < r): the <p>-cosets of Z_{m'}^* are grouped by the <p>-coset of Z_m^* they reduce to (groups
+    ordered by the smallest element of that coset, cosets inside a group by their smallest element); I_k = union over the groups
+    of each group's k-th coset.  (The rule is this library's: Lol's own ordering is not observable here -- parity unpinned.)"""
+    import math
+    m, mb = small.m, big.m
+    assert mb % m == 0 and math.gcd(p, mb) == 1
+    units = [u for u in range(1, mb + 1) if math.gcd(u, mb) == 1] if mb > 1 else [0]
+    seen, cosets = set(), []
+    for u in units:
+        if u in seen:
+            continue
+        c, x = [], u
+        while x not in seen:
+            seen.add(x)
+            c.append(x)
+            x = x * p % mb
+        cosets.append(sorted(c))
+    groups = {}
+    for c in cosets:
+        red = c[0] % m if m > 1 else 0
+        key, x = red, red
+        for _ in range(mult_order(p, m)):
+            key = min(key, x)
+            x = x * p % m if m > 1 else 0
+        groups.setdefault(key, []).append(c)
+    r = len(cosets) // len(groups)
+    assert all(len(g) == r for g in groups.values())
+    return [sorted(u for key in sorted(groups) for u in sorted(groups[key], key=lambda c: c[0])[k]) for k in range(r)]
+
+
+def crt_set_dec_def(small: Index, big: Index, p: int) -> List[List[int]]:
+    """crtSetDec: Dec-basis coefficient vectors over F_p of the relative mod-p CRT set of O_{m'} / O_m.
+    a_j = mhat'^-1 Tr(c g' conj(p_j)) = mhat'^-1 sum_{i in I} g'(w^i) w^(-i e(j))   (the dual of the decoding basis
+    d = (mhat'/g') d^dual-of-conj-powerful is (g'/mhat') conj(p)); checked against the defining property in the tests."""
+    mb = big.m
+    d = mult_order(p, mb)
+    F = GF(p, d)
+    w = F.root_of_unity(mb)
+    pw = [F.one]
+    for _ in range(mb - 1):
+        pw.append(F.mul(pw[-1], w))
+    odd = [q for q, _ in big.pps if q != 2]
+
+    def g_at(i):
+        v = F.one
+        for q in odd:
+            v = F.mul(v, F.add(F.one, F.neg(pw[(mb // q) * i % mb])))
+        return v
+    inv_mhat = pow(mhat(mb), -1, p)
+    ex = [big.pow_exponent(j) for j in range(big.n)]
+    out = []
+    for I in crt_set_cosets(small, big, p):
+        gi = [(i, g_at(i)) for i in I]
+        vec = []
+        for j in range(big.n):
+            acc = F.zero
+            for i, gv in gi:
+                acc = F.add(acc, F.mul(gv, pw[(-i * ex[j]) % mb]))
+            assert all(x == 0 for x in acc[1:]), "not in the prime field"
+            vec.append(acc[0] * inv_mhat % p)
+        out.append(vec)
+    return out
+
+
+def eval_mod_p(pow_coeffs: Sequence[int], idx: Index, F: GF, w, unit: int):
+    """sigma_unit(x) in GF(p^d) for x given by Pow coefficients over F_p (w: the m-th root of unity)."""
+    acc = F.zero
+    for j, c in enumerate(pow_coeffs):
+        if c % F.p:
+            acc = F.add(acc, F.mul(F.from_int(c), F.pow(w, unit * idx.pow_exponent(j) % idx.m)))
+    return acc

@@ -9,7 +9,7 @@ from conftest import ROOT
 CTYPE = {  # C parameter type (qualifiers stripped) -> Haskell FFI type
     "uint32_t": "Word32", "uint64_t": "Word64", "int": "CInt", "size_t": "CSize", "unsigned": "CUInt", "long": "CLong",
     "char*": "CString",
-    "uint64_t*": "Ptr Word64", "uint32_t*": "Ptr Word32", "int*": "Ptr CInt", "size_t*": "Ptr CSize",
+    "uint64_t*": "Ptr Word64", "uint32_t*": "Ptr Word32", "int32_t*": "Ptr Int32", "int*": "Ptr CInt", "size_t*": "Ptr CSize",
     "float*": "Ptr CFloat", "int64_t*": "Ptr Int64", "void*": "Ptr ()", "void**": "Ptr (Ptr ())",
     "alch_ring*": "Ptr AlchRing", "alch_buf*": "Ptr AlchBuf", "alch_hint*": "Ptr AlchHint",
     "alch_tunnel*": "Ptr AlchTunnel", "alch_tunnel**": "Ptr (Ptr AlchTunnel)",
@@ -73,12 +73,47 @@ def _gt_source():
 
 def test_tensor_instance_defines_every_method_and_none_is_a_stub():
     text = _gt_source()
-    inst = text[text.index("instance Tensor GT where"):text.index("-- | The CRTrans-monad tuple")]
+    inst = text[text.index("instance Tensor GT where"):text.index("-- | phi(m) as an Int.")]
     for name in TENSOR_METHODS:
         assert re.search(r"^  %s\b[^\n]*=" % re.escape(name), inst, flags=re.M), f"instance Tensor GT lacks {name}"
     code = "\n".join(l.split("--")[0] for l in text.splitlines())            # comments stripped
     assert not re.search(r"=\s*error\b", code) and "undefined" not in code, "stub bodies are not allowed"
     assert not re.search(r"\berror\s+\"(coerce|see|as )", code)
+
+
+ORDER_DEPENDENT = {   # Tensor method -> the library entry points its definition must reach (directly or through its named helper)
+    "l": ["c_l"], "lInv": ["c_lInv"], "mulGPow": ["c_mulGPow"], "mulGDec": ["c_mulGDec"], "divGPow": ["c_divGPow"],
+    "divGDec": ["c_divGDec"], "crtFuncs": ["c_crt", "c_crtInv", "c_mulGCRT", "c_divGCRT"],
+    "crtExtFuncs": ["c_twaceCRT", "c_embedCRT"], "twacePowDec": ["c_twacePowDec"], "embedPow": ["c_embedPow"],
+    "embedDec": ["c_embedDec"], "coeffs": ["c_coeffs"], "powBasisPow": ["c_extTable"], "crtSetDec": ["c_crtSetDec"],
+}
+
+
+def _top_level_body(text, name):
+    """Source of the top-level definition `name` (from its type signature to the next blank line followed by a top-level item)."""
+    m = re.search(r"^%s\s*::" % re.escape(name), text, flags=re.M)
+    assert m, name
+    rest = text[m.start():]
+    end = re.search(r"\n\n(?=\S)", rest)
+    return rest[:end.start()] if end else rest
+
+
+def test_no_basis_order_dependent_method_is_delegated_to_lol_cpp():
+    """`instance Tensor GT` is sound only if every method whose result depends on a basis ORDER (CRT slots,
+    relative powerful / decoding bases) comes from the library for the element types the library serves -- mixing lol-cpp's slot
+    order with the library's would make `embed` / `twace` of CRT-basis elements silently wrong.  Each such method must reach its
+    C entry point; no rewrite RULES are relied on."""
+    text = _gt_source()
+    inst = text[text.index("instance Tensor GT where"):text.index("-- | phi(m) as an Int.")]
+    for method, syms in ORDER_DEPENDENT.items():
+        m = re.search(r"^  %s\b[^\n]*=(.*?)(?=^  \w[\w']*\s[^\n]*=|\Z)" % re.escape(method), inst, flags=re.M | re.S)
+        assert m, method
+        body = m.group(1)
+        for helper in re.findall(r"\b(\w+GT)\b", body):
+            body += _top_level_body(text, helper)
+        for sym in syms:
+            assert re.search(r"\b%s\b" % sym, body), f"{method} does not reach {sym}: it would run in lol-cpp's basis order"
+    assert "{-# RULES" not in text
 
 
 def test_every_foreign_symbol_used_by_the_instance_is_imported_by_the_backend():
