@@ -87,6 +87,35 @@ def cpu_baseline_all_cores(ops_per_thread: int):
 
 
 RING_OPTS = []
+MASK64 = (1 << 64) - 1
+
+
+def totient(m: int) -> int:
+    r, p, t = m, 2, m
+    while p * p <= t:
+        if t % p == 0:
+            r -= r // p
+            while t % p == 0:
+                t //= p
+        p += 1
+    return r - r // t if t > 1 else r
+
+
+def golden_checksums():
+    """tests/golden/batch_checksums.json: what the C restatement computed offline for the seeded batches timed here
+    (tests/golden/make_batch_checksums.py).  Every driver-timed line asserts its results against it: a wrong word in any chunk
+    of any timed line ends the run."""
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "batch_checksums.json")))
+    except (OSError, ValueError):
+        return {}
+
+
+def assert_checksum(what, got, expected, detail):
+    rec = {"expected": expected, "got": f"{got:016x}", "ok": f"{got:016x}" == expected, **detail}
+    if not rec["ok"]:
+        raise SystemExit(f"[bench] {what}: result batch differs from the oracle's: {rec}")
+    return rec
 
 
 def apply_opts(*rings):
@@ -121,11 +150,83 @@ def general_index_line():
     for _ in range(3):
         tr.crt()
     crt_s = 3 * tr.n_elems * ring.L / (ring.timer_stop() * 1e-3)
+    ref = golden_checksums().get("general_index", {}).get("bench")
+    check = None
+    if ref is not None and ref["batch"] == Bg:
+        check = assert_checksum("general_index", out.checksum(), ref["checksum"], {"batch": Bg})
     return {"workload": "keySwitchQuadCirc(hint, a*b), index m'=20475 (phi=8640), L=4 HomomRLWR moduli, TrivGad, CRT in/out",
-            "ops_per_s": ops, "batch": Bg, "algorithmic_bytes_per_op": algo, "achieved_GBs": ops * algo / 1e9,
+            "ops_per_s": ops, "batch": Bg, "batch_checksum": check, "algorithmic_bytes_per_op": algo, "achieved_GBs": ops * algo / 1e9,
             "frac_of_hbm_peak": ops * algo / 1e9 / HBM_PEAK_GBS, "frac_at_device_word": ops * algo / 2 / 1e9 / HBM_PEAK_GBS,
             "limb_crt_per_s": crt_s, "limb_crt_algorithmic_GBs": crt_s * 2 * n * 8 / 1e9,
             "out_checksum": f"{out.checksum(0, 2):016x}"}
+
+
+def tunnel_hs_line():
+    """Extra line: BASELINE config 5 at the reference's real parameters -- the five hops of examples/Tunnel.hs (BaseBGad 2 hints,
+    its moduli, H0' .. H5'), each as modSwitch . tunnel hint . modSwitch on 256 resident ciphertexts (alchemy_amd/tunnelhops.py);
+    every hop's whole result batch is checked against the C restatement's checksums."""
+    from alchemy_amd.tunnelhops import Hop
+    ref = {h["hop"]: h for h in golden_checksums().get("tunnel_hs", {}).get("hops", [])}
+    hops = []
+    for k in range(5):
+        hop = Hop(k, 256, RING_OPTS)
+        rate, res = hop.measure()
+        check = None
+        if k in ref and ref[k]["batch"] == hop.B:
+            check = assert_checksum(f"tunnel_hs hop {k}", res.checksum(0, 2 * hop.B), ref[k]["checksum"], {"batch": hop.B})
+        algo = hop.algorithmic_bytes()
+        hops.append({"hop": f"H{k}' -> H{k + 1}'", "limbs_in_hint_out": [hop.lin, hop.lh, hop.lout], "d_rel": hop.d_rel,
+                     "digits_per_coefficient": hop.D, "tunnels_per_s": rate, "algorithmic_bytes_per_tunnel": algo,
+                     "frac_of_hbm_peak": rate * algo / 1e9 / HBM_PEAK_GBS, "batch_checksum": check})
+        del hop
+    return {"workload": "examples/Tunnel.hs hops: modSwitch . tunnel hint . modSwitch, BaseBGad 2 hints, Tunnel.hs moduli, limb counts "
+                        "from alch_select_limbs, 256 ciphertexts resident in HBM, synthetic residues", "hops": hops}
+
+
+def config2_line():
+    """Extra line: BASELINE config 2 -- n = 2^14, one limb (60-bit q: 64-bit device words; and the 31-bit reference-compatible point):
+    forward / inverse transform and pointwise product rates on a resident batch, fractions at the word the device moves.
+    Checked: crt and the pointwise product of the first polynomials against the C restatement, crtInv(crt(x)) == x on the batch."""
+    from alchemy_amd import Ring
+    n, polys = 1 << 14, 32768
+    ref = golden_checksums().get("config2", {})
+    out = {"workload": f"BASELINE config 2: n=2^14, 1 limb, {polys} polynomials resident in HBM; crt, crtInv, pointwise product",
+           "algorithmic_bytes_at_8_byte_words": {"transform": 2 * n * 8, "pointwise_mul": 3 * n * 8}}
+    for label, q in (("q60", 1152921504606748673), ("q31", 2147352577)):
+        ring = Ring(2 * n, [q])
+        apply_opts(ring)
+        a, b, c = ring.alloc(polys), ring.alloc(polys), ring.alloc(polys)
+        a.fill_uniform(2026); b.fill_uniform(7)
+        before = a.checksum()
+
+        def best(fn, reps=3):
+            fn(); ring.sync()
+            t = 1e9
+            for _ in range(reps):
+                ring.timer_start(); fn(); t = min(t, ring.timer_stop())
+            return t * 1e-3
+        # timing leaves `a` transformed an even number of times in each direction: 4 forward, then 4 inverse
+        t_f = best(lambda: a.crt())
+        t_i = best(lambda: a.crtinv())
+        if a.checksum() != before:
+            raise SystemExit(f"[bench] config2 {label}: crtInv^4(crt^4(x)) != x")
+        a.crt()
+        t_m = best(lambda: c.mul(a, b, polys))
+        check = None
+        pre = ref.get("prefix")
+        if label in ref and pre and pre <= polys:
+            check = {"crt": assert_checksum(f"config2 {label} crt", a.checksum(0, pre), ref[label]["crt"], {"polynomials": pre}),
+                     "crt_times_b": assert_checksum(f"config2 {label} mul", c.checksum(0, pre), ref[label]["crt_times_b"], {"polynomials": pre})}
+        wb = ring.word_bytes
+        dev = lambda words, t: polys * words * n * wb / t / 1e9
+        out[label] = {"modulus": q, "device_word_bytes": wb, "ntt_per_s": polys / t_f, "intt_per_s": polys / t_i,
+                      "pointwise_mul_per_s": polys / t_m,
+                      "GBs_at_device_word": {"ntt": dev(2, t_f), "intt": dev(2, t_i), "mul": dev(3, t_m)},
+                      "frac_of_hbm_peak_at_device_word": {"ntt": dev(2, t_f) / HBM_PEAK_GBS, "intt": dev(2, t_i) / HBM_PEAK_GBS,
+                                                          "mul": dev(3, t_m) / HBM_PEAK_GBS},
+                      "checks": check}
+        del a, b, c, ring
+    return out
 
 
 def main():
@@ -145,6 +246,10 @@ def main():
                     help="skip the HomomRLWR ringRound pipeline (BASELINE config 4 at the reference's indices and moduli; every rank "
                          "runs its own 1024-ciphertext shard, extra field `homomrlwr`)")
     ap.add_argument("--pipeline-batch", type=int, default=1024, help="ciphertexts per GPU in the HomomRLWR pipeline")
+    ap.add_argument("--no-tunnel-hs", dest="tunnel_hs", action="store_false",
+                    help="skip the examples/Tunnel.hs hops (BASELINE config 5: BaseBGad 2 hints, extra field `tunnel_hs`)")
+    ap.add_argument("--no-config2", dest="config2", action="store_false",
+                    help="skip BASELINE config 2 (n = 2^14, one limb: transform and pointwise rates, extra field `config2`)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="launch-structure option for every ring (alch_ring_set_option), e.g. one_stream=1 for kernel traces "
                          "whose durations add up to the step time")
@@ -226,10 +331,7 @@ def main():
     # (tests/golden/batch_checksums.json, generated by tests/golden/make_batch_checksums.py)
     batch_check = None
     if rank == 0:
-        try:
-            ref = json.load(open(os.path.join(ROOT, "tests", "golden", "batch_checksums.json")))["bench_mul_relin"]
-        except (OSError, KeyError, ValueError):
-            ref = None
+        ref = golden_checksums().get("bench_mul_relin")
         if ref is not None and ref.get("batch") == B:
             got = out.checksum()
             batch_check = {"batch": B, "expected": ref["checksum"], "got": f"{got:016x}", "ok": f"{got:016x}" == ref["checksum"]}
@@ -316,12 +418,21 @@ def main():
     if args.general and rank == 0:
         general = general_index_line()
 
+    tunnel_hs = config2 = None
+    if rank == 0 and (args.tunnel_hs or args.config2):
+        del a, b, out
+        a = b = out = None
+        if args.tunnel_hs:
+            tunnel_hs = tunnel_hs_line()
+        if args.config2:
+            config2 = config2_line()
+
     homomrlwr = None
     if args.pipeline:
         # BASELINE config 4: "examples/HomomRLWR.hs pipeline, 8192-ciphertext batch sharded over 8 GPUs" = 1024 ciphertexts per
         # GPU.  Every rank runs the whole op sequence on its own shard (no collective inside), bracketed like the headline.
         from alchemy_amd.ringround import RingRound
-        del a, b, out
+        a = b = out = None
         Bp = args.pipeline_batch
         rr = RingRound(Bp, RING_OPTS)
         rr.run(); rr.sync()                                    # allocations, first touch
@@ -335,11 +446,32 @@ def main():
         shard.barrier(dist)
         secs = shard.max_over_ranks((time.perf_counter() - t0) / 2, dist, red_dev)
         if rank == 0:
+            # whole-batch check of the timed pass: rank 0's shard starts at ciphertext 0, so the committed per-ciphertext checksums
+            # of the C restatement's replay (tests/ringround_oracle.py) apply to its first min(Bp, fixture batch) results
+            ref = golden_checksums().get("homomrlwr")
+            pipe_check = None
+            if ref is not None:
+                cnt = min(Bp, ref["batch"])
+                want = sum(int(x, 16) for x in ref["per_ciphertext"][:cnt]) & MASK64
+                pipe_check = assert_checksum("homomrlwr", res.checksum(0, 2 * cnt), f"{want:016x}", {"ciphertexts_checked": cnt, "batch": Bp})
             rr.stages.clear()
             rr.run(stage_times=True)
+            # compulsory bytes at the reference's 8-byte word: end to end (one linear ciphertext in over H0', one out over H5') and
+            # summed over the 13 heavy ops (each tunnel / mul_ reads its operands and writes its result once)
+            from alchemy_amd.ringround import HP as _HP
+            phi = {m: totient(m) for m in _HP}
+            e2e = 2 * 8 * (rr.tuns[0][0] * phi[_HP[0]] + rr.muls[3][2] * phi[_HP[5]])
+            per_op = sum(2 * 8 * (li * phi[_HP[k]] + lo * phi[_HP[k + 1]]) for k, (li, _, lo) in enumerate(rr.tuns))
+            mult = [1, 4, 2, 1]
+            per_op += sum(cnt_ * 2 * 8 * (2 * li + lo) * phi[_HP[5]] for cnt_, (li, _, lo) in zip(mult, rr.muls))
+            rate = Bp * world / secs
             homomrlwr = {"workload": "HomomRLWR ringRound op sequence: mulPublic, 5 ring tunnels H0' -> H5', rescale tree with 8 mul_ "
                          "(examples/HomomRLWR.hs:45-59), real indices and moduli, limb counts from alch_select_limbs, synthetic residues",
-                         "ciphertexts_per_gpu": Bp, "n_gpus": world, "pipelines_per_s": Bp * world / secs, "ms_per_batch": secs * 1e3,
+                         "ciphertexts_per_gpu": Bp, "n_gpus": world, "pipelines_per_s": rate, "ms_per_batch": secs * 1e3,
+                         "batch_checksum": pipe_check,
+                         "algorithmic_bytes_per_pipeline": {"end_to_end": e2e, "sum_over_the_13_heavy_ops": per_op},
+                         "frac_of_hbm_peak": {"end_to_end": rate / world * e2e / 1e9 / HBM_PEAK_GBS,
+                                              "sum_over_the_13_heavy_ops": rate / world * per_op / 1e9 / HBM_PEAK_GBS},
                          "tunnel_limbs": rr.tuns, "mul_limbs": rr.muls,
                          "stage_ms_rank0": {k: round(v * 1e3, 3) for k, v in rr.stages.items()},
                          "out_checksum": f"{res.checksum(0, 2):016x}"}
@@ -404,6 +536,10 @@ def main():
             line["general_index"] = general
         if homomrlwr is not None:
             line["homomrlwr"] = homomrlwr
+        if tunnel_hs is not None:
+            line["tunnel_hs"] = tunnel_hs
+        if config2 is not None:
+            line["config2"] = config2
         line["result_gather"] = gather
         if world == 1 and args.cpu_ops > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_ops)

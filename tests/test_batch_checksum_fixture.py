@@ -1,0 +1,44 @@
+"""CPU: tests/golden/batch_checksums.json is what tests/golden/make_batch_checksums.py produces today -- one ciphertext of every
+section is recomputed on the C restatement (the generator's own per-ciphertext functions) and compared with the committed value.
+Guards against a fixture that went stale when the op sequence, the seeds or the oracle changed."""
+import importlib.util
+import os
+
+import pytest
+
+from helpers import GOLDEN, load_golden
+
+
+@pytest.fixture(scope="module")
+def gen(oracle_lib):
+    spec = importlib.util.spec_from_file_location("make_batch_checksums", os.path.join(GOLDEN, "make_batch_checksums.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_homomrlwr_fixture_is_current(gen):
+    ref = load_golden("batch_checksums.json")["homomrlwr"]
+    assert len(ref["per_ciphertext"]) == ref["batch"] >= 64
+    for ct in (0, ref["batch"] - 1):
+        assert f"{gen.ringround_ct(ct):016x}" == ref["per_ciphertext"][ct]
+
+
+def test_tunnel_hs_fixture_is_current(gen):
+    hops = load_golden("batch_checksums.json")["tunnel_hs"]["hops"]
+    assert [h["hop"] for h in hops] == list(range(5))
+    for h in hops:
+        assert f"{gen.hop_ct((h['hop'], 5)):016x}" == h["per_ciphertext"][5]
+        assert f"{sum(int(x, 16) for x in h['per_ciphertext']) & gen.MASK:016x}" == h["checksum"]
+
+
+def test_general_index_and_config2_fixtures_are_current(gen):
+    ref = load_golden("batch_checksums.json")
+    g = ref["general_index"]
+    assert f"{sum(gen.general_ct(ct) for ct in range(4)) & gen.MASK:016x}" == g["first_4"]
+    assert g["test"]["batch"] < g["bench"]["batch"]
+    c2 = ref["config2"]
+    for label in ("q60", "q31"):
+        sums = [gen.config2_poly((label, e)) for e in range(2)]
+        assert [f"{sum(a for a, _ in sums) & gen.MASK:016x}", f"{sum(b for _, b in sums) & gen.MASK:016x}"] == c2[label]["first_2"]
+        assert c2[label]["modulus"] == gen.C2_QS[label]

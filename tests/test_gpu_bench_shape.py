@@ -56,3 +56,22 @@ def test_mul_full_bench_shape(oracle_lib):
                                  o_in.fill_uniform(seeds["a"], 2 * ct + 1), o_in.fill_uniform(seeds["b"], 2 * ct),
                                  o_in.fill_uniform(seeds["b"], 2 * ct + 1))
         assert np.array_equal(got[0], w0) and np.array_equal(got[1], w1), ct
+
+
+def test_general_index_bench_shape(oracle_lib):
+    """bench.py's `general_index` line (keySwitchQuadCirc(a*b) on H5' = F20475, four HomomRLWR moduli) at a ragged batch: whole-batch
+    checksum against the C restatement's offline value, spot ciphertexts against the oracle run live."""
+    ref = load_golden("batch_checksums.json")["general_index"]
+    B, seeds, m, qs = ref["test"]["batch"], ref["seeds"], ref["index"], ref["moduli"]
+    g, o = A.Ring(m, qs), oracle_lib.GenRing(m, qs)
+    a, b, out, hs = g.alloc(2 * B), g.alloc(2 * B), g.alloc(2 * B), g.alloc(2 * g.L)
+    a.fill_uniform(seeds["a"]); b.fill_uniform(seeds["b"]); hs.fill_uniform(seeds["hint"])
+    hint = g.hint_from_buf(hs)
+    g.ct_mul_relin(hint, a, b, out, B)
+    assert f"{out.checksum():016x}" == ref["test"]["checksum"]
+    hint_host = [o.fill_uniform(seeds["hint"], i) for i in range(2 * g.L)]
+    for ct in (0, 1, 255, 256, B - 1):
+        got = out.download(2 * ct, 2)
+        w0, w1 = o.ct_mul_relin(hint_host, o.fill_uniform(seeds["a"], 2 * ct), o.fill_uniform(seeds["a"], 2 * ct + 1),
+                                o.fill_uniform(seeds["b"], 2 * ct), o.fill_uniform(seeds["b"], 2 * ct + 1))
+        assert np.array_equal(got[0], w0) and np.array_equal(got[1], w1), ct

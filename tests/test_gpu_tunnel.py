@@ -92,59 +92,31 @@ def test_tunnel_below_the_hint_ring_equals_mod_switch_then_tunnel(oracle_lib, rp
             assert np.array_equal(one_call[2 * ct], w0) and np.array_equal(one_call[2 * ct + 1], w1), ct
 
 
-TUNNEL_HS_QS = [537264001, 539884801, 555609601, 560851201, 566092801]          # examples/Tunnel.hs:34-39, Zqs order
-
-
-@pytest.mark.parametrize("k,lin,lh,lout", [(0, 2, 2, 2), (2, 2, 1, 1), (4, 1, 1, 1)])
-def test_tunnel_hs_hop_with_base2_hints_at_full_size(oracle_lib, k, lin, lh, lout):
-    """BASELINE config 5 at the reference's real parameters (what tools/bench_tunnel.py times): a hop of examples/Tunnel.hs --
-    BaseBGad 2 hints (:24), its moduli (:34-39), indices H_k' -> H_k+1' (examples/Common.hs:49-54), the limb counts
-    alch_select_limbs derives (the hint may sit on FEWER limbs than the input: the leading modSwitch goes down) -- as
-    modSwitch . tunnel hint . modSwitch on the device against the C restatement's composition."""
-    hp = [11648, 29120, 43680, 54600, 27300, 20475]
-    mods = lambda L: list(reversed(TUNNEL_HS_QS[:L]))
-    rr, rs = A.Ring(hp[k], mods(lh)), A.Ring(hp[k + 1], mods(lh))
-    rin = rr if lin == lh else A.Ring(hp[k], mods(lin))          # buffers are tied to ring handles
-    ro = rs if lout == lh else A.Ring(hp[k + 1], mods(lout))
-    _, d_rel = A.Tunnel.info(rr, rs)
-    D = rs.gadget_digits(capi.ALCH_GAD_BASE2)
-    lin_buf, ks = rs.alloc(d_rel), rs.alloc(2 * d_rel * D)
-    lin_buf.fill_uniform(1); ks.fill_uniform(2)
-    tun = A.Tunnel(rr, rs, lin_buf, ks, gadget=capi.ALCH_GAD_BASE2)
-    batch = 2
-    x, mid, out = rin.alloc(2 * batch), rs.alloc(2 * batch), ro.alloc(2 * batch)
-    x.fill_uniform(3)
-    src = x
-    if lh != lin:
-        src = rr.alloc(2 * batch)
-        capi.ct_mod_switch(x, src, batch)
-    tun.apply(src, mid, batch)
-    res = mid
-    if lout != lh:
-        capi.ct_mod_switch(mid, out, batch); res = out
-    got = res.download()
-    # ---- the same on the oracle
-    G = oracle_lib.GenRing
-    xs, lin_h, ks_h = x.download(), list(lin_buf.download()), list(ks.download())
-    for ct in range(batch):
-        cur = [xs[2 * ct], xs[2 * ct + 1]]
-        if lh < lin:                                             # modSwitch down in front of the tunnel
-            nxt = []
-            for comp, c in enumerate(cur):
-                o = G(hp[k], mods(lin))
-                v = o.crtinv(c)
-                if comp == 0:
-                    v = o.linv(v)
-                for u in range(lin - lh):
-                    v = G(hp[k], mods(lin)[u:]).rescale_drop0(v)
-                oo = G(hp[k], mods(lh))
-                if comp == 0:
-                    v = oo.l(v)
-                nxt.append(oo.crt(v))
-            cur = nxt
-        assert lh <= lin and lout == lh                          # the shapes of this config
-        w0, w1 = oracle_tunnel(oracle_lib, hp[k], hp[k + 1], mods(lh), lin_h, ks_h, cur[0], cur[1], gadget="base2")
+@pytest.mark.parametrize("k", range(5))
+def test_tunnel_hs_hop_with_base2_hints_at_full_size(oracle_lib, k):
+    """BASELINE config 5 at the reference's real parameters (what bench.py's `tunnel_hs` line and tools/bench_tunnel.py time,
+    alchemy_amd/tunnelhops.py): every hop of examples/Tunnel.hs -- BaseBGad 2 hints (:24), its moduli (:34-39), indices
+    H_k' -> H_k+1' (examples/Common.hs:49-54), the limb counts alch_select_limbs derives (the hint may sit on FEWER limbs than the
+    input: the leading modSwitch goes down) -- as modSwitch . tunnel hint . modSwitch on the device:
+      * two ciphertexts word for word against the C restatement's composition run live (tests/tunnelhops_oracle.py),
+      * a ragged batch of 37 by whole-batch checksum against the values the oracle produced offline (what bench.py asserts
+        for its 256-ciphertext batches)."""
+    from alchemy_amd.tunnelhops import Hop
+    from helpers import load_golden
+    from tunnelhops_oracle import HopOracle
+    B = 37
+    hop = Hop(k, B)
+    res = hop.run()
+    hop.rs.sync()
+    orc = HopOracle(oracle_lib, k)
+    assert (orc.lin, orc.lh, orc.lout, orc.d_rel, orc.D) == (hop.lin, hop.lh, hop.lout, hop.d_rel, hop.D)
+    got = res.download(0, 4)
+    for ct in range(2):
+        w0, w1 = orc.run(ct)
         assert np.array_equal(got[2 * ct], w0) and np.array_equal(got[2 * ct + 1], w1), ct
+    ref = load_golden("batch_checksums.json")["tunnel_hs"]["hops"][k]
+    want = sum(int(x, 16) for x in ref["per_ciphertext"][:B]) & ((1 << 64) - 1)
+    assert f"{res.checksum(0, 2 * B):016x}" == f"{want:016x}"
 
 
 def test_tunnel_with_base2_hints_decrypts_to_f_of_pt():
