@@ -993,6 +993,10 @@ extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) 
     else if (k == "rs_half") r->opts.rs_half = value != 0;
     else if (k == "tunnel_ep") r->opts.tunnel_ep = value != 0;
     else if (k == "gen_fused") r->opts.gen_fused = value != 0;
+    else if (k == "gen_nt") {
+        if (value != 0 && value != 128 && value != 256 && value != 512) return fail(ALCH_E_INVALID, "gen_nt must be 0 (by ring size), 128, 256 or 512");
+        r->g32.nt = (int)value; r->g64.nt = (int)value;
+    }
     else if (k == "split_fused") r->opts.split_fused = value != 0;
     else if (k == "scratch_mib") { if (value < 1 || value > 65536) return fail(ALCH_E_INVALID, "scratch_mib must be 1 .. 65536"); r->scratch_mib = (size_t)value; }
     else if (k == "rs_slots") { if (value < 1) return fail(ALCH_E_INVALID, "rs_slots must be >= 1"); r->rs_slots = (unsigned)value; }
@@ -2245,6 +2249,7 @@ extern "C" int alch_tunnel_create(alch_ring* rr, alch_ring* rs, int gadget, cons
         alch_ring* re = nullptr;
         if (alch_ring_create(ep, rs->L, rs->q, &re) == ALCH_OK && re->gen && re->word == rs->word && re->n % 4 == 0 && rs->n % 4 == 0) {
             t->re = re;
+            re->g32.nt = rs->g32.nt; re->g64.nt = rs->g64.nt;      // launch-structure options of the target ring apply to its E' ring
             if (hipMalloc((void**)&t->table_e, tab_e.size() * sizeof(int32_t)) != hipSuccess ||
                 hipMalloc((void**)&t->slot_e, slot_e.size() * sizeof(u32)) != hipSuccess ||
                 hipMemcpy(t->table_e, tab_e.data(), tab_e.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||

@@ -68,6 +68,7 @@ struct GenDev {
     const W* gcrt_inv[MAXL];
     W radinv_m[MAXL];                    // (odd radical of m)^-1 mod q_j in Montgomery form; 0 = not a unit (divG fails)
     u32 rad;
+    int nt;                              // host side: threads per workgroup of the transform kernels (0 = by ring size: gen_threads)
     int plain;                           // ring without CRT over an arbitrary modulus 2 <= q < 2^31 (Lol: a plaintext ring
                                          // Z_p): no Montgomery constants, products by `%`; radinv_m is then a plain residue
 };
@@ -114,8 +115,8 @@ hipError_t gen_ks_dispatch(const DevRing<u64>& R, const GenDev<u64>& G, const Ge
 // 32-bit words: four products are summed in 64 bits before one reduction -- 4 q^2 < 2^64, the sum's high word is < 2q, one
 // conditional subtraction brings the sum below q 2^32, then a single Montgomery reduction: 10 instructions per four terms
 // instead of 20.  64-bit words: one product at a time.
-template <int R>
-__device__ __forceinline__ u32 dense_row(const u32* x, const u32* __restrict__ M, u32 q, u32 qni) {
+template <int R, typename MP>
+__device__ __forceinline__ u32 dense_row(const u32* x, MP M, u32 q, u32 qni) {
     u32 acc = 0;
 #pragma unroll
     for (int t0 = 0; t0 < R; t0 += 4) {
@@ -129,8 +130,8 @@ __device__ __forceinline__ u32 dense_row(const u32* x, const u32* __restrict__ M
     }
     return acc;
 }
-template <int R>
-__device__ __forceinline__ u64 dense_row(const u64* x, const u64* __restrict__ M, u64 q, u64 qni) {
+template <int R, typename MP>
+__device__ __forceinline__ u64 dense_row(const u64* x, MP M, u64 q, u64 qni) {
     u64 acc = csub(mont_mul_lazy(x[0], M[0], q, qni), q);
 #pragma unroll
     for (int t = 1; t < R; ++t) acc = csub(acc + csub(mont_mul_lazy(x[t], M[t], q, qni), q), q);
@@ -151,15 +152,21 @@ template <typename W> __device__ __forceinline__ W gmul(W a, W b, W q, W qni) { 
 template <typename W, int NT, int P, bool IS_DFT, bool INV>
 __device__ __forceinline__ void gen_sym_pass(W* __restrict__ lds, const GenPass& Ps, const W* __restrict__ tab, u32 n, W q, W qni) {
     constexpr int H = (P - 1) / 2, R = IS_DFT ? P : P - 1;
-    const W* __restrict__ T = tab + Ps.mat_off;
-    const W* __restrict__ a = T;
-    const W* __restrict__ b = T + H * H;
-    const bool has_tw = Ps.tw_off != 0xffffffffu;
+    // CRT_p passes never carry twiddles, DFT_p passes always do (gen_plan): a compile-time fact, so the per-element loads below are
+    // straight-line code -- as a run-time flag it cost a branch and ~10 VALU instructions per element loaded
+    constexpr bool has_tw = IS_DFT;
+    // the pass matrices are wave-uniform: read through the constant address space they become scalar loads and live in SGPRs
+    // (as plain global loads hipcc hoisted all 2 h^2 + p of them into VGPRs: 85 registers for p = 13)
+    typedef const W __attribute__((address_space(4)))* CP;
+    CP T = (CP)(tab + Ps.mat_off);
+    CP a = T;
+    CP b = T + H * H;
     const W* __restrict__ tw = tab + (has_tw ? Ps.tw_off : 0u);
-    const u32 step = fdiv(Ps.stride, Ps.axis_stride, Ps.rcp_axis_stride);
+    const u32 stride = Ps.stride;
+    const u32 step = has_tw ? fdiv(stride, Ps.axis_stride, Ps.rcp_axis_stride) : 0u;
     for (u32 w = threadIdx.x; w < n / (u32)R; w += NT) {
-        const u32 hi = fdiv(w, Ps.stride, Ps.rcp_stride), lo = w - hi * Ps.stride;
-        const u32 base = hi * (u32)R * Ps.stride + lo;
+        const u32 hi = fdiv(w, stride, Ps.rcp_stride), lo = w - hi * stride;
+        const u32 base = hi * (u32)R * stride + lo;
         u32 pos0 = 0;
         if (has_tw) {
             const u32 ap = fdiv(base, Ps.axis_stride, Ps.rcp_axis_stride);
@@ -169,10 +176,15 @@ __device__ __forceinline__ void gen_sym_pass(W* __restrict__ lds, const GenPass&
         //   forward CRT_p: in_0..in_{p-2} = x, in_{p-1} = 0;  inverse CRT_p: in_0 = y_0 (below), in_1.. = x;  DFT_p: in = x
         constexpr int OFF = (!IS_DFT && INV) ? 1 : 0;
         W x[R];
+        {   // element t at base + t stride: one running address, one add per element
+            W* pe = lds + base;
 #pragma unroll
-        for (int t = 0; t < R; ++t) {
-            x[t] = lds[base + (u32)t * Ps.stride];
-            if (!INV && has_tw) x[t] = gmul(x[t], tw[pos0 + (u32)t * step], q, qni);
+            for (int t = 0; t < R; ++t) { x[t] = *pe; pe += stride; }
+        }
+        if (!INV && has_tw) {
+            const W* pt = tw + pos0;
+#pragma unroll
+            for (int t = 0; t < R; ++t) { x[t] = gmul(x[t], *pt, q, qni); pt += step; }
         }
         W in0;
         if (!IS_DFT && INV) in0 = dense_row<P - 1>(x, T + 2 * H * H, q, qni);          // y_0 = sum_i y_i (-w^i)
@@ -193,13 +205,12 @@ __device__ __forceinline__ void gen_sym_pass(W* __restrict__ lds, const GenPass&
             u0 = gmul(u0, pinv, q, qni);
             sum = gmul(sum, pinv, q, qni);
         }
-        // results go straight back to LDS (every input of the group is in registers by now): row r of the DFT_p lands at
-        // element r (DFT_p, inverse CRT_p) or r - 1 (forward CRT_p, which has no row 0); inverse CRT_p drops row p - 1 (= 0)
+        // results: row r of the DFT_p lands at element r (DFT_p, inverse CRT_p) or r - 1 (forward CRT_p, which has no row 0);
+        // inverse CRT_p drops row p - 1 (= 0).  Collected in registers in element order, then stored along one running address.
+        W y[R];
         auto put = [&](int row, W val) {
             const int t = (!IS_DFT && !INV) ? row - 1 : row;
-            if (t < 0 || t >= R) return;
-            if (INV && has_tw) val = gmul(val, tw[pos0 + (u32)t * step], q, qni);
-            lds[base + (u32)t * Ps.stride] = val;
+            if (t >= 0 && t < R) y[t] = val;
         };
         put(0, sum);
 #pragma unroll
@@ -208,6 +219,16 @@ __device__ __forceinline__ void gen_sym_pass(W* __restrict__ lds, const GenPass&
             const W B = dense_row<H>(v, b + (i - 1) * H, q, qni);
             put(i, gadd(A, B, q));
             put(P - i, gsub(A, B, q));
+        }
+        if (INV && has_tw) {
+            const W* pt = tw + pos0;
+#pragma unroll
+            for (int t = 0; t < R; ++t) { y[t] = gmul(y[t], *pt, q, qni); pt += step; }
+        }
+        {
+            W* pe = lds + base;
+#pragma unroll
+            for (int t = 0; t < R; ++t) { *pe = y[t]; pe += stride; }
         }
     }
 }
@@ -341,7 +362,7 @@ __global__ void __launch_bounds__(NT, 4) k_gen_crt(DevRing<W> R, GenDev<W> G, W*
 // workgroup = (ciphertext, source limb i, target limb j); the diagonal i == j is skipped (that digit is c2's own
 // limb j, which the caller kept in the CRT basis).
 template <typename W, int NT = GEN_T>
-__global__ void __launch_bounds__(NT) k_gen_crt_digits(DevRing<W> R, GenDev<W> G, const W* __restrict__ c2pow, W* __restrict__ digits, int balanced, int with_diag,
+__global__ void __launch_bounds__(NT, 4) k_gen_crt_digits(DevRing<W> R, GenDev<W> G, const W* __restrict__ c2pow, W* __restrict__ digits, int balanced, int with_diag,
                  int Ls, int sfirst) {
     // Ls, sfirst: the source elements hold the limbs sfirst .. sfirst + Ls - 1 only (tunnel behind a modSwitch up: the added
     // limbs are zero and so are their digits); digits: [element][Ls][L][n].  Key switch: Ls = L, sfirst = 0.
@@ -388,7 +409,7 @@ __global__ void __launch_bounds__(NT) k_gen_crt_digits(DevRing<W> R, GenDev<W> G
 // shifts), so no digit depends on the ones below it and the digits never exist in HBM untransformed (k_crt_base2_digits is the
 // two-power form).  digits: [element][D][L][n].
 template <typename W, int NT = GEN_T>
-__global__ void __launch_bounds__(NT) k_gen_crt_base2_digits(DevRing<W> R, GenDev<W> G, const W* __restrict__ xpow, W* __restrict__ digits,
+__global__ void __launch_bounds__(NT, 4) k_gen_crt_base2_digits(DevRing<W> R, GenDev<W> G, const W* __restrict__ xpow, W* __restrict__ digits,
                                                                 Scal<u32> first_digit, Scal<u32> kd, u32 D) {
     typedef typename Signed<W>::type SW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -475,7 +496,7 @@ __global__ void __launch_bounds__(GEN_KS_T, 4) k_gen_tensor_inv(DevRing<W> R, Ge
 }
 
 template <typename W>
-__global__ void __launch_bounds__(GEN_KS_T, 4) k_gen_ks(DevRing<W> R, GenDev<W> G, GenKsArgs<W> A) {
+__global__ void __launch_bounds__(GEN_KS_T, 2) k_gen_ks(DevRing<W> R, GenDev<W> G, GenKsArgs<W> A) {
     typedef typename Signed<W>::type SW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W* lds = reinterpret_cast<W*>(smem);
@@ -620,14 +641,14 @@ __device__ __forceinline__ void gen_column(W* __restrict__ x, u32 b, u32 s, int 
 }
 
 // the recurrence OP along every odd-prime axis of an LDS-resident limb-polynomial (ends with a barrier)
-template <typename W, bool ZDOM, int OP>
+template <typename W, bool ZDOM, int OP, int NT = GEN_T>
 __device__ __forceinline__ void gen_columns_lds(W* lds, const GenDev<W>& G, const ColArith<W, ZDOM>& A, u32 skip_mask) {
     const u32 n = G.n;
     for (int l = 0; l < G.nfact; ++l) {
         const GenFact f = G.fact[l];
         if (f.p == 2 || ((skip_mask >> l) & 1u)) continue;
         const u32 step = f.mp * f.rts, span = f.dim * f.rts, ncol = n / (u32)(f.p - 1);
-        for (u32 c = threadIdx.x; c < ncol; c += GEN_T) {
+        for (u32 c = threadIdx.x; c < ncol; c += NT) {
             const u32 o = c / step, in = c % step;
             gen_column<W, ZDOM, OP>(lds, o * span + in, step, f.p, A);
         }
@@ -683,8 +704,8 @@ __global__ void __launch_bounds__(GEN_T) k_gen_columns(DevRing<W> R, GenDev<W> G
 //   k_gen_rescale_keep  per (element, kept limb t):     the lift chain from res (element-wise, recomputed per kept limb),
 //                       the combination into LDS, (l,) crt, epilogue x_t C_t - . from the CRT-basis input
 // ------------------------------------------------------------------------------------------------------
-template <typename W>
-__global__ void __launch_bounds__(GEN_T, 4) k_gen_rescale_drop(DevRing<W> R, GenDev<W> G, const W* __restrict__ in, W* __restrict__ res,
+template <typename W, int NT = GEN_T>
+__global__ void __launch_bounds__(NT, 4) k_gen_rescale_drop(DevRing<W> R, GenDev<W> G, const W* __restrict__ in, W* __restrict__ res,
                                                             int ddn, int dec_c0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W* lds = reinterpret_cast<W*>(smem);
@@ -698,29 +719,29 @@ __global__ void __launch_bounds__(GEN_T, 4) k_gen_rescale_drop(DevRing<W> R, Gen
     typedef typename Vec4<W>::type V;
     constexpr u32 VL = Vec4<W>::LANES;
     const bool vec = n % VL == 0;                            // then every limb-polynomial starts 16-byte aligned
-    if (vec) for (u32 i = threadIdx.x * VL; i < n; i += GEN_T * VL) *reinterpret_cast<V*>(lds + i) = *reinterpret_cast<const V*>(src + i);
-    else for (u32 i = threadIdx.x; i < n; i += GEN_T) lds[i] = src[i];
+    if (vec) for (u32 i = threadIdx.x * VL; i < n; i += NT * VL) *reinterpret_cast<V*>(lds + i) = *reinterpret_cast<const V*>(src + i);
+    else for (u32 i = threadIdx.x; i < n; i += NT) lds[i] = src[i];
     lds_barrier();
-    gen_transform<W, true>(lds, G, u, q, qni);
+    gen_transform<W, true, NT>(lds, G, u, q, qni);
     if (dec_c0 && (e & 1) == 0) {                            // c0 is rescaled on the Dec basis
         ColArith<W, false> A{q, qni, R.mod[u].r2, 0};
-        gen_columns_lds<W, false, GEN_LINV>(lds, G, A, 0u);
+        gen_columns_lds<W, false, GEN_LINV, NT>(lds, G, A, 0u);
     }
     const W sc = G.iscale_m[u];                              // crtInv's closing scalar commutes with lInv
     if (vec) {
-        for (u32 i = threadIdx.x * VL; i < n; i += GEN_T * VL) {
+        for (u32 i = threadIdx.x * VL; i < n; i += NT * VL) {
             V v = *reinterpret_cast<const V*>(lds + i);
 #pragma unroll
             for (u32 c = 0; c < VL; ++c) v[c] = csub(mont_mul_lazy(v[c], sc, q, qni), q);
             *reinterpret_cast<V*>(dst + i) = v;
         }
     } else {
-        for (u32 i = threadIdx.x; i < n; i += GEN_T) dst[i] = csub(mont_mul_lazy(lds[i], sc, q, qni), q);
+        for (u32 i = threadIdx.x; i < n; i += NT) dst[i] = csub(mont_mul_lazy(lds[i], sc, q, qni), q);
     }
 }
 
-template <typename W>
-__global__ void __launch_bounds__(GEN_T) k_gen_rescale_keep(DevRing<W> R, GenDev<W> G, const W* __restrict__ in, const W* __restrict__ res,
+template <typename W, int NT = GEN_T>
+__global__ void __launch_bounds__(NT, 4) k_gen_rescale_keep(DevRing<W> R, GenDev<W> G, const W* __restrict__ in, const W* __restrict__ res,
                                                             W* __restrict__ out, DropTab<W> D, int dec_c0) {
     typedef typename Signed<W>::type SW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -756,7 +777,7 @@ __global__ void __launch_bounds__(GEN_T) k_gen_rescale_keep(DevRing<W> R, GenDev
         *acc = a;
     };
     if (vec) {
-        for (u32 k = threadIdx.x * VL; k < n; k += GEN_T * VL) {
+        for (u32 k = threadIdx.x * VL; k < n; k += NT * VL) {
             V in[MAXDROP], o;
 #pragma unroll
             for (int u = 0; u < MAXDROP; ++u) if (u < ddn) in[u] = *reinterpret_cast<const V*>(r0 + (size_t)u * n + k);
@@ -771,7 +792,7 @@ __global__ void __launch_bounds__(GEN_T) k_gen_rescale_keep(DevRing<W> R, GenDev
             *reinterpret_cast<V*>(lds + k) = o;
         }
     } else {
-        for (u32 k = threadIdx.x; k < n; k += GEN_T) {
+        for (u32 k = threadIdx.x; k < n; k += NT) {
             W y0[MAXDROP], a;
 #pragma unroll
             for (int u = 0; u < MAXDROP; ++u) y0[u] = u < ddn ? r0[(size_t)u * n + k] : (W)0;
@@ -782,14 +803,14 @@ __global__ void __launch_bounds__(GEN_T) k_gen_rescale_keep(DevRing<W> R, GenDev
     lds_barrier();
     if (dec_c0 && (e & 1) == 0) {                            // Dec -> Pow
         ColArith<W, false> A{q, qni, R.mod[t].r2, 0};
-        gen_columns_lds<W, false, GEN_L>(lds, G, A, 0u);
+        gen_columns_lds<W, false, GEN_L, NT>(lds, G, A, 0u);
     }
-    gen_transform<W, false>(lds, G, t, q, qni);
+    gen_transform<W, false, NT>(lds, G, t, q, qni);
     const W Ct = D.comb_m[0][t];
     const W* x = in + (e * (size_t)L + t) * (size_t)n;
     W* o = out + (e * (size_t)Lo + (t - ddn)) * (size_t)n;
     if (vec) {
-        for (u32 k = threadIdx.x * VL; k < n; k += GEN_T * VL) {
+        for (u32 k = threadIdx.x * VL; k < n; k += NT * VL) {
             const V xv = *reinterpret_cast<const V*>(x + k), lv = *reinterpret_cast<const V*>(lds + k);
             V r;
 #pragma unroll
@@ -797,7 +818,7 @@ __global__ void __launch_bounds__(GEN_T) k_gen_rescale_keep(DevRing<W> R, GenDev
             *reinterpret_cast<V*>(o + k) = r;
         }
     } else {
-        for (u32 k = threadIdx.x; k < n; k += GEN_T)
+        for (u32 k = threadIdx.x; k < n; k += NT)
             o[k] = csub((W)(csub(mont_mul_lazy(x[k], Ct, q, qni), q) + (q - lds[k])), q);
     }
 }
@@ -806,8 +827,8 @@ __global__ void __launch_bounds__(GEN_T) k_gen_rescale_keep(DevRing<W> R, GenDev
 // handed over in the Pow basis saves that tunnel's crtInv): per (element, kept limb) crtInv of the limb itself (+ lInv for c0),
 // z = x C_t - sum_u reduce_t(R_u) c_{u,t} coefficient-wise (crtInv's closing scalar folded into C_t), (l,) store.  Same number
 // of transforms as k_gen_rescale_keep (one per kept limb-polynomial), inverse instead of forward.
-template <typename W>
-__global__ void __launch_bounds__(GEN_T, 4) k_gen_rescale_keep_pow(DevRing<W> R, GenDev<W> G, const W* __restrict__ in, const W* __restrict__ res,
+template <typename W, int NT = GEN_T>
+__global__ void __launch_bounds__(NT, 4) k_gen_rescale_keep_pow(DevRing<W> R, GenDev<W> G, const W* __restrict__ in, const W* __restrict__ res,
                                                                    W* __restrict__ out, DropTab<W> D, int dec_c0) {
     typedef typename Signed<W>::type SW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -826,13 +847,13 @@ __global__ void __launch_bounds__(GEN_T, 4) k_gen_rescale_keep_pow(DevRing<W> R,
     constexpr u32 VL = Vec4<W>::LANES;
     const bool vec = n % VL == 0;
     const W* x = in + (e * (size_t)L + t) * (size_t)n;
-    if (vec) for (u32 i = threadIdx.x * VL; i < n; i += GEN_T * VL) *reinterpret_cast<V*>(lds + i) = *reinterpret_cast<const V*>(x + i);
-    else for (u32 i = threadIdx.x; i < n; i += GEN_T) lds[i] = x[i];
+    if (vec) for (u32 i = threadIdx.x * VL; i < n; i += NT * VL) *reinterpret_cast<V*>(lds + i) = *reinterpret_cast<const V*>(x + i);
+    else for (u32 i = threadIdx.x; i < n; i += NT) lds[i] = x[i];
     lds_barrier();
-    gen_transform<W, true>(lds, G, t, q, qni);
+    gen_transform<W, true, NT>(lds, G, t, q, qni);
     const bool dec = dec_c0 && (e & 1) == 0;
     ColArith<W, false> A{q, qni, R.mod[t].r2, 0};
-    if (dec) gen_columns_lds<W, false, GEN_LINV>(lds, G, A, 0u);
+    if (dec) gen_columns_lds<W, false, GEN_LINV, NT>(lds, G, A, 0u);
     const W scCt = csub(mont_mul_lazy(G.iscale_m[t], D.comb_m[0][t], q, qni), q);      // crtInv's closing scalar times C_t (Montgomery form)
     const W* r0 = res + (e * (size_t)ddn) * (size_t)n;
     auto combine = [&](const W* y0) -> W {                     // one coefficient: y0[u] = residue of dropped limb u
@@ -853,7 +874,7 @@ __global__ void __launch_bounds__(GEN_T, 4) k_gen_rescale_keep_pow(DevRing<W> R,
     };
     // every lane rewrites the words it read: no barrier between the column pass above and this loop is needed beyond the one it ends with
     if (vec) {
-        for (u32 k = threadIdx.x * VL; k < n; k += GEN_T * VL) {
+        for (u32 k = threadIdx.x * VL; k < n; k += NT * VL) {
             V rin[MAXDROP], z = *reinterpret_cast<const V*>(lds + k);
 #pragma unroll
             for (int u = 0; u < MAXDROP; ++u) if (u < ddn) rin[u] = *reinterpret_cast<const V*>(r0 + (size_t)u * n + k);
@@ -867,7 +888,7 @@ __global__ void __launch_bounds__(GEN_T, 4) k_gen_rescale_keep_pow(DevRing<W> R,
             *reinterpret_cast<V*>(lds + k) = z;
         }
     } else {
-        for (u32 k = threadIdx.x; k < n; k += GEN_T) {
+        for (u32 k = threadIdx.x; k < n; k += NT) {
             W y0[MAXDROP];
 #pragma unroll
             for (int u = 0; u < MAXDROP; ++u) y0[u] = u < ddn ? r0[(size_t)u * n + k] : (W)0;
@@ -875,25 +896,45 @@ __global__ void __launch_bounds__(GEN_T, 4) k_gen_rescale_keep_pow(DevRing<W> R,
         }
     }
     lds_barrier();
-    if (dec) gen_columns_lds<W, false, GEN_L>(lds, G, A, 0u);
+    if (dec) gen_columns_lds<W, false, GEN_L, NT>(lds, G, A, 0u);
     W* o = out + (e * (size_t)Lo + (t - ddn)) * (size_t)n;
-    if (vec) for (u32 i = threadIdx.x * VL; i < n; i += GEN_T * VL) *reinterpret_cast<V*>(o + i) = *reinterpret_cast<const V*>(lds + i);
-    else for (u32 i = threadIdx.x; i < n; i += GEN_T) o[i] = lds[i];
+    if (vec) for (u32 i = threadIdx.x * VL; i < n; i += NT * VL) *reinterpret_cast<V*>(o + i) = *reinterpret_cast<const V*>(lds + i);
+    else for (u32 i = threadIdx.x; i < n; i += NT) o[i] = lds[i];
+}
+
+// Threads per workgroup of the LDS-resident transform kernels.  The pass matrices live in SGPRs (gen_sym_pass), so the kernels need
+// ~50-60 VGPRs and four 512-thread workgroups (eight waves per SIMD) fit a CU whenever four polynomials fit its LDS; small rings
+// keep 2-wave workgroups, eight or more to a CU.
+template <typename W>
+inline int gen_threads(const GenDev<W>& G) {
+    if (G.nt == 128 || G.nt == 256 || G.nt == 512) return G.nt;
+    const size_t bytes = (size_t)G.n * sizeof(W);
+    return bytes <= 18432 ? GEN_T_SMALL : GEN_T;
+}
+
+template <typename W, int NT>
+inline hipError_t gen_launch_rescale_lin_nt(const DevRing<W>& R, const GenDev<W>& G, const W* in, W* res, W* out, const DropTab<W>& D,
+                                            int dec_c0, size_t nelem, hipStream_t stream, bool pow_out) {
+    const size_t lds_bytes = (size_t)G.n * sizeof(W);
+    auto k1 = k_gen_rescale_drop<W, NT>;
+    auto k2 = pow_out ? k_gen_rescale_keep_pow<W, NT> : k_gen_rescale_keep<W, NT>;
+    hipError_t e;
+    if ((e = set_lds(k1, lds_bytes)) != hipSuccess) return e;
+    if ((e = set_lds(k2, lds_bytes)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k1, dim3((unsigned)(nelem * (size_t)D.ddn)), dim3(NT), lds_bytes, stream, R, G, in, res, D.ddn, dec_c0);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(k2, dim3((unsigned)(nelem * (size_t)(R.L - D.ddn))), dim3(NT), lds_bytes, stream, R, G, in, res, out, D, dec_c0);
+    return hipGetLastError();
 }
 
 template <typename W>
 inline hipError_t gen_launch_rescale_lin(const DevRing<W>& R, const GenDev<W>& G, const W* in, W* res, W* out, const DropTab<W>& D,
                                          int dec_c0, size_t nelem, hipStream_t stream, bool pow_out = false) {
-    const size_t lds_bytes = (size_t)G.n * sizeof(W);
-    auto k1 = k_gen_rescale_drop<W>;
-    auto k2 = pow_out ? k_gen_rescale_keep_pow<W> : k_gen_rescale_keep<W>;
-    hipError_t e;
-    if ((e = set_lds(k1, lds_bytes)) != hipSuccess) return e;
-    if ((e = set_lds(k2, lds_bytes)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k1, dim3((unsigned)(nelem * (size_t)D.ddn)), dim3(GEN_T), lds_bytes, stream, R, G, in, res, D.ddn, dec_c0);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(k2, dim3((unsigned)(nelem * (size_t)(R.L - D.ddn))), dim3(GEN_T), lds_bytes, stream, R, G, in, res, out, D, dec_c0);
-    return hipGetLastError();
+    switch (gen_threads(G)) {
+    case 128: return gen_launch_rescale_lin_nt<W, 128>(R, G, in, res, out, D, dec_c0, nelem, stream, pow_out);
+    case 512: return gen_launch_rescale_lin_nt<W, 512>(R, G, in, res, out, D, dec_c0, nelem, stream, pow_out);
+    default: return gen_launch_rescale_lin_nt<W, 256>(R, G, in, res, out, D, dec_c0, nelem, stream, pow_out);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -909,40 +950,50 @@ inline hipError_t gen_launch_columns(const GenCall<W>& c, size_t lds_bytes) {
     return hipGetLastError();
 }
 
-template <typename W>
-inline hipError_t gen_run(const GenCall<W>& c) {
-    const size_t lds_bytes = (size_t)c.gen->n * sizeof(W);
-    // small rings (<= 18 KiB of LDS: E' of the reference's hops, H0') run 2-wave workgroups, eight to a CU: measured on H0' (phi = 4608)
-    // 18.6 against 20.7 ns per limb-polynomial; from phi = 5760 on the 4-wave form is faster (34 against 37 ns)
-    const bool small = (size_t)c.gen->n * sizeof(W) <= 18432;
-    const unsigned nt = small ? GEN_T_SMALL : GEN_T;
+template <typename W, int NT>
+inline hipError_t gen_run_nt(const GenCall<W>& c, size_t lds_bytes) {
     hipError_t e;
     switch (c.op) {
     case GEN_CRT: {
-        auto k = small ? k_gen_crt<W, false, GEN_T_SMALL> : k_gen_crt<W, false, GEN_T>;
+        auto k = k_gen_crt<W, false, NT>;
         if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(nt), lds_bytes, c.stream, *c.ring, *c.gen, c.data, c.src, c.first_poly);
+        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(NT), lds_bytes, c.stream, *c.ring, *c.gen, c.data, c.src, c.first_poly);
         break;
     }
     case GEN_CRTINV: {
-        auto k = small ? k_gen_crt<W, true, GEN_T_SMALL> : k_gen_crt<W, true, GEN_T>;
+        auto k = k_gen_crt<W, true, NT>;
         if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(nt), lds_bytes, c.stream, *c.ring, *c.gen, c.data, c.src, c.first_poly);
+        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(NT), lds_bytes, c.stream, *c.ring, *c.gen, c.data, c.src, c.first_poly);
         break;
     }
     case GEN_CRT_BASE2: {
-        auto k = small ? k_gen_crt_base2_digits<W, GEN_T_SMALL> : k_gen_crt_base2_digits<W, GEN_T>;
+        auto k = k_gen_crt_base2_digits<W, NT>;
         if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(nt), lds_bytes, c.stream, *c.ring, *c.gen, c.src, c.data, c.b2_first, c.b2_kd, c.b2_D);
+        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(NT), lds_bytes, c.stream, *c.ring, *c.gen, c.src, c.data, c.b2_first, c.b2_kd, c.b2_D);
         break;
     }
     case GEN_CRT_DIGITS: {
-        auto k = small ? k_gen_crt_digits<W, GEN_T_SMALL> : k_gen_crt_digits<W, GEN_T>;
+        auto k = k_gen_crt_digits<W, NT>;
         if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(nt), lds_bytes, c.stream, *c.ring, *c.gen, c.src, c.data, c.balanced ? 1 : 0, c.with_diag ? 1 : 0,
+        hipLaunchKernelGGL(k, dim3((unsigned)c.npoly), dim3(NT), lds_bytes, c.stream, *c.ring, *c.gen, c.src, c.data, c.balanced ? 1 : 0, c.with_diag ? 1 : 0,
                            c.src_limbs ? c.src_limbs : c.ring->L, c.src_first);
         break;
     }
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+template <typename W>
+inline hipError_t gen_run(const GenCall<W>& c) {
+    const size_t lds_bytes = (size_t)c.gen->n * sizeof(W);
+    switch (c.op) {
+    case GEN_CRT: case GEN_CRTINV: case GEN_CRT_BASE2: case GEN_CRT_DIGITS:
+        switch (gen_threads(*c.gen)) {
+        case 128: return gen_run_nt<W, 128>(c, lds_bytes);
+        case 512: return gen_run_nt<W, 512>(c, lds_bytes);
+        default: return gen_run_nt<W, 256>(c, lds_bytes);
+        }
     // npoly = number of (element, limb) workgroups; first_poly = first ELEMENT here
     case GEN_L: return c.zdom ? gen_launch_columns<W, true, GEN_L>(c, lds_bytes) : gen_launch_columns<W, false, GEN_L>(c, lds_bytes);
     case GEN_LINV: return c.zdom ? gen_launch_columns<W, true, GEN_LINV>(c, lds_bytes) : gen_launch_columns<W, false, GEN_LINV>(c, lds_bytes);

@@ -83,8 +83,9 @@ struct LaunchOpts {
     int ti_split = 1;        // n = 2^15 tensor kernel: 1 = split form, one workgroup per item; 0 = whole-polynomial kernel; > 1 = that many persistent workgroups
     int ti_grid = -1;        // whole-polynomial tensor kernel: -1 = one resident set of persistent workgroups, 0 = one workgroup per item, n > 0 = n workgroups
     int split_fused = 1;     // n = 2^16 (32-bit) / 2^15 (64-bit): digit transforms + hint products in one kernel (k_ks_accum_split)
-    int gen_fused = 0;       // general index: 1 = fused tensor + key switch kernels (kernel_gen.hpp).  Measured 0.69-0.82x the composed
-                             // path on H0'..H5' (48 accumulators + a CRT_13 pass spill at 128 VGPRs, 4-byte global accesses): off
+    int gen_fused = 1;       // general index: 1 = fused tensor + key switch kernels (kernel_gen.hpp).  Round 2 measured 0.69-0.82x the composed
+                             // path (48 accumulators + the CRT_13 pass matrices in VGPRs spilled); with the pass matrices in SGPRs (round 3) the
+                             // kernel needs 127 VGPRs, no scratch: 1.13x on H5', 1.24x on H3', 1.08x on H1', 0.99x on H0'  (key switch, L = 4)
     int crt_half = 1;        // crt / crtInv of a 128-KiB limb-polynomial: 1 = two half-size workgroups per CU (k_crt_half), 0 = k_crt
     int rs_half = 0;         // closing modSwitch at n = 2^15 (32-bit): 1 = always the two launches of half-size workgroups (kernel_rescale_half.hpp);
                              // 0 = only where k_rescale_out_lin cannot serve (three dropped limbs, unbalanced two-limb drops).  Measured on the

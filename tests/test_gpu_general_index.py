@@ -193,11 +193,14 @@ def test_ct_mod_switch_down_and_up(oracle_lib, m, L, drop):
         assert np.array_equal(up[e][:, drop:], mk(qs[drop:]).scale(got[e], [mult % q for q in qs[drop:]])), e
 
 
-def test_fused_general_key_switch_option(oracle_lib):
-    """gen_fused = 1 (two fused launches; slower than the composed path, kept as an option) gives the same bits."""
+@pytest.mark.parametrize("fused,nt", [(0, 0), (1, 0), (0, 128), (0, 512), (1, 512), (1, 256)])
+def test_general_key_switch_launch_options(oracle_lib, fused, nt):
+    """gen_fused (1 = the two fused launches, the default since round 3; 0 = the composed path) and gen_nt (threads per workgroup of
+    the transform kernels) are launch-structure options: the same bits either way, for keySwitchQuadCirc(a*b) and for PT2CT's
+    whole mul_ (4 -> 5 -> 3 limbs) on H5'."""
     m, qs, batch = 20475, RLWR_QS[:4], 3
     g, o = A.Ring(m, qs), oracle_lib.GenRing(m, qs)
-    g.set_option("gen_fused", 1)
+    g.set_option("gen_fused", fused); g.set_option("gen_nt", nt)
     rng = np.random.default_rng(77)
     hint, a, b = rand_elems(rng, 8, g.n, qs), rand_elems(rng, 2 * batch, g.n, qs), rand_elems(rng, 2 * batch, g.n, qs)
     gh, ga, gb, gout = g.hint_load(hint), g.upload(a), g.upload(b), g.alloc(2 * batch)
@@ -205,6 +208,20 @@ def test_fused_general_key_switch_option(oracle_lib):
     got = gout.download()
     for ct in range(batch):
         w0, w1 = o.ct_mul_relin(list(hint), a[2 * ct], a[2 * ct + 1], b[2 * ct], b[2 * ct + 1])
+        assert np.array_equal(got[2 * ct], w0) and np.array_equal(got[2 * ct + 1], w1), ct
+    from helpers import oracle_full_mul_general
+    qh = list(reversed(RLWR_QS[:5]))
+    rh, rin, rout = A.Ring(m, qh), A.Ring(m, qh[1:]), A.Ring(m, qh[2:])
+    for r in (rh, rin, rout):
+        r.set_option("gen_fused", fused); r.set_option("gen_nt", nt)
+    hint5 = rand_elems(rng, 10, rh.n, qh)
+    a4, b4 = rand_elems(rng, 2 * batch, rh.n, qh[1:]), rand_elems(rng, 2 * batch, rh.n, qh[1:])
+    s_pre = [int(rng.integers(1, q)) for q in qh[1:]]
+    out = rout.alloc(2 * batch)
+    capi.ct_mul_full(rh.hint_load(hint5), rin.upload(a4), rin.upload(b4), out, batch, s_pre=s_pre)
+    got = out.download()
+    for ct in range(batch):
+        w0, w1 = oracle_full_mul_general(oracle_lib, m, qh, 4, 3, list(hint5), a4[2 * ct], a4[2 * ct + 1], b4[2 * ct], b4[2 * ct + 1], s_pre)
         assert np.array_equal(got[2 * ct], w0) and np.array_equal(got[2 * ct + 1], w1), ct
 
 

@@ -11,6 +11,7 @@ QS = [1543651201, 689270401, 718099201, 720720001, 1556755201, 1567238401]
 H = [11648, 29120, 43680, 54600, 27300, 20475]
 SCR = int(os.environ.get('GEN_SCRATCH_MIB', '1024'))
 FUSED = int(os.environ.get('GEN_FUSED', '0'))
+NT = int(os.environ.get('GEN_NT', '0'))
 only = [int(x) for x in sys.argv[1:]] or H
 
 
@@ -26,7 +27,7 @@ for m in only:
     L = 4
     qs = QS[:L]
     g = A.Ring(m, qs)
-    g.set_option('scratch_mib', SCR); g.set_option('gen_fused', FUSED)
+    g.set_option('scratch_mib', SCR); g.set_option('gen_fused', FUSED); g.set_option('gen_nt', NT)
     n, E = g.n, 8192
     buf = g.alloc(E); buf.fill_uniform(1)
     t_f, t_i = timed(g, buf.crt), timed(g, buf.crtinv)
@@ -38,6 +39,7 @@ for m in only:
     qh = list(reversed(QS[:5]))
     rh, rin, rout = A.Ring(m, qh), A.Ring(m, qh[1:]), A.Ring(m, qh[2:])
     rh.set_option('scratch_mib', SCR); rh.set_option('gen_fused', FUSED)
+    for r_ in (rh, rin, rout): r_.set_option('gen_nt', NT)
     hs5 = rh.alloc(10); hs5.fill_uniform(5); hint5 = rh.hint_from_buf(hs5)
     a4, b4, o3 = rin.alloc(2 * B), rin.alloc(2 * B), rout.alloc(2 * B)
     a4.fill_uniform(6); b4.fill_uniform(7)
@@ -48,6 +50,7 @@ for m in only:
     if m != H[-1]:
         ms = H[H.index(m) + 1]
         gs = A.Ring(ms, qs)
+        gs.set_option('gen_nt', NT)
         ep, d_rel = A.Tunnel.info(g, gs)
         lin, ks = gs.alloc(d_rel), gs.alloc(2 * d_rel * L)
         lin.fill_uniform(8); ks.fill_uniform(9)

@@ -7,7 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from alchemy_amd.ringround import RingRound
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-rr = RingRound(B)
+import os
+NT = int(os.environ.get('GEN_NT', '0'))
+rr = RingRound(B, (('gen_nt', NT),) if NT else ())
 secs, out = rr.measure(passes=2)
 rr.stages.clear()
 rr.run(stage_times=True)
