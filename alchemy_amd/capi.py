@@ -31,7 +31,7 @@ SYMBOLS = [
     "alch_buf_divg", "alch_buf_mul_public", "alch_buf_add_public", "alch_select_limbs", "alch_modulus_units",
     "alch_tunnel_info", "alch_tunnel_create", "alch_tunnel_free", "alch_ct_tunnel", "alch_ct_mod_switch",
     "alch_buf_embed", "alch_buf_twace", "alch_buf_coeffs", "alch_embed_pow", "alch_embed_dec", "alch_embed_crt",
-    "alch_twace_pow_dec", "alch_twace_crt", "alch_coeffs", "alch_ext_table", "alch_crt_set_dec",
+    "alch_twace_pow_dec", "alch_twace_crt", "alch_coeffs", "alch_ext_table", "alch_crt_set_dec", "alch_ct_add_public",
 ]
 
 
@@ -140,6 +140,7 @@ def load_library():
         "alch_buf_decompose_triv": [VP, C.c_size_t, VP, C.c_size_t],
         "alch_buf_embed": [VP, VP, C.c_size_t, C.c_int], "alch_buf_twace": [VP, VP, C.c_size_t, C.c_int],
         "alch_buf_coeffs": [VP, VP, C.c_size_t],
+        "alch_ct_add_public": [VP, VP, C.c_size_t, PU64, VP, C.c_size_t],
         "alch_embed_pow": [VP, VP, P64, P64], "alch_embed_dec": [VP, VP, P64, P64], "alch_embed_crt": [VP, VP, P64, P64],
         "alch_twace_pow_dec": [VP, VP, P64, P64], "alch_twace_crt": [VP, VP, P64, P64], "alch_coeffs": [VP, VP, P64, P64],
         "alch_ext_table": [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_size_t)],
@@ -487,6 +488,10 @@ class Buf:
 
     def add_public(self, pub: "Buf", pub_index: int, batch: int):
         _check(self.ring._l.alch_buf_add_public(self._h, pub._h, pub_index, batch))
+
+    def ct_add_public(self, src: "Buf", batch: int, s, pub: "Buf", pub_index: int = 0):
+        """self = s * src with pub added to every c0: SymmSHE addPublic including its toLSD scalar, one pass."""
+        _check(self.ring._l.alch_ct_add_public(self._h, src._h, batch, _pu64(s) if s is not None else None, pub._h, pub_index))
 
     def embed_from(self, src_small: "Buf", count: int, basis: int):
         _check(self.ring._l.alch_buf_embed(self._h, src_small._h, count, basis))

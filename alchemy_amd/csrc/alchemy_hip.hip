@@ -549,6 +549,25 @@ __global__ void k_add_bcast(DevRing<W> R, W* dst, const W* pub, size_t cts) {
     }
 }
 
+// SymmSHE addPublic in one pass: dst = src * s_j, c0 components (even elements) += pub.  Element-major walk with VW-word pieces.
+template <typename W, int VW = 1>
+__global__ void k_scale_add_bcast(DevRing<W> R, W* dst, const W* src, const W* pub, size_t words, Scal<W> sm) {
+    typedef Pack<W, VW> P;
+    ALCH_WALK_INIT(R.n / VW, R.L);
+    ALCH_WALK(w, words / VW, wk) {
+        P x = reinterpret_cast<const P*>(src)[w];
+        const ModP<W> mp = R.mod[wk.mid];
+#pragma unroll
+        for (int c = 0; c < VW; ++c) x.v[c] = mont_mul(x.v[c], sm.v[wk.mid], mp);
+        if ((wk.outer & 1u) == 0) {
+            const P b = reinterpret_cast<const P*>(pub)[(size_t)wk.mid * (R.n / VW) + wk.k];
+#pragma unroll
+            for (int c = 0; c < VW; ++c) x.v[c] = add_mod(x.v[c], b.v[c], mp.q);
+        }
+        reinterpret_cast<P*>(dst)[w] = x;
+    }
+}
+
 // Tunnel, step 1: the E'-coefficients of (c0, c1) embedded into S' (coeffs + embedPow as one index gather; toMSD's
 // per-limb scalar folded in).  in: [ct][2][L - dup][n_r] -- the ciphertexts may live `dup` limbs below the tunnel's ring
 // (PT2CT's modSwitch_ in front of tunnel_, PT2CT.hs:224-229: x -> (0, q_a x), the factor folded into s_m by the host);
@@ -734,6 +753,8 @@ static int build_gen_ring(alch_ring* r, DevRing<W>& d, GenDev<W>& g) {
     for (int i = 0; i < h.npass; ++i) g.pass[i] = h.pass[i];
     for (int i = 0; i < h.nfact; ++i) g.fact[i] = h.fact[i];
     g.plain = (!r->has_crt && !r->zdom) ? 1 : 0;
+    g.smallq = r->has_crt ? 1 : 0;
+    for (int j = 0; j < L; ++j) if (r->q[j] >= 1753413056ull) g.smallq = 0;      // 6 q^2 < 2^64
     u64 maxhalf = 0;
     for (int j = 0; j < L; ++j) maxhalf = std::max(maxhalf, r->q[j] ? (r->q[j] - 1) / 2 : 0);
     if (!r->has_crt) {
@@ -1506,6 +1527,29 @@ extern "C" int alch_hint_free(alch_hint* h) {
     (void)hipStreamSynchronize(h->ring->stream);
     (void)hipFree(h->dptr);
     delete h;
+    return ALCH_OK;
+}
+
+extern "C" int alch_ct_add_public(alch_buf* dst, const alch_buf* src, size_t batch, const uint64_t* s, const alch_buf* pub, size_t pub_index) {
+    if (!dst || !src || !pub) return fail(ALCH_E_INVALID, "null buffer");
+    alch_ring* r = dst->ring;
+    if (src->ring != r || pub->ring != r) return fail(ALCH_E_INVALID, "buffers belong to different rings");
+    if (!r->has_crt) return fail(ALCH_E_UNSUPPORTED, "scalar products are implemented for rings with Montgomery constants (prime moduli) only");
+    if (2 * batch > dst->n_elems || 2 * batch > src->n_elems || pub_index >= pub->n_elems) return fail(ALCH_E_INVALID, "count out of bounds");
+    if (batch == 0) return ALCH_OK;
+    BIND(r);
+    const size_t words = 2 * batch * elem_words(r);
+    const char* pp = reinterpret_cast<const char*>(pub->dptr) + pub_index * elem_bytes(r);
+    if (r->word == 4) {
+        typedef u32 W;
+        Scal<W> sm; scal_to_mont<W>(r, s, 1, sm);
+        ALCH_LAUNCH_VW(k_scale_add_bcast, r, words, r->stream, r->d32, (W*)dst->dptr, (const W*)src->dptr, (const W*)pp, words, sm);
+    } else {
+        typedef u64 W;
+        Scal<W> sm; scal_to_mont<W>(r, s, 1, sm);
+        ALCH_LAUNCH_VW(k_scale_add_bcast, r, words, r->stream, r->d64, (W*)dst->dptr, (const W*)src->dptr, (const W*)pp, words, sm);
+    }
+    HIP_TRY(hipGetLastError());
     return ALCH_OK;
 }
 

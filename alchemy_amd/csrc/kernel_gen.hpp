@@ -68,6 +68,7 @@ struct GenDev {
     const W* gcrt_inv[MAXL];
     W radinv_m[MAXL];                    // (odd radical of m)^-1 mod q_j in Montgomery form; 0 = not a unit (divG fails)
     u32 rad;
+    int smallq;                          // every modulus < 2^32 / sqrt(6): six-term lazy accumulation in the p = 13 passes (dense_row)
     int nt;                              // host side: threads per workgroup of the transform kernels (0 = by ring size: gen_threads)
     int plain;                           // ring without CRT over an arbitrary modulus 2 <= q < 2^31 (Lol: a plaintext ring
                                          // Z_p): no Montgomery constants, products by `%`; radinv_m is then a plain residue
@@ -115,22 +116,28 @@ hipError_t gen_ks_dispatch(const DevRing<u64>& R, const GenDev<u64>& G, const Ge
 // 32-bit words: four products are summed in 64 bits before one reduction -- 4 q^2 < 2^64, the sum's high word is < 2q, one
 // conditional subtraction brings the sum below q 2^32, then a single Montgomery reduction: 10 instructions per four terms
 // instead of 20.  64-bit words: one product at a time.
-template <int R, typename MP>
+// SMALLQ (every modulus of the ring below 2^32 / sqrt(6) = 1 753 413 056: all of the reference's): up to SIX products are summed
+// before one reduction -- 6 q^2 < 2^64, the sum's high word is < 2.2 q and takes two conditional subtractions (2q, q).  One
+// Montgomery reduction per row of a CRT_13 / DFT_13 half-matrix instead of two: 14 instructions per row instead of 21.
+template <int R, bool SMALLQ = false, typename MP>
 __device__ __forceinline__ u32 dense_row(const u32* x, MP M, u32 q, u32 qni) {
+    constexpr int CH = SMALLQ ? 6 : 4;
     u32 acc = 0;
 #pragma unroll
-    for (int t0 = 0; t0 < R; t0 += 4) {
+    for (int t0 = 0; t0 < R; t0 += CH) {
         u64 p = (u64)x[t0] * M[t0];
 #pragma unroll
-        for (int t = t0 + 1; t < t0 + 4 && t < R; ++t) p += (u64)x[t] * M[t];
-        const u64 pr = ((u64)csub((u32)(p >> 32), q) << 32) | (u32)p;          // high word < 2q -> < q
+        for (int t = t0 + 1; t < t0 + CH && t < R; ++t) p += (u64)x[t] * M[t];
+        u32 hi = (u32)(p >> 32);
+        if (SMALLQ && R - t0 > 4) hi = csub(hi, 2u * q);                        // more than four terms: high word < 2.2 q
+        const u64 pr = ((u64)csub(hi, q) << 32) | (u32)p;                        // high word < 2q -> < q
         const u32 m = (u32)pr * qni;
         const u32 v = csub((u32)((pr + (u64)m * q) >> 32), q);
         acc = t0 ? csub(acc + v, q) : v;
     }
     return acc;
 }
-template <int R, typename MP>
+template <int R, bool SMALLQ = false, typename MP>
 __device__ __forceinline__ u64 dense_row(const u64* x, MP M, u64 q, u64 qni) {
     u64 acc = csub(mont_mul_lazy(x[0], M[0], q, qni), q);
 #pragma unroll
@@ -149,7 +156,7 @@ template <typename W> __device__ __forceinline__ W gmul(W a, W b, W q, W qni) { 
 //   forward CRT_p : inputs x_0..x_{p-2} (x_{p-1} = 0), outputs y_1..y_{p-1} at slots 0..p-2
 //   inverse CRT_p : y_0 = -sum_i y_i w^i (the condition x_{p-1} = 0), then the inverse DFT_p (w -> w^-1, a, b, carry 1/p)
 //   forward DFT_p : y_0 = sum_j x_j as well;  inverse DFT_p : the same with w^-1 and 1/p
-template <typename W, int NT, int P, bool IS_DFT, bool INV>
+template <typename W, int NT, int P, bool IS_DFT, bool INV, bool SMALLQ = false>
 __device__ __forceinline__ void gen_sym_pass(W* __restrict__ lds, const GenPass& Ps, const W* __restrict__ tab, u32 n, W q, W qni) {
     constexpr int H = (P - 1) / 2, R = IS_DFT ? P : P - 1;
     // CRT_p passes never carry twiddles, DFT_p passes always do (gen_plan): a compile-time fact, so the per-element loads below are
@@ -176,7 +183,19 @@ __device__ __forceinline__ void gen_sym_pass(W* __restrict__ lds, const GenPass&
         //   forward CRT_p: in_0..in_{p-2} = x, in_{p-1} = 0;  inverse CRT_p: in_0 = y_0 (below), in_1.. = x;  DFT_p: in = x
         constexpr int OFF = (!IS_DFT && INV) ? 1 : 0;
         W x[R];
-        {   // element t at base + t stride: one running address, one add per element
+        typedef typename Vec4<W>::type V;
+        constexpr int VL = Vec4<W>::LANES;
+        // innermost axis (stride 1, every index of the reference ends in p = 13: R = 12): the group is R contiguous words, moved as
+        // 16-byte pieces -- the 4-byte form is 4-way bank-conflicted there (lane stride R words)
+        const bool contiguous = R % VL == 0 && stride == 1;
+        if (contiguous) {
+#pragma unroll
+            for (int t = 0; t < R; t += VL) {
+                const V v = *reinterpret_cast<const V*>(lds + base + t);
+#pragma unroll
+                for (int c = 0; c < VL; ++c) x[t + c] = v[c];
+            }
+        } else {   // element t at base + t stride: one running address, one add per element
             W* pe = lds + base;
 #pragma unroll
             for (int t = 0; t < R; ++t) { x[t] = *pe; pe += stride; }
@@ -187,7 +206,7 @@ __device__ __forceinline__ void gen_sym_pass(W* __restrict__ lds, const GenPass&
             for (int t = 0; t < R; ++t) { x[t] = gmul(x[t], *pt, q, qni); pt += step; }
         }
         W in0;
-        if (!IS_DFT && INV) in0 = dense_row<P - 1>(x, T + 2 * H * H, q, qni);          // y_0 = sum_i y_i (-w^i)
+        if (!IS_DFT && INV) in0 = dense_row<P - 1, SMALLQ>(x, T + 2 * H * H, q, qni);          // y_0 = sum_i y_i (-w^i)
         else in0 = x[0];
         auto in = [&](int t) -> W { return t == 0 ? in0 : (t - OFF < R ? x[t - OFF] : (W)0); };
         W u[H], v[H];
@@ -215,8 +234,8 @@ __device__ __forceinline__ void gen_sym_pass(W* __restrict__ lds, const GenPass&
         put(0, sum);
 #pragma unroll
         for (int i = 1; i <= H; ++i) {
-            const W A = gadd(u0, dense_row<H>(u, a + (i - 1) * H, q, qni), q);
-            const W B = dense_row<H>(v, b + (i - 1) * H, q, qni);
+            const W A = gadd(u0, dense_row<H, SMALLQ>(u, a + (i - 1) * H, q, qni), q);
+            const W B = dense_row<H, SMALLQ>(v, b + (i - 1) * H, q, qni);
             put(i, gadd(A, B, q));
             put(P - i, gsub(A, B, q));
         }
@@ -225,7 +244,15 @@ __device__ __forceinline__ void gen_sym_pass(W* __restrict__ lds, const GenPass&
 #pragma unroll
             for (int t = 0; t < R; ++t) { y[t] = gmul(y[t], *pt, q, qni); pt += step; }
         }
-        {
+        if (contiguous) {
+#pragma unroll
+            for (int t = 0; t < R; t += VL) {
+                V v;
+#pragma unroll
+                for (int c = 0; c < VL; ++c) v[c] = y[t + c];
+                *reinterpret_cast<V*>(lds + base + t) = v;
+            }
+        } else {
             W* pe = lds + base;
 #pragma unroll
             for (int t = 0; t < R; ++t) { *pe = y[t]; pe += stride; }
@@ -281,7 +308,7 @@ __device__ __forceinline__ void gen_r2block_pass(W* __restrict__ lds, const GenP
 }
 
 template <typename W, int NT, bool INV>
-__device__ __forceinline__ void gen_run_pass(W* lds, const GenPass& P, const W* tab, u32 n, W q, W qni) {
+__device__ __forceinline__ void gen_run_pass(W* lds, const GenPass& P, const W* tab, u32 n, W q, W qni, int smallq) {
     if (P.kind == GK_R2BLOCK) {                    // every branch here is wave-uniform
         if (P.r == 8) gen_r2block_pass<W, NT, 3, INV>(lds, P, tab, n, q, qni);
         else if (P.r == 4) gen_r2block_pass<W, NT, 2, INV>(lds, P, tab, n, q, qni);
@@ -295,7 +322,10 @@ __device__ __forceinline__ void gen_run_pass(W* lds, const GenPass& P, const W* 
         case 5: gen_sym_pass<W, NT, 5, false, INV>(lds, P, tab, n, q, qni); break;
         case 7: gen_sym_pass<W, NT, 7, false, INV>(lds, P, tab, n, q, qni); break;
         case 11: gen_sym_pass<W, NT, 11, false, INV>(lds, P, tab, n, q, qni); break;
-        case 13: gen_sym_pass<W, NT, 13, false, INV>(lds, P, tab, n, q, qni); break;
+        case 13:                                   // (wave-uniform: the ring's moduli decide)
+            if (sizeof(W) == 4 && smallq) gen_sym_pass<W, NT, 13, false, INV, true>(lds, P, tab, n, q, qni);
+            else gen_sym_pass<W, NT, 13, false, INV>(lds, P, tab, n, q, qni);
+            break;
         default: break;                            // the host refuses indices with other odd primes
         }
     } else {
@@ -304,7 +334,10 @@ __device__ __forceinline__ void gen_run_pass(W* lds, const GenPass& P, const W* 
         case 5: gen_sym_pass<W, NT, 5, true, INV>(lds, P, tab, n, q, qni); break;
         case 7: gen_sym_pass<W, NT, 7, true, INV>(lds, P, tab, n, q, qni); break;
         case 11: gen_sym_pass<W, NT, 11, true, INV>(lds, P, tab, n, q, qni); break;
-        case 13: gen_sym_pass<W, NT, 13, true, INV>(lds, P, tab, n, q, qni); break;
+        case 13:
+            if (sizeof(W) == 4 && smallq) gen_sym_pass<W, NT, 13, true, INV, true>(lds, P, tab, n, q, qni);
+            else gen_sym_pass<W, NT, 13, true, INV>(lds, P, tab, n, q, qni);
+            break;
         default: break;
         }
     }
@@ -314,9 +347,9 @@ __device__ __forceinline__ void gen_run_pass(W* lds, const GenPass& P, const W* 
 template <typename W, bool INV, int NT = GEN_T>
 __device__ __forceinline__ void gen_transform(W* lds, const GenDev<W>& G, int j, W q, W qni) {
     if (!INV) {
-        for (int ps = 0; ps < G.npass; ++ps) { gen_run_pass<W, NT, false>(lds, G.pass[ps], G.tabf[j], G.n, q, qni); lds_barrier(); }
+        for (int ps = 0; ps < G.npass; ++ps) { gen_run_pass<W, NT, false>(lds, G.pass[ps], G.tabf[j], G.n, q, qni, G.smallq); lds_barrier(); }
     } else {
-        for (int ps = G.npass - 1; ps >= 0; --ps) { gen_run_pass<W, NT, true>(lds, G.pass[ps], G.tabi[j], G.n, q, qni); lds_barrier(); }
+        for (int ps = G.npass - 1; ps >= 0; --ps) { gen_run_pass<W, NT, true>(lds, G.pass[ps], G.tabi[j], G.n, q, qni, G.smallq); lds_barrier(); }
     }
 }
 

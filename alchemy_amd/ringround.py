@@ -5,8 +5,9 @@ H0' .. H5' (examples/Common.hs:49-54,78-95), then rescaleTreePow2 (Language/Resc
 leaves (addPublic + div2), 4 + 2 + 1 pairwise mul_ each followed by div2.  This module issues exactly those library
 calls on a batch of ciphertexts that stays in HBM, with the limb counts PT2CT's type-level rules pick
 (alch_select_limbs, SURVEY 3.3: tunnels 5/6/5 .. 5/5/4, products 4/5/3, 3/4/2, 2/3/1, 1/2/1) and the HomomRLWR moduli
-(examples/HomomRLWR.hs:37-43).  Residues and hints are synthetic: throughput does not need valid encryptions;
-bit-exactness of every op is covered by the parity tests, the op ORDER by tests/test_gpu_homomrlwr_mini.py.
+(examples/HomomRLWR.hs:37-43).  Residues and hints are synthetic: throughput does not need valid encryptions (examples/homomrlwr_replay.cpp runs the same
+sequence with real keys, hints and encryptions to the example's PASS); every bit of the result batch is checked against the C
+restatement's replay of the op-by-op sequence (tests/ringround_oracle.py, bench.py's homomrlwr.batch_checksum).
 Used by bench.py (extra field `homomrlwr`) and tools/bench_homomrlwr.py."""
 import time
 
@@ -95,14 +96,25 @@ class RingRound:
             self.stages[name] = self.stages.get(name, 0.0) + time.perf_counter() - t0
             return v
 
-        # fresh ciphertexts over H0', mulPublic a
-        r0 = ring(HP[0], tuns[0][0])
+        # Per-limb scalars (toLSD / toMSD of SymmSHE, div2's 2^-1) are not run as passes of their own: a ciphertext batch carries
+        # a pending scalar `pend` that the next kernel taking a per-limb scalar absorbs (the tensor product's s_pre, addPublic's
+        # fused scalar, the public element of mulPublic).  Arithmetic in Z_q is exact, so the results are bit for bit those of the
+        # op-by-op sequence (tests/ringround_oracle.py replays that one).
+        def mulv(a, b, L):
+            return [x * y % q for x, y, q in zip(a, b, moduli(L))]
+
+        # fresh ciphertexts over H0', mulPublic a (times toMSD's scalar: folded into the one public element)
+        L_0 = tuns[0][0]
+        r0 = ring(HP[0], L_0)
         self.cursor = 0
         if "x" not in self.pubs:
             self.pubs["x"] = self.seeded(r0, 2 * B, 1)
-        x, pub, x1 = self.pubs["x"], public(r0, 2), scratch(r0, 2 * B)
-        timed("mulPublic", r0, lambda: (x1.mul_public(x, pub, 0, 2 * B),
-                                        x1.scale(x1, 2 * B, [pow(P, -1, q) for q in moduli(tuns[0][0])])))
+        if "pub_msd" not in self.pubs:
+            ps = r0.alloc(1)
+            ps.scale(public(r0, 2), 1, [pow(P, -1, q) for q in moduli(L_0)])
+            self.pubs["pub_msd"] = ps
+        x, x1 = self.pubs["x"], scratch(r0, 2 * B)
+        timed("mulPublic", r0, lambda: x1.mul_public(x, self.pubs["pub_msd"], 0, 2 * B))
         cur = x1
         for k in range(5):
             lin_, lh_, lout_ = tuns[k]
@@ -125,34 +137,37 @@ class RingRound:
         # rescale tree on H5'
         m5 = HP[5]
 
-        def product(level, a, b):
+        def product(level, a, pa, b, pb):
+            """mul_ of (a, pending pa) and (b, pending pb): the product's own toMSD scalar P^-1 and both pending scalars ride on s_pre."""
             lin_, _, lout_ = muls[level]
             o = scratch(ring(m5, lout_), 2 * B)
-            capi.ct_mul_full(self.quads[level], a, b, o, B, s_pre=[pow(P, -1, q) for q in moduli(lin_)])
+            capi.ct_mul_full(self.quads[level], a, b, o, B, s_pre=mulv(mulv(pa, pb, lin_), [pow(P, -1, q) for q in moduli(lin_)], lin_))
             return o
 
-        def plus_public(src, L, seed):                 # toLSD, addPublic, back to MSD (div2_'s modSwitchPT) -- element-wise
+        def plus_public(src, ps, L, seed):             # toLSD, addPublic (div2_'s modSwitchPT is metadata) -- one fused pass
             r = ring(m5, L)
             o = scratch(r, 2 * B)
-            o.scale(src, 2 * B, [P % q for q in moduli(L)])
-            o.add_public(public(r, seed), 0, B)
+            o.ct_add_public(src, B, mulv(ps, [P % q for q in moduli(L)], L), public(r, seed), 0)
             return o
 
         L0 = muls[0][0]
+        one0 = [1] * L0
 
-        def level0():
-            x_lsd = scratch(ring(m5, L0), 2 * B); x_lsd.scale(cur, 2 * B, [P % q for q in moduli(L0)])
-            return product(0, x_lsd, plus_public(cur, L0, 50))
+        def level0():                                   # x_lsd = P x stays pending on x itself
+            return product(0, cur, [P % q for q in moduli(L0)], plus_public(cur, one0, L0, 50), one0)
         y = timed("x(1+x)", ring(m5, muls[0][1]), level0)
         L1 = muls[1][0]
-        t = timed("leaves(addPublic,div2)", ring(m5, L1), lambda: [plus_public(y, L1, 60 + i) for i in range(8)])
+        one1 = [1] * L1
+        t = timed("leaves(addPublic,div2)", ring(m5, L1), lambda: [plus_public(y, one1, L1, 60 + i) for i in range(8)])
 
         def tree(t=t):
+            pend = one1
             for level in (1, 2, 3):
-                t = [product(level, t[2 * i], t[2 * i + 1]) for i in range(len(t) // 2)]
-                for o in t:                             # div2_: toMSD scalar, plaintext modulus halves (metadata)
-                    o.scale(o, 2 * B, [pow(2, -1, q) for q in moduli(muls[level][2])])
-            return t[0]
+                t = [product(level, t[2 * i], pend, t[2 * i + 1], pend) for i in range(len(t) // 2)]
+                pend = [pow(2, -1, q) for q in moduli(muls[level][2])]          # div2_: toMSD scalar, plaintext modulus halves (metadata)
+            res = t[0]
+            res.scale(res, 2 * B, pend)                 # the last div2's scalar: nothing follows that could absorb it
+            return res
         return timed("tree(4+2+1 mul_, div2)", ring(m5, muls[3][1]), tree)
 
     def measure(self, passes=1):

@@ -98,6 +98,7 @@ foreign import ccall safe   "alch_buf_add_public"      c_bufAddPublic    :: Ptr 
 foreign import ccall safe   "alch_buf_embed"           c_bufEmbed        :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> CInt -> IO CInt
 foreign import ccall safe   "alch_buf_twace"           c_bufTwace        :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> CInt -> IO CInt
 foreign import ccall safe   "alch_buf_coeffs"          c_bufCoeffs       :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> IO CInt
+foreign import ccall safe   "alch_ct_add_public"       c_ctAddPublic     :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> Ptr Word64 -> Ptr AlchBuf -> CSize -> IO CInt
 foreign import ccall safe   "alch_buf_checksum"        c_bufChecksum     :: Ptr AlchBuf -> CSize -> CSize -> Ptr Word64 -> IO CInt
 foreign import ccall safe   "alch_buf_rescale_drop0"   c_bufRescaleDrop0 :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> IO CInt
 foreign import ccall safe   "alch_buf_rescale_add0"    c_bufRescaleAdd0  :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> IO CInt

@@ -205,6 +205,10 @@ int alch_buf_mul_public(alch_buf *dst, const alch_buf *src, const alch_buf *pub,
 /* SymmSHE addPublic (Eval.hs:131; PT2CT.hs:114-118 uses it for constants): cts[2b] += pub[pub_index] for b < batch
  * (c0 of every linear ciphertext; `pub` = the public element times l^-1 g^k, embedded, in the basis of cts). */
 int alch_buf_add_public(alch_buf *cts, const alch_buf *pub, size_t pub_index, size_t batch);
+/* SymmSHE addPublic with its encoding change as ONE pass (Eval.hs:131: addPublic works on the LSD form, i.e. toLSD's per-limb scalar
+ * comes first): dst[e] = src[e] * s_j for every element e < 2*batch, then c0 components (even e) += pub[pub_index].  s = NULL: no
+ * scalar.  dst may equal src.  Same results as alch_buf_scale followed by alch_buf_add_public. */
+int alch_ct_add_public(alch_buf *dst, const alch_buf *src, size_t batch, const uint64_t *s, const alch_buf *pub, size_t pub_index);
 /* Device-resident Lol `decompose` (TrivGad) + `reduce`: element `src_index` of src (Pow basis) -> L digit
  * elements written to dst[dst_first .. dst_first+L) (Pow basis). */
 int alch_buf_decompose_triv(const alch_buf *src, size_t src_index, alch_buf *dst, size_t dst_first);

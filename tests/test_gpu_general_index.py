@@ -240,6 +240,16 @@ def test_public_ops_general_index(oracle_lib):
     for ct in range(batch):
         want[2 * ct] = o.add(cts[2 * ct], pub[0])
     assert np.array_equal(gc.download(), want)
+    # addPublic with its toLSD scalar as one pass (alch_ct_add_public) == scale, then add_public
+    sc = [int(rng.integers(1, q)) for q in qs]
+    ge = g.alloc(2 * batch)
+    ge.ct_add_public(gc, batch, sc, gp, 1)
+    ref = g.alloc(2 * batch)
+    ref.scale(gc, 2 * batch, sc); ref.add_public(gp, 1, batch)
+    assert np.array_equal(ge.download(), ref.download())
+    ge.ct_add_public(gc, batch, None, gp, 0)
+    gc.add_public(gp, 0, batch)
+    assert np.array_equal(ge.download(), gc.download())
 
 
 def test_sixty_bit_moduli_general_index(oracle_lib):

@@ -10,7 +10,7 @@ from alchemy_amd import capi
 QS = [1543651201, 689270401, 718099201, 720720001, 1556755201, 1567238401]
 H = [11648, 29120, 43680, 54600, 27300, 20475]
 SCR = int(os.environ.get('GEN_SCRATCH_MIB', '1024'))
-FUSED = int(os.environ.get('GEN_FUSED', '0'))
+FUSED = int(os.environ.get('GEN_FUSED', '1'))
 NT = int(os.environ.get('GEN_NT', '0'))
 only = [int(x) for x in sys.argv[1:]] or H
 
