@@ -503,10 +503,14 @@ struct GenKsArgs {
     int use_g;               // index has odd prime factors: mulG is not the identity
 };
 
-template <typename W>
+// VEC: the ring dimension is a multiple of the 16-byte vector width (every index of the reference): all global and LDS traffic of
+// both kernels moves 16-byte pieces, a lane owning VL consecutive slots; else one word at a time.
+template <typename W, bool VEC>
 __global__ void __launch_bounds__(GEN_KS_T, 4) k_gen_tensor_inv(DevRing<W> R, GenDev<W> G, GenKsArgs<W> A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W* lds = reinterpret_cast<W*>(smem);
+    typedef typename Vec4<W>::type V;
+    constexpr u32 VL = VEC ? Vec4<W>::LANES : 1;
     const int L = R.L, Ls = L - A.dup;
     const size_t ct = blockIdx.x / (unsigned)Ls;
     const int is = (int)(blockIdx.x % (unsigned)Ls), i = is + A.dup;
@@ -516,23 +520,48 @@ __global__ void __launch_bounds__(GEN_KS_T, 4) k_gen_tensor_inv(DevRing<W> R, Ge
     const W* b1 = A.b + ((2 * ct + 1) * (size_t)Ls + is) * n;
     const W* g = G.gcrt[i];
     const W sr2 = A.sr2.v[is];
-    for (u32 k = threadIdx.x; k < n; k += GEN_KS_T) {
-        W v = gmul(gmul(a1[k], sr2, q, qni), b1[k], q, qni);
-        if (A.use_g) v = gmul(v, g[k], q, qni);
-        lds[k] = v;
+    for (u32 k = threadIdx.x * VL; k < n; k += GEN_KS_T * VL) {
+        if constexpr (VEC) {
+            const V av = *reinterpret_cast<const V*>(a1 + k), bv = *reinterpret_cast<const V*>(b1 + k);
+            V gv = av, o;
+            if (A.use_g) gv = *reinterpret_cast<const V*>(g + k);
+#pragma unroll
+            for (u32 e = 0; e < VL; ++e) {
+                W v = gmul(gmul(av[e], sr2, q, qni), bv[e], q, qni);
+                if (A.use_g) v = gmul(v, gv[e], q, qni);
+                o[e] = v;
+            }
+            *reinterpret_cast<V*>(lds + k) = o;
+        } else {
+            W v = gmul(gmul(a1[k], sr2, q, qni), b1[k], q, qni);
+            if (A.use_g) v = gmul(v, g[k], q, qni);
+            lds[k] = v;
+        }
     }
     lds_barrier();
     gen_transform<W, true, GEN_KS_T>(lds, G, i, q, qni);
     const W sc = G.iscale_m[i];
     W* dst = A.c2pow + (ct * (size_t)Ls + is) * n;
-    for (u32 k = threadIdx.x; k < n; k += GEN_KS_T) dst[k] = gmul(lds[k], sc, q, qni);
+    for (u32 k = threadIdx.x * VL; k < n; k += GEN_KS_T * VL) {
+        if constexpr (VEC) {
+            V v = *reinterpret_cast<const V*>(lds + k);
+#pragma unroll
+            for (u32 e = 0; e < VL; ++e) v[e] = gmul(v[e], sc, q, qni);
+            *reinterpret_cast<V*>(dst + k) = v;
+        } else {
+            dst[k] = gmul(lds[k], sc, q, qni);
+        }
+    }
 }
 
-template <typename W>
+template <typename W, bool VEC>
 __global__ void __launch_bounds__(GEN_KS_T, 2) k_gen_ks(DevRing<W> R, GenDev<W> G, GenKsArgs<W> A) {
     typedef typename Signed<W>::type SW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     W* lds = reinterpret_cast<W*>(smem);
+    typedef typename Vec4<W>::type V;
+    constexpr int VL = VEC ? Vec4<W>::LANES : 1;
+    constexpr int NP = GEN_KS_NPT / VL;                       // pieces per lane; slot of (piece kk, element e) = (tid + kk T) VL + e
     const int L = R.L, Ls = L - A.dup;
     const size_t ct = blockIdx.x / (unsigned)L;
     const int j = (int)(blockIdx.x % (unsigned)L), js = j - A.dup;
@@ -540,11 +569,19 @@ __global__ void __launch_bounds__(GEN_KS_T, 2) k_gen_ks(DevRing<W> R, GenDev<W> 
     const W q = R.mod[j].q, qni = R.mod[j].qni;
     const size_t Ln = (size_t)L * n;
     const W* hj = A.hint + (size_t)j * n;                    // + (2 i + c) * Ln
-    W acc0[GEN_KS_NPT], acc1[GEN_KS_NPT];
-    if (js < 0) {
+    auto ld = [&](const W* p, u32 s, W (&o)[VL]) {            // VL consecutive words at p + s
+        if constexpr (VEC) {
+            const V v = *reinterpret_cast<const V*>(p + s);
 #pragma unroll
-        for (int k = 0; k < GEN_KS_NPT; ++k) { acc0[k] = 0; acc1[k] = 0; }
-    } else {
+            for (int e = 0; e < VL; ++e) o[e] = v[e];
+        } else o[0] = p[s];
+    };
+    W acc0[NP][VL], acc1[NP][VL];
+#pragma unroll
+    for (int kk = 0; kk < NP; ++kk)
+#pragma unroll
+        for (int e = 0; e < VL; ++e) { acc0[kk][e] = 0; acc1[kk][e] = 0; }
+    if (js >= 0) {
         const size_t o = (size_t)js * n;
         const W* a0 = A.a + (2 * ct) * (size_t)Ls * n + o;
         const W* a1 = A.a + (2 * ct + 1) * (size_t)Ls * n + o;
@@ -555,17 +592,22 @@ __global__ void __launch_bounds__(GEN_KS_T, 2) k_gen_ks(DevRing<W> R, GenDev<W> 
         const W* g = G.gcrt[j];
         const W sr2 = A.sr2.v[js];
 #pragma unroll
-        for (int k = 0; k < GEN_KS_NPT; ++k) {
-            const u32 s = threadIdx.x + (u32)k * GEN_KS_T;
-            acc0[k] = 0; acc1[k] = 0;
+        for (int kk = 0; kk < NP; ++kk) {
+            const u32 s = (threadIdx.x + (u32)kk * GEN_KS_T) * VL;
             if (s < n) {
-                const W x0 = gmul(a0[s], sr2, q, qni), x1 = gmul(a1[s], sr2, q, qni);
-                W c0 = gmul(x0, b0[s], q, qni);
-                W c1 = gadd(gmul(x0, b1[s], q, qni), gmul(x1, b0[s], q, qni), q);
-                W c2 = gmul(x1, b1[s], q, qni);
-                if (A.use_g) { const W gv = g[s]; c0 = gmul(c0, gv, q, qni); c1 = gmul(c1, gv, q, qni); c2 = gmul(c2, gv, q, qni); }
-                acc0[k] = gadd(c0, gmul(c2, h0[s], q, qni), q);
-                acc1[k] = gadd(c1, gmul(c2, h1[s], q, qni), q);
+                W va0[VL], va1[VL], vb0[VL], vb1[VL], vg[VL], vh0[VL], vh1[VL];
+                ld(a0, s, va0); ld(a1, s, va1); ld(b0, s, vb0); ld(b1, s, vb1); ld(h0, s, vh0); ld(h1, s, vh1);
+                if (A.use_g) ld(g, s, vg);
+#pragma unroll
+                for (int e = 0; e < VL; ++e) {
+                    const W x0 = gmul(va0[e], sr2, q, qni), x1 = gmul(va1[e], sr2, q, qni);
+                    W c0 = gmul(x0, vb0[e], q, qni);
+                    W c1 = gadd(gmul(x0, vb1[e], q, qni), gmul(x1, vb0[e], q, qni), q);
+                    W c2 = gmul(x1, vb1[e], q, qni);
+                    if (A.use_g) { const W gv = vg[e]; c0 = gmul(c0, gv, q, qni); c1 = gmul(c1, gv, q, qni); c2 = gmul(c2, gv, q, qni); }
+                    acc0[kk][e] = gadd(c0, gmul(c2, vh0[e], q, qni), q);
+                    acc1[kk][e] = gadd(c1, gmul(c2, vh1[e], q, qni), q);
+                }
             }
         }
     }
@@ -575,42 +617,64 @@ __global__ void __launch_bounds__(GEN_KS_T, 2) k_gen_ks(DevRing<W> R, GenDev<W> 
         const W qi = R.mod[i].q, hqi = (qi - 1) >> 1;
         const W* src = A.c2pow + (ct * (size_t)Ls + is) * n;
         lds_barrier();                                      // the previous digit's products have been read
-        for (u32 k = threadIdx.x; k < n; k += GEN_KS_T) {
-            const W v = src[k];
-            const SW z = v > hqi ? (SW)v - (SW)qi : (SW)v;
-            SW r;
-            if (A.balanced) r = z < 0 ? z + (SW)q : z;
-            else { r = z % (SW)q; if (r < 0) r += (SW)q; }
-            lds[k] = (W)r;
+        for (u32 k = threadIdx.x * VL; k < n; k += GEN_KS_T * VL) {
+            W v[VL];
+            ld(src, k, v);
+#pragma unroll
+            for (int e = 0; e < VL; ++e) {
+                const SW z = v[e] > hqi ? (SW)v[e] - (SW)qi : (SW)v[e];
+                SW r;
+                if (A.balanced) r = z < 0 ? z + (SW)q : z;
+                else { r = z % (SW)q; if (r < 0) r += (SW)q; }
+                v[e] = (W)r;
+            }
+            if constexpr (VEC) {
+                V o;
+#pragma unroll
+                for (int e = 0; e < VL; ++e) o[e] = v[e];
+                *reinterpret_cast<V*>(lds + k) = o;
+            } else lds[k] = v[0];
         }
         lds_barrier();
         gen_transform<W, false, GEN_KS_T>(lds, G, j, q, qni);
         const W* h0 = hj + (size_t)(2 * i) * Ln;
         const W* h1 = hj + (size_t)(2 * i + 1) * Ln;
 #pragma unroll
-        for (int k = 0; k < GEN_KS_NPT; ++k) {
-            const u32 s = threadIdx.x + (u32)k * GEN_KS_T;
+        for (int kk = 0; kk < NP; ++kk) {
+            const u32 s = (threadIdx.x + (u32)kk * GEN_KS_T) * VL;
             if (s < n) {
-                const W x = lds[s];
-                acc0[k] = gadd(acc0[k], gmul(x, h0[s], q, qni), q);
-                acc1[k] = gadd(acc1[k], gmul(x, h1[s], q, qni), q);
+                W x[VL], vh0[VL], vh1[VL];
+                ld(lds, s, x); ld(h0, s, vh0); ld(h1, s, vh1);
+#pragma unroll
+                for (int e = 0; e < VL; ++e) {
+                    acc0[kk][e] = gadd(acc0[kk][e], gmul(x[e], vh0[e], q, qni), q);
+                    acc1[kk][e] = gadd(acc1[kk][e], gmul(x[e], vh1[e], q, qni), q);
+                }
             }
         }
     }
     W* o0 = A.out + ((2 * ct) * (size_t)L + j) * n;
     W* o1 = A.out + ((2 * ct + 1) * (size_t)L + j) * n;
 #pragma unroll
-    for (int k = 0; k < GEN_KS_NPT; ++k) {
-        const u32 s = threadIdx.x + (u32)k * GEN_KS_T;
-        if (s < n) { o0[s] = acc0[k]; o1[s] = acc1[k]; }
+    for (int kk = 0; kk < NP; ++kk) {
+        const u32 s = (threadIdx.x + (u32)kk * GEN_KS_T) * VL;
+        if (s < n) {
+            if constexpr (VEC) {
+                V v0, v1;
+#pragma unroll
+                for (int e = 0; e < VL; ++e) { v0[e] = acc0[kk][e]; v1[e] = acc1[kk][e]; }
+                *reinterpret_cast<V*>(o0 + s) = v0;
+                *reinterpret_cast<V*>(o1 + s) = v1;
+            } else { o0[s] = acc0[kk][0]; o1[s] = acc1[kk][0]; }
+        }
     }
 }
 
-template <typename W>
-inline hipError_t gen_launch_ks(const DevRing<W>& R, const GenDev<W>& G, const GenKsArgs<W>& A, size_t nct, hipStream_t stream) {
+template <typename W, bool VEC>
+inline hipError_t gen_launch_ks_v(const DevRing<W>& R, const GenDev<W>& G, const GenKsArgs<W>& A, size_t nct, hipStream_t stream) {
     const size_t lds_bytes = (size_t)G.n * sizeof(W);
-    auto k1 = k_gen_tensor_inv<W>;
-    auto k2 = k_gen_ks<W>;
+    auto k1 = k_gen_tensor_inv<W, VEC>;
+    auto k2 = k_gen_ks<W, VEC>;
     hipError_t e;
     if ((e = set_lds(k1, lds_bytes)) != hipSuccess) return e;
     if ((e = set_lds(k2, lds_bytes)) != hipSuccess) return e;
@@ -618,6 +682,11 @@ inline hipError_t gen_launch_ks(const DevRing<W>& R, const GenDev<W>& G, const G
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(k2, dim3((unsigned)(nct * (size_t)R.L)), dim3(GEN_KS_T), lds_bytes, stream, R, G, A);
     return hipGetLastError();
+}
+
+template <typename W>
+inline hipError_t gen_launch_ks(const DevRing<W>& R, const GenDev<W>& G, const GenKsArgs<W>& A, size_t nct, hipStream_t stream) {
+    return G.n % Vec4<W>::LANES == 0 ? gen_launch_ks_v<W, true>(R, G, A, nct, stream) : gen_launch_ks_v<W, false>(R, G, A, nct, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -942,6 +1011,9 @@ template <typename W>
 inline int gen_threads(const GenDev<W>& G) {
     if (G.nt == 128 || G.nt == 256 || G.nt == 512) return G.nt;
     const size_t bytes = (size_t)G.n * sizeof(W);
+    // more than 40 KiB per polynomial (H3', phi = 11520): only three workgroups fit a CU's LDS, so they are made 8 waves wide
+    // (measured on H3': crt 63 -> 59 ns, mul_ 302 k -> 338 k/s; on the 36-KiB rings 512 threads change nothing, below 18 KiB they lose)
+    if (bytes > 40960) return 512;
     return bytes <= 18432 ? GEN_T_SMALL : GEN_T;
 }
 
