@@ -9,15 +9,15 @@
 #   6. the HomomRLWR pipeline (config 4) under --kernel-trace --stats                             -> ${tag}_homomrlwr_kernel_stats.csv
 #   7. the measurement tools themselves (no profiler): general indices, pipeline, Tunnel.hs hops, config 2, other paths -> ${tag}_*.jsonl
 # Counters run in their own passes, never together with --stats or an API trace.  The program after `--` is python3 itself.
-tag=${1:-r02}
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-HEAD="--cpu-ops 0 --no-full --no-pow --no-general --no-pipeline"
+HEAD="--cpu-ops 0 --no-full --no-pow --no-general --no-pipeline --no-tunnel-hs --no-config2"
 run() { name=$1; shift; echo "== $name: $*" >> "$out/commands.txt"; timeout -k 10 300 "$@" > "$out/$name.log" 2>&1 || echo "$name failed" >> "$out/commands.txt"; }
 run stats   rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o stats -- python3 $root/bench.py --steps 5 --warmup 1 $HEAD
-run stats1  rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o stats1 -- python3 $root/bench.py --steps 5 --warmup 1 --cpu-ops 0 --opt one_stream=1
+run stats1  rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o stats1 -- python3 $root/bench.py --steps 5 --warmup 1 --cpu-ops 0 --no-tunnel-hs --no-config2 --opt one_stream=1
 run fetch   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out" -o fetch -- python3 $root/bench.py --steps 1 --warmup 0 --batch 2048 $HEAD
 run write   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out" -o write -- python3 $root/bench.py --steps 1 --warmup 0 --batch 2048 $HEAD
 run general rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o general -- python3 $root/tools/bench_general.py 11648 20475
