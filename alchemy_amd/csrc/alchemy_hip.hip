@@ -97,6 +97,7 @@ struct alch_tunnel {
     alch_ring* re = nullptr;                   // E'_q, same moduli (owned)
     int32_t* table_e = nullptr;                // device: [d_rel][n_e] source positions in R'
     u32* slot_e = nullptr;                     // device: [n_s] CRT slot of E' behind every CRT slot of S'
+    bool pieces_ok = false;                    // every aligned group of four S' slots reads four consecutive, aligned E' slots
 };
 
 struct alch_hint {
@@ -1014,6 +1015,7 @@ extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) 
     else if (k == "rs_half") r->opts.rs_half = value != 0;
     else if (k == "tunnel_ep") r->opts.tunnel_ep = value != 0;
     else if (k == "gen_fused") r->opts.gen_fused = value != 0;
+    else if (k == "tunnel_fused") { if (value < 0 || (value != 0 && value != 2 && value != 4)) return fail(ALCH_E_INVALID, "tunnel_fused: 0 (composed), 2 or 4 (digits side by side)"); r->opts.tunnel_fused = (int)value; }
     else if (k == "gen_nt") {
         if (value != 0 && value != 128 && value != 256 && value != 512) return fail(ALCH_E_INVALID, "gen_nt must be 0 (by ring size), 128, 256 or 512");
         r->g32.nt = (int)value; r->g64.nt = (int)value;
@@ -2294,6 +2296,9 @@ extern "C" int alch_tunnel_create(alch_ring* rr, alch_ring* rs, int gadget, cons
         if (alch_ring_create(ep, rs->L, rs->q, &re) == ALCH_OK && re->gen && re->word == rs->word && re->n % 4 == 0 && rs->n % 4 == 0) {
             t->re = re;
             re->g32.nt = rs->g32.nt; re->g64.nt = rs->g64.nt;      // launch-structure options of the target ring apply to its E' ring
+            t->pieces_ok = true;
+            for (size_t k = 0; k + 3 < slot_e.size(); k += 4)
+                if (slot_e[k] % 4 || slot_e[k + 1] != slot_e[k] + 1 || slot_e[k + 2] != slot_e[k] + 2 || slot_e[k + 3] != slot_e[k] + 3) { t->pieces_ok = false; break; }
             if (hipMalloc((void**)&t->table_e, tab_e.size() * sizeof(int32_t)) != hipSuccess ||
                 hipMalloc((void**)&t->slot_e, slot_e.size() * sizeof(u32)) != hipSuccess ||
                 hipMemcpy(t->table_e, tab_e.data(), tab_e.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
@@ -2364,8 +2369,12 @@ static int do_tunnel(const alch_tunnel* t, alch_ring* rin, const void* in, void*
     alch_ring* rx = t->re ? t->re : rs;
     const u32* slot_e = t->re ? t->slot_e : nullptr;
     const size_t ebr = elem_bytes(rin), ebs = elem_bytes(rs), ebd = elem_bytes(rx), ebx = ebd / (size_t)L * Lx;
+    // TrivGad, 32-bit words, E'-level transforms with piece-aligned slot table: digit transforms + hint products fused (k_gen_tunnel_ks)
+    const bool fused = sizeof(W) == 4 && !base2 && t->re && t->pieces_ok && rs->opts.tunnel_fused && rs->n % 4 == 0 && rx->n % 4 == 0 &&
+                       rs->n <= (u32)(GEN_TUN_T * 4 * 6) && 2 * (size_t)rx->n * sizeof(W) <= 65536;
+    const int tun_ng = (rs->opts.tunnel_fused == 4 && 4 * (size_t)rx->n * sizeof(W) <= 65536) ? 4 : 2;     // two workgroups per CU: 64 KiB of LDS each
     // scratch per ciphertext: Pow copy of the input (2 R'-elements), x0, x1 (D coefficients each), digits (D * GD elements of rx)
-    const size_t per_ct = 2 * ebr + 2 * (size_t)D * ebx + (size_t)D * GD * ebd;
+    const size_t per_ct = 2 * ebr + 2 * (size_t)D * ebx + (fused ? 0 : (size_t)D * GD * ebd);
     size_t chunk = std::max<size_t>(1, (rs->scratch_mib << 20) / per_ct);
     chunk = std::min(chunk, batch);
     int rc = ensure_ws(&rs->ws_full, &rs->ws_full_bytes, chunk * per_ct);
@@ -2421,6 +2430,16 @@ static int do_tunnel(const alch_tunnel* t, alch_ring* rin, const void* in, void*
                            (const W*)t->lin, D, now, Lx, xoff, slot_e, rx->n);
         HIP_TRY(hipGetLastError());
         // linear term: decompose + reduce + crt of every embedded coefficient, inner product with the hints
+        if (fused) {                                  // one kernel, no digits in HBM (k_gen_tunnel_ks)
+            if constexpr (sizeof(W) == 4) {
+                GenTunArgs<u32> A{};
+                A.x1 = reinterpret_cast<const u32*>(x1); A.hint = reinterpret_cast<const u32*>(t->ks); A.out = reinterpret_cast<u32*>(po);
+                A.slot_e = slot_e; A.D = D; A.Lx = Lx; A.xoff = xoff; A.n_s = rs->n; A.balanced = rs->balanced ? 1 : 0;
+                hipError_t e = gen_tunnel_ks_dispatch(rs->d32, rx->g32, A, now, tun_ng, rs->stream);
+                if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("fused tunnel key switch launch: ") + hipGetErrorString(e));
+            }
+            continue;
+        }
         if (base2) {                                 // BaseBGad 2 (examples/Tunnel.hs:24): decompose + reduce in the transforms' loader
             GenCall<W> g{};
             g.op = GEN_CRT_BASE2; g.ring = &dev_ring<W>(rx); g.gen = &gen_dev<W>(rx); g.stream = rs->stream;

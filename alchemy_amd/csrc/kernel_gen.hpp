@@ -106,6 +106,8 @@ hipError_t gen_dispatch(const GenCall<u64>& c);
 template <typename W> struct GenKsArgs;
 hipError_t gen_rescale_lin_dispatch(const DevRing<u32>& R, const GenDev<u32>& G, const u32* in, u32* res, u32* out, const DropTab<u32>& D, int dec_c0, size_t nelem, hipStream_t stream, bool pow_out = false);
 hipError_t gen_rescale_lin_dispatch(const DevRing<u64>& R, const GenDev<u64>& G, const u64* in, u64* res, u64* out, const DropTab<u64>& D, int dec_c0, size_t nelem, hipStream_t stream, bool pow_out = false);
+template <typename W> struct GenTunArgs;
+hipError_t gen_tunnel_ks_dispatch(const DevRing<u32>& R, const GenDev<u32>& GE, const GenTunArgs<u32>& A, size_t nct, int ng, hipStream_t stream);
 hipError_t gen_ks_dispatch(const DevRing<u32>& R, const GenDev<u32>& G, const GenKsArgs<u32>& A, size_t nct, hipStream_t stream);
 hipError_t gen_ks_dispatch(const DevRing<u64>& R, const GenDev<u64>& G, const GenKsArgs<u64>& A, size_t nct, hipStream_t stream);
 
@@ -157,7 +159,7 @@ template <typename W> __device__ __forceinline__ W gmul(W a, W b, W q, W qni) { 
 //   inverse CRT_p : y_0 = -sum_i y_i w^i (the condition x_{p-1} = 0), then the inverse DFT_p (w -> w^-1, a, b, carry 1/p)
 //   forward DFT_p : y_0 = sum_j x_j as well;  inverse DFT_p : the same with w^-1 and 1/p
 template <typename W, int NT, int P, bool IS_DFT, bool INV, bool SMALLQ = false>
-__device__ __forceinline__ void gen_sym_pass(W* __restrict__ lds, const GenPass& Ps, const W* __restrict__ tab, u32 n, W q, W qni) {
+__device__ __forceinline__ void gen_sym_pass(W* __restrict__ lds, const GenPass& Ps, const W* __restrict__ tab, u32 n, W q, W qni, u32 tid) {
     constexpr int H = (P - 1) / 2, R = IS_DFT ? P : P - 1;
     // CRT_p passes never carry twiddles, DFT_p passes always do (gen_plan): a compile-time fact, so the per-element loads below are
     // straight-line code -- as a run-time flag it cost a branch and ~10 VALU instructions per element loaded
@@ -171,7 +173,7 @@ __device__ __forceinline__ void gen_sym_pass(W* __restrict__ lds, const GenPass&
     const W* __restrict__ tw = tab + (has_tw ? Ps.tw_off : 0u);
     const u32 stride = Ps.stride;
     const u32 step = has_tw ? fdiv(stride, Ps.axis_stride, Ps.rcp_axis_stride) : 0u;
-    for (u32 w = threadIdx.x; w < n / (u32)R; w += NT) {
+    for (u32 w = tid; w < n / (u32)R; w += NT) {
         const u32 hi = fdiv(w, stride, Ps.rcp_stride), lo = w - hi * stride;
         const u32 base = hi * (u32)R * stride + lo;
         u32 pos0 = 0;
@@ -265,11 +267,11 @@ __device__ __forceinline__ void gen_sym_pass(W* __restrict__ lds, const GenPass&
 // index -- the table is tw[k] = psi^brev(k), exactly the two-power engine's.  Inverse: Gentleman-Sande, the stages backwards with
 // tw^-1; the factor 2^-K is collected in GenDev::iscale_m.
 template <typename W, int NT, int K, bool INV>
-__device__ __forceinline__ void gen_r2block_pass(W* __restrict__ lds, const GenPass& P, const W* __restrict__ tab, u32 n, W q, W qni) {
+__device__ __forceinline__ void gen_r2block_pass(W* __restrict__ lds, const GenPass& P, const W* __restrict__ tab, u32 n, W q, W qni, u32 tid) {
     constexpr int R = 1 << K;
     const W* __restrict__ tw = tab + P.tw_off;
     const u32 smask = (1u << P.aux) - 1u;
-    for (u32 w = threadIdx.x; w < n / (u32)R; w += NT) {
+    for (u32 w = tid; w < n / (u32)R; w += NT) {
         const u32 hi = fdiv(w, P.stride, P.rcp_stride), lo = w - hi * P.stride;
         const u32 base = hi * (u32)R * P.stride + lo;
         const u32 gm = (1u << P.aux) + (hi & smask);
@@ -308,35 +310,35 @@ __device__ __forceinline__ void gen_r2block_pass(W* __restrict__ lds, const GenP
 }
 
 template <typename W, int NT, bool INV>
-__device__ __forceinline__ void gen_run_pass(W* lds, const GenPass& P, const W* tab, u32 n, W q, W qni, int smallq) {
+__device__ __forceinline__ void gen_run_pass(W* lds, const GenPass& P, const W* tab, u32 n, W q, W qni, int smallq, u32 tid) {
     if (P.kind == GK_R2BLOCK) {                    // every branch here is wave-uniform
-        if (P.r == 8) gen_r2block_pass<W, NT, 3, INV>(lds, P, tab, n, q, qni);
-        else if (P.r == 4) gen_r2block_pass<W, NT, 2, INV>(lds, P, tab, n, q, qni);
-        else gen_r2block_pass<W, NT, 1, INV>(lds, P, tab, n, q, qni);
+        if (P.r == 8) gen_r2block_pass<W, NT, 3, INV>(lds, P, tab, n, q, qni, tid);
+        else if (P.r == 4) gen_r2block_pass<W, NT, 2, INV>(lds, P, tab, n, q, qni, tid);
+        else gen_r2block_pass<W, NT, 1, INV>(lds, P, tab, n, q, qni, tid);
         return;
     }
     const int p = P.kind == GK_SYM_DFT ? P.r : P.r + 1;
     if (P.kind == GK_SYM_CRT) {
         switch (p) {
-        case 3: gen_sym_pass<W, NT, 3, false, INV>(lds, P, tab, n, q, qni); break;
-        case 5: gen_sym_pass<W, NT, 5, false, INV>(lds, P, tab, n, q, qni); break;
-        case 7: gen_sym_pass<W, NT, 7, false, INV>(lds, P, tab, n, q, qni); break;
-        case 11: gen_sym_pass<W, NT, 11, false, INV>(lds, P, tab, n, q, qni); break;
+        case 3: gen_sym_pass<W, NT, 3, false, INV>(lds, P, tab, n, q, qni, tid); break;
+        case 5: gen_sym_pass<W, NT, 5, false, INV>(lds, P, tab, n, q, qni, tid); break;
+        case 7: gen_sym_pass<W, NT, 7, false, INV>(lds, P, tab, n, q, qni, tid); break;
+        case 11: gen_sym_pass<W, NT, 11, false, INV>(lds, P, tab, n, q, qni, tid); break;
         case 13:                                   // (wave-uniform: the ring's moduli decide)
-            if (sizeof(W) == 4 && smallq) gen_sym_pass<W, NT, 13, false, INV, true>(lds, P, tab, n, q, qni);
-            else gen_sym_pass<W, NT, 13, false, INV>(lds, P, tab, n, q, qni);
+            if (sizeof(W) == 4 && smallq) gen_sym_pass<W, NT, 13, false, INV, true>(lds, P, tab, n, q, qni, tid);
+            else gen_sym_pass<W, NT, 13, false, INV>(lds, P, tab, n, q, qni, tid);
             break;
         default: break;                            // the host refuses indices with other odd primes
         }
     } else {
         switch (p) {
-        case 3: gen_sym_pass<W, NT, 3, true, INV>(lds, P, tab, n, q, qni); break;
-        case 5: gen_sym_pass<W, NT, 5, true, INV>(lds, P, tab, n, q, qni); break;
-        case 7: gen_sym_pass<W, NT, 7, true, INV>(lds, P, tab, n, q, qni); break;
-        case 11: gen_sym_pass<W, NT, 11, true, INV>(lds, P, tab, n, q, qni); break;
+        case 3: gen_sym_pass<W, NT, 3, true, INV>(lds, P, tab, n, q, qni, tid); break;
+        case 5: gen_sym_pass<W, NT, 5, true, INV>(lds, P, tab, n, q, qni, tid); break;
+        case 7: gen_sym_pass<W, NT, 7, true, INV>(lds, P, tab, n, q, qni, tid); break;
+        case 11: gen_sym_pass<W, NT, 11, true, INV>(lds, P, tab, n, q, qni, tid); break;
         case 13:
-            if (sizeof(W) == 4 && smallq) gen_sym_pass<W, NT, 13, true, INV, true>(lds, P, tab, n, q, qni);
-            else gen_sym_pass<W, NT, 13, true, INV>(lds, P, tab, n, q, qni);
+            if (sizeof(W) == 4 && smallq) gen_sym_pass<W, NT, 13, true, INV, true>(lds, P, tab, n, q, qni, tid);
+            else gen_sym_pass<W, NT, 13, true, INV>(lds, P, tab, n, q, qni, tid);
             break;
         default: break;
         }
@@ -344,13 +346,19 @@ __device__ __forceinline__ void gen_run_pass(W* lds, const GenPass& P, const W* 
 }
 
 // whole transform on an LDS-resident polynomial (canonical values in, canonical values out)
+// NT threads with ids tid = 0 .. NT-1 work on the polynomial (the whole workgroup by default; k_gen_tunnel_ks runs several
+// polynomials side by side, one per sub-group of threads: every thread of the workgroup reaches the same barriers)
+template <typename W, bool INV, int NT = GEN_T>
+__device__ __forceinline__ void gen_transform(W* lds, const GenDev<W>& G, int j, W q, W qni, u32 tid) {
+    if (!INV) {
+        for (int ps = 0; ps < G.npass; ++ps) { gen_run_pass<W, NT, false>(lds, G.pass[ps], G.tabf[j], G.n, q, qni, G.smallq, tid); lds_barrier(); }
+    } else {
+        for (int ps = G.npass - 1; ps >= 0; --ps) { gen_run_pass<W, NT, true>(lds, G.pass[ps], G.tabi[j], G.n, q, qni, G.smallq, tid); lds_barrier(); }
+    }
+}
 template <typename W, bool INV, int NT = GEN_T>
 __device__ __forceinline__ void gen_transform(W* lds, const GenDev<W>& G, int j, W q, W qni) {
-    if (!INV) {
-        for (int ps = 0; ps < G.npass; ++ps) { gen_run_pass<W, NT, false>(lds, G.pass[ps], G.tabf[j], G.n, q, qni, G.smallq); lds_barrier(); }
-    } else {
-        for (int ps = G.npass - 1; ps >= 0; --ps) { gen_run_pass<W, NT, true>(lds, G.pass[ps], G.tabi[j], G.n, q, qni, G.smallq); lds_barrier(); }
-    }
+    gen_transform<W, INV, NT>(lds, G, j, q, qni, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -687,6 +695,130 @@ inline hipError_t gen_launch_ks_v(const DevRing<W>& R, const GenDev<W>& G, const
 template <typename W>
 inline hipError_t gen_launch_ks(const DevRing<W>& R, const GenDev<W>& G, const GenKsArgs<W>& A, size_t nct, hipStream_t stream) {
     return G.n % Vec4<W>::LANES == 0 ? gen_launch_ks_v<W, true>(R, G, A, nct, stream) : gen_launch_ks_v<W, false>(R, G, A, nct, stream);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Fused linear key switch of a ring tunnel (SymmSHE tunnel, Eval.hs:134; TrivGad): digit transforms + hint inner product in one
+// kernel, the counterpart of k_gen_ks for tunnels.  Workgroup = (ciphertext, limb j of S'_q).  The digits are E'-coefficients of c1
+// (dimension phi(e'), 2-5 times smaller than phi(s')): NG of them are transformed side by side, one per sub-group of T / NG
+// threads, in NG phi(e') words of LDS; the CRT over S' of an embedded E'-element is its CRT over E' replicated (slot_e), so the
+// inner product reads the transformed digit through that table, 16 bytes at a time, against the hint rows of the lane's own
+// output slots; the 2 phi(s') / T accumulators per lane stay in registers.  No digit is written to or read from HBM
+// (d_rel (L - dup) L limb-vectors of phi(e') words per ciphertext before).
+// ------------------------------------------------------------------------------------------------------
+constexpr int GEN_TUN_T = 512;
+
+template <typename W>
+struct GenTunArgs {
+    const W* x1;             // [ct][D][Lx][n_e]: Pow-basis E'-coefficients of c1, limbs xoff .. xoff + Lx - 1 of the ring
+    const W* hint;           // [i * L + limb][2][L][n_s], Montgomery form
+    W* out;                  // [ct][2][L][n_s]: the c0 rows hold f'(c0) on entry; both rows are (over)written
+    const u32* slot_e;       // [n_s]: CRT slot of E' behind every CRT slot of S'; consecutive and aligned within every 16-byte piece
+    u32 D, Lx, xoff, n_s;
+    int balanced;
+};
+
+template <typename W, int NG, int NP>                       // NP: 16-byte output pieces per lane, phi(s') <= NP * 4 * GEN_TUN_T words
+__global__ void __launch_bounds__(GEN_TUN_T, 4) k_gen_tunnel_ks(DevRing<W> R, GenDev<W> GE, GenTunArgs<W> A) {
+    typedef typename Signed<W>::type SW;
+    typedef typename Vec4<W>::type V;
+    constexpr int VL = Vec4<W>::LANES, TS = GEN_TUN_T / NG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W* lds = reinterpret_cast<W*>(smem);
+    const int L = R.L;
+    const size_t ct = blockIdx.x / (unsigned)L;
+    const int j = (int)(blockIdx.x % (unsigned)L);
+    const u32 n_e = GE.n, n_s = A.n_s;
+    const W q = R.mod[j].q, qni = R.mod[j].qni;
+    const size_t Ln = (size_t)L * n_s;
+    const u32 g = threadIdx.x / TS, lt = threadIdx.x - g * TS;
+    W* mine = lds + (size_t)g * n_e;
+    W* o0 = A.out + ((2 * ct) * (size_t)L + j) * n_s;
+    W* o1 = A.out + ((2 * ct + 1) * (size_t)L + j) * n_s;
+    V acc0[NP], acc1[NP];
+    constexpr bool CACHE_SE = NP < 6;                      // six pieces per lane (phi(s') = 11520) leave no room for the slot indices
+    u32 se[CACHE_SE ? NP : 1];
+#pragma unroll
+    for (int kk = 0; kk < NP; ++kk) {
+        const u32 s = (threadIdx.x + (u32)kk * GEN_TUN_T) * VL;
+        if (CACHE_SE) se[kk] = 0;
+#pragma unroll
+        for (int e = 0; e < VL; ++e) { acc0[kk][e] = 0; acc1[kk][e] = 0; }
+        if (s < n_s) { acc0[kk] = *reinterpret_cast<const V*>(o0 + s); if (CACHE_SE) se[kk] = A.slot_e[s]; }
+    }
+    const u32 ndig = A.D * A.Lx;
+    for (u32 d0 = 0; d0 < ndig; d0 += NG) {
+        lds_barrier();                                      // the previous round's products have been read
+        const u32 dd = d0 + g;
+        if (dd < ndig) {                                    // decompose + reduce in the loader (TrivGad: centred lift of limb t)
+            const u32 t = dd % A.Lx;
+            const W qi = R.mod[t + A.xoff].q, hqi = (qi - 1) >> 1;
+            const W* src = A.x1 + (ct * (size_t)ndig + dd) * (size_t)n_e;
+            for (u32 k = lt * VL; k < n_e; k += TS * VL) {
+                V v = *reinterpret_cast<const V*>(src + k);
+#pragma unroll
+                for (int e = 0; e < VL; ++e) {
+                    const SW z = v[e] > hqi ? (SW)v[e] - (SW)qi : (SW)v[e];
+                    SW r;
+                    if (A.balanced) r = z < 0 ? z + (SW)q : z;
+                    else { r = z % (SW)q; if (r < 0) r += (SW)q; }
+                    v[e] = (W)r;
+                }
+                *reinterpret_cast<V*>(mine + k) = v;
+            }
+        } else {
+            for (u32 k = lt * VL; k < n_e; k += TS * VL) {
+                V z;
+#pragma unroll
+                for (int e = 0; e < VL; ++e) z[e] = 0;
+                *reinterpret_cast<V*>(mine + k) = z;
+            }
+        }
+        lds_barrier();
+        gen_transform<W, false, TS>(mine, GE, j, q, qni, lt);       // every sub-group its own digit; ends with a barrier
+        for (u32 gg = 0; gg < (u32)NG && d0 + gg < ndig; ++gg) {
+            const u32 d = d0 + gg, i = d / A.Lx, t = d - i * A.Lx;
+            const W* h0 = A.hint + (size_t)(2 * (i * (u32)L + t + A.xoff)) * Ln + (size_t)j * n_s;
+            const W* h1 = h0 + Ln;
+            const W* x = lds + (size_t)gg * n_e;
+#pragma unroll
+            for (int kk = 0; kk < NP; ++kk) {
+                const u32 s = (threadIdx.x + (u32)kk * GEN_TUN_T) * VL;
+                if (s < n_s) {
+                    const V xv = *reinterpret_cast<const V*>(x + (CACHE_SE ? se[kk] : A.slot_e[s]));
+                    const V v0 = *reinterpret_cast<const V*>(h0 + s), v1 = *reinterpret_cast<const V*>(h1 + s);
+#pragma unroll
+                    for (int e = 0; e < VL; ++e) {
+                        acc0[kk][e] = gadd(acc0[kk][e], gmul(xv[e], v0[e], q, qni), q);
+                        acc1[kk][e] = gadd(acc1[kk][e], gmul(xv[e], v1[e], q, qni), q);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < NP; ++kk) {
+        const u32 s = (threadIdx.x + (u32)kk * GEN_TUN_T) * VL;
+        if (s < n_s) { *reinterpret_cast<V*>(o0 + s) = acc0[kk]; *reinterpret_cast<V*>(o1 + s) = acc1[kk]; }
+    }
+}
+
+template <typename W, int NG, int NP>
+inline hipError_t gen_launch_tunnel_ks_t(const DevRing<W>& R, const GenDev<W>& GE, const GenTunArgs<W>& A, size_t nct, hipStream_t stream) {
+    const size_t lds_bytes = (size_t)NG * GE.n * sizeof(W);
+    auto k = k_gen_tunnel_ks<W, NG, NP>;
+    hipError_t e = set_lds(k, lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3((unsigned)(nct * (size_t)R.L)), dim3(GEN_TUN_T), lds_bytes, stream, R, GE, A);
+    return hipGetLastError();
+}
+
+template <typename W>
+inline hipError_t gen_launch_tunnel_ks(const DevRing<W>& R, const GenDev<W>& GE, const GenTunArgs<W>& A, size_t nct, int ng, hipStream_t stream) {
+    const u32 pieces = (A.n_s / Vec4<W>::LANES + GEN_TUN_T - 1) / GEN_TUN_T;
+    if (pieces <= 3) return ng == 4 ? gen_launch_tunnel_ks_t<W, 4, 3>(R, GE, A, nct, stream) : gen_launch_tunnel_ks_t<W, 2, 3>(R, GE, A, nct, stream);
+    if (pieces <= 5) return ng == 4 ? gen_launch_tunnel_ks_t<W, 4, 5>(R, GE, A, nct, stream) : gen_launch_tunnel_ks_t<W, 2, 5>(R, GE, A, nct, stream);
+    return ng == 4 ? gen_launch_tunnel_ks_t<W, 4, 6>(R, GE, A, nct, stream) : gen_launch_tunnel_ks_t<W, 2, 6>(R, GE, A, nct, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------

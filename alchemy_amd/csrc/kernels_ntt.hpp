@@ -86,6 +86,11 @@ struct LaunchOpts {
     int gen_fused = 1;       // general index: 1 = fused tensor + key switch kernels (kernel_gen.hpp).  Round 2 measured 0.69-0.82x the composed
                              // path (48 accumulators + the CRT_13 pass matrices in VGPRs spilled); with the pass matrices in SGPRs (round 3) the
                              // kernel needs 127 VGPRs, no scratch: 1.13x on H5', 1.24x on H3', 1.08x on H1', 0.99x on H0'  (key switch, L = 4)
+    int tunnel_fused = 0;    // alch_ct_tunnel (TrivGad, E'-level transforms): 2 or 4 = digit transforms + hint products in one kernel with that many
+                             // digits side by side per workgroup (k_gen_tunnel_ks); 0 = k_gen_crt_digits + k_hint_mac_v through HBM.  Measured on the
+                             // HomomRLWR pipeline (round 3): 41.7 k ringRounds/s composed, 41.2 k fused (hop 1: 2.17 -> 2.36 ms, hop 3: 3.75 -> 4.1 ms,
+                             // hop 2: 3.12 -> 3.05): the E'-size transforms fill a 512-thread workgroup poorly and the digit round trip they save
+                             // is small (phi(e') words per digit) -- kept as a tested option, off
     int crt_half = 1;        // crt / crtInv of a 128-KiB limb-polynomial: 1 = two half-size workgroups per CU (k_crt_half), 0 = k_crt
     int rs_half = 0;         // closing modSwitch at n = 2^15 (32-bit): 1 = always the two launches of half-size workgroups (kernel_rescale_half.hpp);
                              // 0 = only where k_rescale_out_lin cannot serve (three dropped limbs, unbalanced two-limb drops).  Measured on the

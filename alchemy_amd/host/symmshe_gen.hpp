@@ -155,6 +155,27 @@ inline CT addPublic(PtOps& ops, const PtCyc& b, const CT& ct_) {
     return ct;
 }
 
+// SymmSHE absorbGFactors: what `tunnel` runs first when k > 0 -- every component times reduce(liftPow d), d = g^-k in R'_p
+// (`iterate divG one !! k`), then k = 0.  On this ABI: alch_divg_pow on a ring without CRT over Z_p, a centred lift, `reduce`,
+// one ring product per component.
+inline CT absorbGFactors(RingCache& rc, const CT& ct) {
+    if (ct.k == 0) return ct;
+    const Ring& r = ct.c[0].ring();
+    const Ring& zp = rc.get(r.m(), {(uint64_t)ct.p}, false);
+    std::vector<int64_t> d(zp.n(), 0);
+    d[0] = 1;
+    for (int i = 0; i < ct.k; ++i) {
+        int rcg = alch_divg_pow(zp.handle(), d.data());
+        check(rcg, "alch_divg_pow (plaintext)");
+        if (rcg == ALCH_NOT_DIVISIBLE) throw std::runtime_error("absorbGFactors: g is not a unit modulo p");
+    }
+    for (auto& v : d) v = centred(v, ct.p);
+    const Cyc rep = Cyc::fromIntegers(r, d).toCRT();
+    CT o{ct.enc, 0, ct.l, ct.p, ct.m, {}};
+    for (const Cyc& x : ct.c) o.c.push_back(x * rep);
+    return o;
+}
+
 // modSwitchPT (PT2CT's div2_, PT2CT.hs:179-189): MSD form, plaintext modulus p -> p' | p, ring elements unchanged
 inline CT modSwitchPT(const CT& ct_, int64_t p_new) {
     CT ct = toMSD(ct_);
@@ -248,8 +269,8 @@ inline TunnelHint tunnelHint(RingCache& rc, PtOps& ops, const Linear& f, uint32_
 
 // SymmSHE tunnel (per element): linear ciphertext, k = 0, MSD
 inline CT tunnel(RingCache& rc, const TunnelHint& h, const CT& ct_, uint32_t m_out) {
-    CT ct = toMSD(ct_);
-    if (ct.k != 0 || ct.c.size() != 2) throw std::runtime_error("tunnel: linear ciphertexts with k = 0");
+    CT ct = toMSD(absorbGFactors(rc, ct_));
+    if (ct.c.size() != 2) throw std::runtime_error("tunnel: linear ciphertexts");
     const Ring& rr = ct.c[0].ring();
     const Ring &re = rc.get(h.ep, rr.qs()), &rs = rc.get(h.sp, rr.qs());
     Cyc c0 = evalLinExt(h.lin, re, rs, ct.c[0]);

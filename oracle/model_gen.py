@@ -556,6 +556,20 @@ def g_add_public(pub_pow, ct: GCT) -> GCT:
     return GCT(LSD, ct.k, ct.l, [c0] + ct.c[1:], ct.p, ct.qs, ct.big, ct.small)
 
 
+def g_absorb_g_factors(ct: GCT) -> GCT:
+    """SymmSHE absorbGFactors (what `tunnel` runs first on a ciphertext with k > 0): every component times
+    reduce(liftPow d), d = g^-k in R'_p (`iterate divG one !! k`), k <- 0.  d g^k = 1 (mod p R'), so the plaintext is unchanged."""
+    if ct.k == 0:
+        return ct
+    d = [1] + [0] * (ct.big.n - 1)
+    for _ in range(ct.k):
+        d = divg_pow_def(d, ct.big, ct.p)
+        assert d is not None
+    dz = [centred(v, ct.p) for v in d]
+    c = [[ring_mul_def(cl, dz, ct.big, q) for cl, q in zip(comp, ct.qs)] for comp in ct.c]
+    return GCT(ct.enc, 0, ct.l, c, ct.p, ct.qs, ct.big, ct.small)
+
+
 def g_decrypt(sk, ct: GCT) -> List[int]:
     """Pow coefficients (mod p) of the plaintext: l * twace(g^-k * (liftDec(c(s)) mod p))."""
     ct = g_to_lsd(ct)

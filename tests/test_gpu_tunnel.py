@@ -53,13 +53,15 @@ def test_tunnel_hop_matches_the_oracle(oracle_lib, rp, sp, L, batch):
     gin, gout = gr.upload(cts), gs.alloc(2 * batch)
     # tunnel_ep = 1 (default): the embedded E'-coefficients are transformed at dimension phi(e') and read through the embedCRT slot
     # table; 0: embedded into S' first and transformed there
-    for ep_level in (1, 0):
+    # tunnel_fused: digit transforms + hint products in one kernel (2 or 4 digits side by side), or through HBM (0)
+    for ep_level, fused in ((1, 2), (1, 4), (1, 0), (0, 2)):
         gs.set_option("tunnel_ep", ep_level)
+        gs.set_option("tunnel_fused", fused)
         tun = A.Tunnel(gr, gs, gs.upload(lin), gs.upload(ks))
         tun.apply(gin, gout, batch, s_pre=s_pre)
         got = gout.download()
         for ct in range(batch):
-            assert np.array_equal(got[2 * ct], want[ct][0]) and np.array_equal(got[2 * ct + 1], want[ct][1]), (ct, ep_level)
+            assert np.array_equal(got[2 * ct], want[ct][0]) and np.array_equal(got[2 * ct + 1], want[ct][1]), (ct, ep_level, fused)
 
 
 @pytest.mark.parametrize("rp,sp,L,dup,gadget", [(40, 60, 3, 1, "triv"), (63, 105, 4, 2, "triv"), (11648, 29120, 6, 1, "triv"),
@@ -163,3 +165,53 @@ def test_tunnel_argument_checks():
     t = A.Tunnel(gr, gs, lin, ks)
     with pytest.raises(A.AlchemyError):
         t.apply(gs.alloc(2), gs.alloc(2), 1)                  # input must live in R'
+
+
+def test_tunnel_on_a_ciphertext_with_g_factors():
+    """SymmSHE `tunnel` on a ciphertext with k > 0 (after a product): Lol runs `absorbGFactors` first -- every component times
+    reduce(liftPow(g^-k mod p)), k <- 0 -- composed here from entry points that exist (alch_divg_pow on a ring without CRT over Z_p,
+    alch_crt, alch_buf_mul_public), then alch_ct_tunnel.  A valid model instance: product of two encryptions (k = 1), key switch,
+    absorb, tunnel; the device result equals the model's bit for bit and the model decrypts it to f(pt1 * pt2).  No ALCHEMY example
+    reaches this path (every tunnel of the reference sits in front of the first product)."""
+    import random
+    from oracle import model_gen as G
+    rng = random.Random(31)
+    r, s, rp, sp, p = 8, 12, 40, 60, 8
+    T = G.tunnel_indices(r, s, rp, sp)
+    qs = primes_1_mod(rp * sp // math.gcd(rp, sp), 3, 1 << 29)
+    sk_in, sk_out = G.g_gen_sk(T.rp, rng), G.g_gen_sk(T.sp, rng)
+    ys = [[rng.randrange(p) for _ in range(T.s.n)] for _ in range(T.r.n // T.e.n)]
+    pt1, pt2 = ([rng.randrange(p) for _ in range(T.r.n)] for _ in range(2))
+    prod = G.g_key_switch(G.g_ks_hint(sk_in, T.rp, qs, rng), G.g_ct_mul(G.g_encrypt(sk_in, pt1, T.r, T.rp, p, qs, rng),
+                                                                    G.g_encrypt(sk_in, pt2, T.r, T.rp, p, qs, rng)))
+    assert prod.k == 1 and G.g_decrypt(sk_in, prod) == G.ring_mul_def(pt1, pt2, T.r, p)
+    absorbed = G.g_absorb_g_factors(prod)
+    assert absorbed.k == 0 and G.g_decrypt(sk_in, absorbed) == G.ring_mul_def(pt1, pt2, T.r, p)
+    lin_q, hints = G.g_tunnel_hint(ys, T, p, sk_in, sk_out, qs, rng)
+    want = G.g_tunnel(lin_q, hints, absorbed, T)
+    # ---- the device
+    gr, gs, zp = A.Ring(rp, qs), A.Ring(sp, qs), A.Ring(rp, [p], nocrt=True)
+    d = np.zeros((T.rp.n, 1), dtype=np.int64)
+    d[0, 0] = 1
+    for _ in range(prod.k):
+        d = zp.divg_pow(d)                                            # g^-1 over Z_p, once per power
+        assert d is not None
+    dz = np.where(d[:, 0] > (p - 1) // 2, d[:, 0] - p, d[:, 0])
+    rep = gr.upload(np.stack([np.stack([dz % q for q in qs], axis=1)]))
+    rep.crt()
+    cin = gr.upload(np.stack([to_aos(c) for c in prod.c]))             # MSD, Pow basis
+    cin.crt()
+    cabs = gr.alloc(2)
+    cabs.mul_public(cin, rep, 0, 2)
+    lin = gs.upload(np.stack([to_aos(y) for y in lin_q]))
+    ks = gs.upload(np.stack([to_aos(x) for hint_i in hints for pair in hint_i for x in pair]))
+    lin.crt(); ks.crt()
+    tun = A.Tunnel(gr, gs, lin, ks)
+    cout = gs.alloc(2)
+    tun.apply(cabs, cout, 1, flags=capi.ALCH_POW_OUT)
+    got = cout.download()
+    lm = lambda a: np.asarray(a).T.tolist()
+    assert lm(got[0]) == want.c[0] and lm(got[1]) == want.c[1]
+    dev = G.GCT(want.enc, 0, want.l, [lm(got[0]), lm(got[1])], p, qs, T.sp, T.s)
+    f_of = G.eval_lin_dec(ys, G.linv_def(G.ring_mul_def(pt1, pt2, T.r, p), T.r, p), T.e, T.r, T.s, p)
+    assert G.g_decrypt(sk_out, dev) == f_of

@@ -9,7 +9,9 @@ from alchemy_amd.ringround import RingRound
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 import os
 NT = int(os.environ.get('GEN_NT', '0'))
-rr = RingRound(B, (('gen_nt', NT),) if NT else ())
+TF = os.environ.get('TUNNEL_FUSED')
+opts = ((('gen_nt', NT),) if NT else ()) + ((('tunnel_fused', int(TF)),) if TF is not None else ())
+rr = RingRound(B, opts)
 secs, out = rr.measure(passes=2)
 rr.stages.clear()
 rr.run(stage_times=True)
