@@ -196,15 +196,29 @@ inline CT operator*(const CT& a_, const CT& b_) {
 }
 
 // ---- hints -------------------------------------------------------------------------------------------------------
-struct KSHint { std::vector<std::pair<Cyc, Cyc>> h; };          // TrivGad: one (b, a) per limb, CRT basis; b + a s = g_t v + e
+struct KSHint { std::vector<std::pair<Cyc, Cyc>> h; };          // one (b, a) per gadget entry, CRT basis; b + a s = g_t v + e
 
-// ksHint skout v: LWE samples under skout hiding g_t * v, g_t the TrivGad gadget (unit vector of limb t)
-inline KSHint ksHint(RingCache& rc, const Ring& r, const SK& skout, const Cyc& v_crt, std::mt19937_64& rng) {
+// The gadget vector as per-limb scalars (Lol Gadget for an RNS product: the per-limb gadgets placed in their own limb, zeros
+// elsewhere): TrivGad = the unit vectors; BaseBGad 2 = 2^t on limb i for t < ceil(log2 q_i), limb 0's entries first.
+inline std::vector<std::vector<uint64_t>> gadgetVector(const Ring& r, int gadget) {
+    std::vector<std::vector<uint64_t>> g;
+    for (int i = 0; i < r.L(); ++i) {
+        int k = 1;
+        if (gadget == ALCH_GAD_BASE2) { k = 0; for (uint64_t v = 1; v < r.qs()[i]; v <<= 1) ++k; }
+        for (int t = 0; t < k; ++t) {
+            std::vector<uint64_t> e(r.L(), 0);
+            e[i] = powmod(2, (uint64_t)t, r.qs()[i]);
+            g.push_back(e);
+        }
+    }
+    return g;
+}
+
+// ksHint skout v: LWE samples under skout hiding g_t * v for every entry g_t of the gadget
+inline KSHint ksHint(RingCache& rc, const Ring& r, const SK& skout, const Cyc& v_crt, std::mt19937_64& rng, int gadget = ALCH_GAD_TRIV) {
     const Cyc s = Cyc::fromIntegers(r, skout.s).toCRT();
     KSHint hint;
-    for (int t = 0; t < r.L(); ++t) {
-        std::vector<uint64_t> gt(r.L(), 0);
-        gt[t] = 1;
+    for (const auto& gt : gadgetVector(r, gadget)) {
         const Cyc e = roundedError(rc, r, skout.svar, rng).toCRT();
         const Cyc a = uniformCRT(r, rng);
         hint.h.emplace_back(v_crt.scale(gt) + e - a * s, a);
@@ -230,6 +244,7 @@ inline CT keySwitchQuadCirc(const KSHint& hint, const CT& ct_) {
 // and, for every element p_i of the relative powerful basis of R'/E', a key-switch hint for f'(s_in p_i) under s_out.
 struct TunnelHint {
     uint32_t ep, rp, sp;
+    int gadget = ALCH_GAD_TRIV;
     std::vector<Cyc> lin;                       // d_rel values f'(d_i) over S'_q, CRT basis
     std::vector<KSHint> ks;                     // d_rel hints
 };
@@ -243,7 +258,7 @@ inline Cyc evalLinExt(const std::vector<Cyc>& lin_crt, const Ring& re, const Rin
 }
 
 inline TunnelHint tunnelHint(RingCache& rc, PtOps& ops, const Linear& f, uint32_t rp, uint32_t sp, const std::vector<uint64_t>& qs,
-                             const SK& skout, const SK& skin, std::mt19937_64& rng) {
+                             const SK& skout, const SK& skin, std::mt19937_64& rng, int gadget = ALCH_GAD_TRIV) {
     uint32_t a = rp, b = sp;
     while (b) { uint32_t t = a % b; a = b; b = t; }
     const uint32_t ep = a;
@@ -251,7 +266,7 @@ inline TunnelHint tunnelHint(RingCache& rc, PtOps& ops, const Linear& f, uint32_
     uint32_t chk_e = 0, d_rel = 0;
     check(alch_tunnel_info(rr.handle(), rs.handle(), &chk_e, &d_rel), "alch_tunnel_info");
     if (d_rel != f.ys.size() || chk_e != ep) throw std::runtime_error("tunnelHint: the linear function does not match the rings");
-    TunnelHint h{ep, rp, sp, {}, {}};
+    TunnelHint h{ep, rp, sp, gadget, {}, {}};
     for (const PtCyc& y : f.ys) h.lin.push_back(liftEmbed(ops, rs, y).toCRT());
     // relative powerful basis of R'/E': unit vectors at the positions table ALCH_EXT_COEFFS lists first
     size_t len = (size_t)d_rel * re.n();
@@ -262,7 +277,7 @@ inline TunnelHint tunnelHint(RingCache& rc, PtOps& ops, const Linear& f, uint32_
         std::vector<int64_t> unit(rr.n(), 0);
         unit[(size_t)tab[(size_t)i * re.n()]] = 1;
         const Cyc x = sin * Cyc::fromIntegers(rr, unit);                                   // s_in p_i over R'_q
-        h.ks.push_back(ksHint(rc, rs, skout, evalLinExt(h.lin, re, rs, x), rng));
+        h.ks.push_back(ksHint(rc, rs, skout, evalLinExt(h.lin, re, rs, x), rng, gadget));
     }
     return h;
 }
@@ -271,6 +286,7 @@ inline TunnelHint tunnelHint(RingCache& rc, PtOps& ops, const Linear& f, uint32_
 inline CT tunnel(RingCache& rc, const TunnelHint& h, const CT& ct_, uint32_t m_out) {
     CT ct = toMSD(absorbGFactors(rc, ct_));
     if (ct.c.size() != 2) throw std::runtime_error("tunnel: linear ciphertexts");
+    if (h.gadget != ALCH_GAD_TRIV) throw std::runtime_error("tunnel (per element): TrivGad hints; BaseBGad hints run on the batched entry point");
     const Ring& rr = ct.c[0].ring();
     const Ring &re = rc.get(h.ep, rr.qs()), &rs = rc.get(h.sp, rr.qs());
     Cyc c0 = evalLinExt(h.lin, re, rs, ct.c[0]);
@@ -399,7 +415,7 @@ struct DevTunnel {
     const Ring *rr = nullptr, *rs = nullptr;
     DevTunnel() {}
     DevTunnel(const Ring& r, const Ring& s, const TunnelHint& h) : rr(&r), rs(&s) {
-        const size_t d = h.lin.size(), D = (size_t)s.L();
+        const size_t d = h.lin.size(), D = h.ks.empty() ? 0 : h.ks[0].h.size();
         alch_buf *lin = nullptr, *ks = nullptr;
         check(alch_buf_alloc(s.handle(), d, &lin), "alch_buf_alloc");
         check(alch_buf_alloc(s.handle(), 2 * d * D, &ks), "alch_buf_alloc");
@@ -410,7 +426,7 @@ struct DevTunnel {
                 check(alch_buf_upload(ks, (i * D + t2) * 2 + 1, 1, h.ks[i].h[t2].second.toCRT().data().data()), "alch_buf_upload");
             }
         }
-        check(alch_tunnel_create(r.handle(), s.handle(), ALCH_GAD_TRIV, lin, ks, &t), "alch_tunnel_create");
+        check(alch_tunnel_create(r.handle(), s.handle(), h.gadget, lin, ks, &t), "alch_tunnel_create");
         alch_buf_free(lin);
         alch_buf_free(ks);
     }
@@ -424,6 +440,15 @@ struct DevTunnel {
 // tunnel's R' ring (the leading modSwitch up is part of alch_ct_tunnel); the result is rescaled down to rout.
 inline DevBatch tunnelBatch(const DevTunnel& tun, DevBatch& x, const Ring& rout, uint32_t m_out) {
     if (x.k != 0) throw std::runtime_error("tunnelBatch: k must be 0");
+    if (x.ring->L() > tun.rs->L()) {
+        // BaseBGad hints may sit on FEWER limbs than the input (KSPNoise, PT2CT.hs:140): the leading modSwitch goes down
+        x.toMSD();
+        DevBatch dn(*tun.rr, x.B);
+        check(alch_ct_mod_switch(x.buf, dn.buf, x.B, x.basis == Basis::Pow ? ALCH_POW_IN : 0u), "alch_ct_mod_switch");
+        dn.meta(x);
+        dn.basis = Basis::CRT;
+        return tunnelBatch(tun, dn, rout, m_out);
+    }
     // toMSD rides on the call as its per-limb scalar (indexed by the tunnel ring's limbs; the input holds its last limbs)
     const Ring& rs = *tun.rs;
     const int dup = rs.L() - x.ring->L();

@@ -109,3 +109,19 @@ def test_first_hop_linear_function_is_dec_to_crt_by_definition(replay):
     x0 = np.fromfile(os.path.join(d, "pt_h0.i64"), dtype=np.int64).tolist()
     x1 = np.fromfile(os.path.join(d, "pt_h1.i64"), dtype=np.int64).tolist()
     assert G.eval_lin_dec(ys.tolist(), G.linv_def(x0, r, 32), e, r, s, 32) == x1
+
+
+def test_tunnel_example_at_the_reference_parameters():
+    """examples/Tunnel.hs (BASELINE config 5) through the compiled C++ host: switch3 = H0 -> H1 -> H2 -> H3 (the file's `tunnel3`),
+    BaseBGad 2 hints (:24), its moduli (:34-39), Gaussian parameter 3.0 (:59), plaintext modulus 2^3, limb counts from
+    alch_select_limbs with the BaseBGad rule (2/1/1, 1/1/1, 1/1/1: the first modSwitch goes DOWN).  The reference prints error rates
+    only; the replay also decrypts after every hop and compares with the plaintext evalLin chain."""
+    exe = os.path.join(ROOT, "examples", "tunnel_replay")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "examples", "tunnel_replay.cpp"),
+                    "-L" + os.path.join(ROOT, "alchemy_amd", "lib"), "-lalchemy_hip",
+                    "-Wl,-rpath," + os.path.join(ROOT, "alchemy_amd", "lib")], check=True)
+    out = subprocess.run([exe, "3", "4"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "limbs (in/hint/out): 2/1/1 1/1/1 1/1/1" in out.stdout
+    assert out.stdout.count("decrypts to the plaintext evaluation: 4 of 4") == 3
+    assert out.stdout.strip().endswith("PASS")
