@@ -486,6 +486,57 @@ __global__ void k_hint_mac_v(DevRing<W> R, W* out, const W* digits, const W* hin
     }
 }
 
+// The E'-level form of k_hint_mac_v on its own (tunnels whose digits were transformed at dimension phi(e'), every 16-byte piece of S'
+// slots reading one aligned piece of the small vector: alch_tunnel::pieces_ok): without the other forms' address paths the kernel
+// needs far fewer registers than k_hint_mac_v's 128 + scratch.
+template <typename W, int TILE>
+__global__ void k_hint_mac_e(DevRing<W> R, W* out, const W* digits, const W* hint, size_t nct, u32 D, u32 grp, u32 hskip,
+                             const u32* slot_e, u32 n_d) {
+    typedef typename Vec4<W>::type V;
+    constexpr int VL = Vec4<W>::LANES;
+    const size_t n = (size_t)R.n;
+    const size_t Ln = (size_t)R.L * n;
+    const size_t ntile = (nct + TILE - 1) / TILE;
+    const size_t nv = n / VL;
+    ALCH_WALK_INIT(nv, R.L);
+    ALCH_WALK(w, ntile * (size_t)R.L * nv, wk) {
+        const size_t ct0 = wk.outer * TILE, rem = (size_t)wk.mid * n + (size_t)wk.k * VL;
+        const u32 limb = wk.mid;
+        const W q = R.mod[limb].q, qni = R.mod[limb].qni;
+        const u32 se = slot_e[(size_t)wk.k * VL];
+        V acc0[TILE], acc1[TILE];
+        const W* dv[TILE];
+#pragma unroll
+        for (int c = 0; c < TILE; ++c) {
+            const size_t ct = ct0 + c < nct ? ct0 + c : ct0;   // a dead lane of the tile recomputes ciphertext ct0 and stores nothing
+            acc0[c] = *reinterpret_cast<const V*>(out + 2 * ct * Ln + rem);
+            acc1[c] = *reinterpret_cast<const V*>(out + (2 * ct + 1) * Ln + rem);
+            dv[c] = digits + (ct * (size_t)D * R.L + limb) * (size_t)n_d + se;
+        }
+        const size_t dstep = (size_t)R.L * n_d;
+        for (u32 d = 0; d < D; ++d) {
+            const u32 hd = hskip ? d + (d / grp + 1) * hskip : d;
+            const V h0 = *reinterpret_cast<const V*>(hint + (size_t)(2 * hd) * Ln + rem);
+            const V h1 = *reinterpret_cast<const V*>(hint + (size_t)(2 * hd + 1) * Ln + rem);
+#pragma unroll
+            for (int c = 0; c < TILE; ++c) {
+                const V x = *reinterpret_cast<const V*>(dv[c] + (size_t)d * dstep);
+#pragma unroll
+                for (int e = 0; e < VL; ++e) {
+                    acc0[c][e] = csub((W)(acc0[c][e] + csub(mont_mul_lazy(x[e], h0[e], q, qni), q)), q);
+                    acc1[c][e] = csub((W)(acc1[c][e] + csub(mont_mul_lazy(x[e], h1[e], q, qni), q)), q);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < TILE; ++c) {
+            if (ct0 + c >= nct) continue;
+            *reinterpret_cast<V*>(out + 2 * (ct0 + c) * Ln + rem) = acc0[c];
+            *reinterpret_cast<V*>(out + (2 * (ct0 + c) + 1) * Ln + rem) = acc1[c];
+        }
+    }
+}
+
 // Rescale (a,b) -> b: dst limb j-1 = q_0^-1 (src_j - reduce(lift src_0)).  q0inv_m[j] = q_0^-1 mod q_j (Montgomery).
 template <typename W>
 __global__ void k_rescale_drop0(DevRing<W> R, const W* src, W* dst, size_t elems, Scal<W> q0inv_m) {
@@ -1696,8 +1747,12 @@ static int launch_gen_ks(alch_ring* r, const alch_hint* hint, const u32* a, cons
 
 template <typename W>
 static void launch_hint_mac(alch_ring* r, hipStream_t stream, W* out, const W* digits, const W* hint, size_t nct, u32 D,
-                            const W* diag = nullptr, u32 grp = 0, u32 hskip = 0, const u32* slot_e = nullptr, u32 n_d = 0) {
-    if (r->n % Vec4<W>::LANES == 0) {
+                            const W* diag = nullptr, u32 grp = 0, u32 hskip = 0, const u32* slot_e = nullptr, u32 n_d = 0,
+                            bool pieces_ok = false) {
+    if (slot_e && pieces_ok && !diag && r->n % Vec4<W>::LANES == 0) {
+        const size_t pieces = (nct + 3) / 4 * (size_t)r->L * (r->n / Vec4<W>::LANES);
+        hipLaunchKernelGGL((k_hint_mac_e<W, 4>), dim3(ew_grid(pieces)), dim3(256), 0, stream, dev_ring<W>(r), out, digits, hint, nct, D, grp, hskip, slot_e, n_d);
+    } else if (r->n % Vec4<W>::LANES == 0) {
         const size_t pieces = (nct + 3) / 4 * (size_t)r->L * (r->n / Vec4<W>::LANES);
         hipLaunchKernelGGL((k_hint_mac_v<W, 4>), dim3(ew_grid(pieces)), dim3(256), 0, stream, dev_ring<W>(r), out, digits, hint, nct, D, diag, grp, hskip, slot_e, n_d);
     } else {
@@ -2457,7 +2512,7 @@ static int do_tunnel(const alch_tunnel* t, alch_ring* rin, const void* in, void*
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("tunnel crt_digits launch: ") + hipGetErrorString(e));
         }
         launch_hint_mac<W>(rs, rs->stream, po, (const W*)dig, (const W*)t->ks, now, D * GD, (const W*)nullptr, Lx, compact ? (u32)dup : 0u,
-                           slot_e, rx->n);
+                           slot_e, rx->n, t->pieces_ok);
         HIP_TRY(hipGetLastError());
     }
     return ALCH_OK;
