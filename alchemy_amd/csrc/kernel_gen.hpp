@@ -878,13 +878,39 @@ __device__ __forceinline__ void gen_column(W* __restrict__ x, u32 b, u32 s, int 
 template <typename W, bool ZDOM, int OP, int NT = GEN_T>
 __device__ __forceinline__ void gen_columns_lds(W* lds, const GenDev<W>& G, const ColArith<W, ZDOM>& A, u32 skip_mask) {
     const u32 n = G.n;
+    typedef typename Vec4<W>::type V;
+    constexpr int VL = Vec4<W>::LANES;
     for (int l = 0; l < G.nfact; ++l) {
         const GenFact f = G.fact[l];
         if (f.p == 2 || ((skip_mask >> l) & 1u)) continue;
         const u32 step = f.mp * f.rts, span = f.dim * f.rts, ncol = n / (u32)(f.p - 1);
-        for (u32 c = threadIdx.x; c < ncol; c += NT) {
-            const u32 o = c / step, in = c % step;
-            gen_column<W, ZDOM, OP>(lds, o * span + in, step, f.p, A);
+        if (step == 1 && f.p == 13) {
+            // innermost axis of every reference index: a column is 12 contiguous words -- three 16-byte accesses and the recurrence
+            // in registers (the strided 4-byte form is 4-way bank-conflicted: lane stride 12 words)
+            for (u32 c = threadIdx.x; c < ncol; c += NT) {
+                W x[12];
+#pragma unroll
+                for (int t = 0; t < 12; t += VL) {
+                    const V v = *reinterpret_cast<const V*>(lds + c * 12u + t);
+#pragma unroll
+                    for (int e = 0; e < VL; ++e) x[t + e] = v[e];
+                }
+                gen_column<W, ZDOM, OP>(x, 0u, 1u, 13, A);
+#pragma unroll
+                for (int t = 0; t < 12; t += VL) {
+                    V v;
+#pragma unroll
+                    for (int e = 0; e < VL; ++e) v[e] = x[t + e];
+                    *reinterpret_cast<V*>(lds + c * 12u + t) = v;
+                }
+            }
+        } else {
+            // column c = (o, in): o = c / step by a reciprocal product (exact: c * step < 2^32), not a run-time division per column
+            const u32 rcp = step > 1 ? (u32)(((u64)1 << 32) / step) + 1u : 0u;
+            for (u32 c = threadIdx.x; c < ncol; c += NT) {
+                const u32 o = fdiv(c, step, rcp), in = c - o * step;
+                gen_column<W, ZDOM, OP>(lds, o * span + in, step, f.p, A);
+            }
         }
         lds_barrier();
     }
