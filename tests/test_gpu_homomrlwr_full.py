@@ -125,3 +125,47 @@ def test_tunnel_example_at_the_reference_parameters():
     assert "limbs (in/hint/out): 2/1/1 1/1/1 1/1/1" in out.stdout
     assert out.stdout.count("decrypts to the plaintext evaluation: 4 of 4") == 3
     assert out.stdout.strip().endswith("PASS")
+
+
+def test_ring_round_is_coefficientwise_rounding(replay):
+    """What ringRound MEANS (independent of Lol's internals and of this build's conventions): the five switches move the 64
+    decoding-basis coefficients c_j in Z_32 of x = s * a over H0 = O_128 into mod-2^5 CRT slots of H5 = O_4095, and the rescale tree
+    rounds every slot, v -> [8 <= v < 24] (the RLWR rounding floor((v + 8) / 16) mod 2; Language/RescaleTree.hs:64-87 on scalars).
+    So the plaintext result, reduced mod 2, must take the value 0 or 1 at every prime above 2 of O_4095 (144 of them, residue field
+    GF(2^12)), and the multiset of those values must be {round(c_j)} plus zeros.  This pins crtSet / decToCRT / evalLin and the tree
+    of the host layer to the function the example computes, not merely to each other."""
+    out, d = replay
+    assert out.returncode == 0
+    h5 = G.Index(H[5])
+    x0 = np.fromfile(os.path.join(d, "pt_h0.i64"), dtype=np.int64).tolist()           # x = s * a: Pow = Dec coefficients over O_128
+    res = np.fromfile(os.path.join(d, "expect_pow.i64"), dtype=np.int64).reshape(-1, h5.n)[0].tolist()
+    F = G.GF(2, G.mult_order(2, H[5]))
+    w = F.root_of_unity(H[5])
+    pw, acc = [], F.one                                      # powers of w as bit masks: addition in GF(2^12) is XOR
+    for _ in range(H[5]):
+        pw.append(sum(b << i for i, b in enumerate(acc)))
+        acc = F.mul(acc, w)
+    ex = [h5.pow_exponent(j) for j, c in enumerate(res) if c % 2]
+    reps = [c[0] for c in _cosets(H[5])]
+    assert len(reps) == 144
+    vals = []
+    for u in reps:
+        v = 0
+        for e in ex:
+            v ^= pw[u * e % H[5]]
+        vals.append(v)
+    assert all(v in (0, 1) for v in vals)
+    ones = sum(vals)
+    assert ones == sum(1 for c in x0 if 8 <= c % 32 < 24)
+    assert len(x0) == 64 and 0 < ones < 64
+
+
+def _cosets(m):
+    import math
+    seen = set()
+    for u in range(1, m):
+        if math.gcd(u, m) == 1 and u not in seen:
+            c, x = [], u
+            while x not in seen:
+                seen.add(x); c.append(x); x = x * 2 % m
+            yield c
