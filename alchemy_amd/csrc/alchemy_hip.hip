@@ -2249,6 +2249,73 @@ static bool is_suffix_ring(const alch_ring* small, const alch_ring* big) {
     return true;
 }
 
+// PT2CT's mul_ with a BaseBGad 2 hint whose ring has at least as many limbs as the operands': composed from the entry points'
+// own implementations.  modSwitch up is linear and the tensor product bilinear, so  modSwitch (a * b) = (up a) * (up b) / q_a  on the
+// old limbs and 0 on the added ones: both operands are switched up (alch_ct_mod_switch's kernel), the factor q_a^-1 rides on the
+// tensor product's scalar, then the BaseBGad key switch of alch_ct_mul_relin and the closing alch_ct_mod_switch.
+// A hint on FEWER limbs than the operands (what KSPNoise (BaseBGad 2) normally selects) would need the modSwitch of the quadratic
+// ciphertext (c0 on the decoding, c1 and c2 on the powerful basis) in front of the key switch: not served.
+template <typename W> static int do_mod_switch(alch_ring* rin, alch_ring* rout, const void* in, void* out, size_t batch, unsigned flags);
+static int mul_full_base2(const alch_hint* hint, const alch_buf* a, const alch_buf* b, alch_buf* out, size_t batch, const uint64_t* s_pre,
+                          unsigned flags) {
+    alch_ring* rh = hint->ring;
+    alch_ring* rin = a->ring;
+    alch_ring* rout = out->ring;
+    if (rin->L > rh->L)
+        return fail(ALCH_E_UNSUPPORTED, "BaseBGad 2 hint on fewer limbs than the operands: mul_ would rescale the quadratic ciphertext first (not served)");
+    auto same_ring = [](const alch_ring* x, const alch_ring* y) {           // another handle of the same (index, moduli)
+        if (x->m != y->m || x->word != y->word || x->L != y->L) return false;
+        for (int j = 0; j < x->L; ++j) if (x->q[j] != y->q[j]) return false;
+        return true;
+    };
+    if (!same_ring(rin, rh) && !is_suffix_ring(rin, rh)) return fail(ALCH_E_INVALID, "operand moduli must be the last limbs of the hint's ring (same word size)");
+    if (!same_ring(rout, rh) && !is_suffix_ring(rout, rh)) return fail(ALCH_E_INVALID, "output moduli must be the last limbs of the hint's ring (same word size)");
+    if (flags & ~(unsigned)ALCH_POW_OUT) return fail(ALCH_E_UNSUPPORTED, "only ALCH_POW_OUT is accepted");
+    if (!rh->has_crt) return fail(ALCH_E_NO_CRT, "the hint's ring has no CRT basis");
+    if (batch == 0) return ALCH_OK;
+    if (a->n_elems < 2 * batch || b->n_elems < 2 * batch || out->n_elems < 2 * batch) return fail(ALCH_E_INVALID, "buffers must hold 2*batch ring elements");
+    BIND(rh);
+    const int dup = rh->L - rin->L;
+    alch_buf *ua = nullptr, *ub = nullptr, *ks = nullptr;
+    int rc = ALCH_OK;
+    auto done = [&](int code) { if (ua) alch_buf_free(ua); if (ub) alch_buf_free(ub); if (ks && ks != out) alch_buf_free(ks); return code; };
+    // everything below is queued on ring_h's stream, behind the work of the other two rings
+    HIP_TRY(hipStreamSynchronize(rin->stream));
+    HIP_TRY(hipStreamSynchronize(rout->stream));
+    const alch_buf *pa = a, *pb = b;
+    uint64_t s_eff[MAXL];
+    for (int j = 0; j < rh->L; ++j) s_eff[j] = 1;
+    for (int j = dup; j < rh->L; ++j) {
+        u64 v = s_pre ? s_pre[j - dup] % rh->q[j] : 1;
+        for (int u = 0; u < dup; ++u) v = h_mulmod(v, h_invmod(rh->q[u] % rh->q[j], rh->q[j]), rh->q[j]);
+        s_eff[j] = v;
+    }
+    if (dup > 0) {
+        if ((rc = alch_buf_alloc(rh, 2 * batch, &ua)) != ALCH_OK || (rc = alch_buf_alloc(rh, 2 * batch, &ub)) != ALCH_OK) return done(rc);
+        // alch_ct_mod_switch up works on rout's stream = rh's here
+        rc = rh->word == 4 ? do_mod_switch<u32>(rin, rh, a->dptr, ua->dptr, batch, 0) : do_mod_switch<u64>(rin, rh, a->dptr, ua->dptr, batch, 0);
+        if (rc == ALCH_OK) rc = rh->word == 4 ? do_mod_switch<u32>(rin, rh, b->dptr, ub->dptr, batch, 0) : do_mod_switch<u64>(rin, rh, b->dptr, ub->dptr, batch, 0);
+        if (rc != ALCH_OK) return done(rc);
+        pa = ua; pb = ub;
+    }
+    const bool down = rout->L < rh->L;
+    if (down || (flags & ALCH_POW_OUT)) { if ((rc = alch_buf_alloc(rh, 2 * batch, &ks)) != ALCH_OK) return done(rc); }
+    else ks = out;
+    rc = rh->word == 4 ? do_mul_relin_unfused<u32>(rh, hint, pa->dptr, pb->dptr, ks->dptr, batch, s_eff)
+                       : do_mul_relin_unfused<u64>(rh, hint, pa->dptr, pb->dptr, ks->dptr, batch, s_eff);
+    if (rc != ALCH_OK) return done(rc);
+    if (down) {
+        rc = rh->word == 4 ? do_mod_switch<u32>(rh, rout, ks->dptr, out->dptr, batch, flags & ALCH_POW_OUT)
+                           : do_mod_switch<u64>(rh, rout, ks->dptr, out->dptr, batch, flags & ALCH_POW_OUT);
+    } else if (flags & ALCH_POW_OUT) {
+        HIP_TRY(hipMemcpyAsync(out->dptr, ks->dptr, 2 * batch * elem_bytes(rh), hipMemcpyDeviceToDevice, rh->stream));
+        rc = rh->word == 4 ? do_crt<u32>(rh, out->dptr, 0, 2 * batch, true) : do_crt<u64>(rh, out->dptr, 0, 2 * batch, true);
+    }
+    if (rc != ALCH_OK) return done(rc);
+    HIP_TRY(hipStreamSynchronize(rh->stream));                 // the scratch buffers are freed on return
+    return done(ALCH_OK);
+}
+
 extern "C" int alch_ct_mul_full(const alch_hint* hint, const alch_buf* a, const alch_buf* b, alch_buf* out, size_t batch,
                                 const uint64_t* s_pre, unsigned flags) {
     if (!hint || !a || !b || !out) return fail(ALCH_E_INVALID, "null argument");
@@ -2256,7 +2323,7 @@ extern "C" int alch_ct_mul_full(const alch_hint* hint, const alch_buf* a, const 
     alch_ring* rin = a->ring;
     alch_ring* rout = out->ring;
     if (b->ring != rin) return fail(ALCH_E_INVALID, "operands belong to different rings");
-    if (hint->gadget != ALCH_GAD_TRIV) return fail(ALCH_E_UNSUPPORTED, "only TrivGad hints");
+    if (hint->gadget != ALCH_GAD_TRIV) return mul_full_base2(hint, a, b, out, batch, s_pre, flags);
     if (!is_suffix_ring(rin, rh)) return fail(ALCH_E_INVALID, "operand moduli must be the last limbs of the hint's ring (same word size)");
     if (!is_suffix_ring(rout, rh)) return fail(ALCH_E_INVALID, "output moduli must be the last limbs of the hint's ring (same word size)");
     if (rh->L - rout->L > MAXDROP) return fail(ALCH_E_UNSUPPORTED, "at most 3 limbs dropped per call");

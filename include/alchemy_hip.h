@@ -295,7 +295,10 @@ int alch_ct_mul_relin(alch_ring *ring, const alch_hint *hint, const alch_buf *a,
  * for it.  s_pre[j] (j < L_in): toLSD scalars of both operands times the first modSwitch's toMSD scalar
  * (p^-1 mod q when both operands are LSD), NULL = 1; the library itself multiplies in the added moduli
  * (Rescale b -> (a,b): x -> (0, q_a x)) and performs both later toMSD as the identities they are.
- * flags: ALCH_POW_OUT leaves the result in the Pow basis (what Lol's rescale produces); operands are CRT basis. */
+ * flags: ALCH_POW_OUT leaves the result in the Pow basis (what Lol's rescale produces); operands are CRT basis.
+ * BaseBGad 2 hints: served when the hint's ring has at least as many limbs as the operands' (composed: both operands switched up,
+ * the BaseBGad key switch of alch_ct_mul_relin, the closing modSwitch); a hint on FEWER limbs than the operands -- what
+ * KSPNoise (BaseBGad 2) normally selects, PT2CT.hs:140 -- would rescale the quadratic ciphertext first: ALCH_E_UNSUPPORTED. */
 int alch_ct_mul_full(const alch_hint *hint, const alch_buf *a, const alch_buf *b, alch_buf *out, size_t batch,
                      const uint64_t *s_pre, unsigned flags);
 

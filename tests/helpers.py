@@ -40,7 +40,7 @@ def hint_to_crt_aos(ring_oracle, hint_pow):
     return out
 
 
-def oracle_full_mul(oracle_lib, n, qs_h, l_in, l_out, hint_crt, a0, a1, b0, b1, s_pre=None, pow_out=False):
+def oracle_full_mul(oracle_lib, n, qs_h, l_in, l_out, hint_crt, a0, a1, b0, b1, s_pre=None, pow_out=False, gadget="triv"):
     """PT2CT's whole mul_ (PT2CT.hs:172-177) composed from the C restatement's primitives:
     modSwitch (keySwitchQuadCirc hint (modSwitch (a * b))) with operands on the last l_in limbs of qs_h, the hint on
     all of qs_h and the result on the last l_out limbs.  Operands / hint / result in the CRT basis ((n, L) int64),
@@ -61,7 +61,8 @@ def oracle_full_mul(oracle_lib, n, qs_h, l_in, l_out, hint_crt, a0, a1, b0, b1, 
         scaled = o_in.scale(x, [mult % q for q in qs_h[dup:]])
         up.append(np.ascontiguousarray(np.concatenate([np.zeros((n, dup), dtype=np.int64), scaled], axis=1)))
     # keySwitchQuadCirc: [c0, c1] + sum_i crt(reduce d_i) * hint_i
-    digs = o_h.decompose_triv(o_h.crtinv(up[2]))
+    digs = o_h.decompose_triv(o_h.crtinv(up[2])) if gadget == "triv" else o_h.decompose_base2(o_h.crtinv(up[2]))
+    assert 2 * len(digs) == len(hint_crt)
     ks = [up[0], up[1]]
     for i, d in enumerate(digs):
         dc = o_h.crt(d)

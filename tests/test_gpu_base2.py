@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from conftest import ARITH_QS, CFG3_QS
-from helpers import from_aos, hint_to_crt_aos, load_golden, oracle_mul_relin_base2, to_aos
+from helpers import from_aos, hint_to_crt_aos, load_golden, oracle_full_mul, oracle_mul_relin_base2, to_aos
 
 pytestmark = pytest.mark.gpu
 
@@ -48,3 +48,38 @@ def test_base2_key_switch_matches_oracle(oracle_lib, logn, qs, batch):
         w0, w1 = oracle_mul_relin_base2(oracle_lib, n, qs, list(hint), a[2 * ct], a[2 * ct + 1], b[2 * ct], b[2 * ct + 1],
                                         s_pre=s_pre)
         assert np.array_equal(got[2 * ct], w0) and np.array_equal(got[2 * ct + 1], w1), f"mismatch ct {ct}"
+
+
+@pytest.mark.parametrize("logn,qs_h,l_in,l_out", [(6, ARITH_QS, 3, 2), (6, ARITH_QS, 2, 1), (11, CFG3_QS[:3], 2, 2), (11, CFG3_QS[:3], 3, 1),
+                                                  (13, CFG3_QS[:2], 1, 1)])
+def test_full_mul_with_base2_hint(oracle_lib, logn, qs_h, l_in, l_out):
+    """PT2CT's whole mul_ (modSwitch . keySwitchQuad hint . modSwitch $ a * b, PT2CT.hs:172-177) with a BaseBGad 2 hint
+    (PT2CT.hs:140) whose ring has at least as many limbs as the operands': alch_ct_mul_full against the C restatement's
+    op-by-op composition (tensor product on the operands' ring, modSwitch up of all three components, BaseBGad 2 decomposition of c2,
+    hint products, modSwitch down).  A hint on fewer limbs than the operands is refused (the quadratic modSwitch is not served)."""
+    import alchemy_amd as A
+    from alchemy_amd import capi
+    n, L, batch = 1 << logn, len(qs_h), 2
+    rng = np.random.default_rng(9100 + logn + l_in)
+    rh, rin, rout = A.Ring(2 * n, qs_h), A.Ring(2 * n, qs_h[L - l_in:]), A.Ring(2 * n, qs_h[L - l_out:])
+    D = rh.gadget_digits(capi.ALCH_GAD_BASE2)
+
+    def rand(count, qs):
+        return np.stack([np.stack([rng.integers(0, q, size=n, dtype=np.int64) for q in qs], axis=1) for _ in range(count)])
+
+    hint, a, b = rand(2 * D, qs_h), rand(2 * batch, qs_h[L - l_in:]), rand(2 * batch, qs_h[L - l_in:])
+    s_pre = [int(rng.integers(1, q)) for q in qs_h[L - l_in:]]
+    gh = rh.hint_load(hint, gadget=capi.ALCH_GAD_BASE2)
+    for pow_out in (False, True):
+        out = rout.alloc(2 * batch)
+        capi.ct_mul_full(gh, rin.upload(a), rin.upload(b), out, batch, s_pre=s_pre, flags=capi.ALCH_POW_OUT if pow_out else 0)
+        got = out.download()
+        for ct in range(batch):
+            w0, w1 = oracle_full_mul(oracle_lib, n, qs_h, l_in, l_out, list(hint), a[2 * ct], a[2 * ct + 1], b[2 * ct], b[2 * ct + 1],
+                                     s_pre, pow_out=pow_out, gadget="base2")
+            assert np.array_equal(got[2 * ct], w0) and np.array_equal(got[2 * ct + 1], w1), (ct, pow_out)
+    if L > 1:                                           # hint on fewer limbs than the operands
+        small = A.Ring(2 * n, qs_h[1:])
+        hs = small.hint_load(rand(2 * small.gadget_digits(capi.ALCH_GAD_BASE2), qs_h[1:]), gadget=capi.ALCH_GAD_BASE2)
+        with pytest.raises(capi.AlchemyError):
+            capi.ct_mul_full(hs, rh.alloc(2), rh.alloc(2), small.alloc(2), 1)
