@@ -59,6 +59,8 @@ struct alch_ring {
     int device = 0;                            // HIP device the ring's streams, tables and buffers live on
     LaunchOpts opts;                           // launch-structure options (alch_ring_set_option)
     bool one_stream = false;
+    int pipe = 0;                              // alch_ct_mul_relin: 1 = tensor kernels on the aux stream one chunk ahead of the key-switch kernels
+    hipEvent_t ev_pa[2] = {nullptr, nullptr}, ev_pb[2] = {nullptr, nullptr};
     unsigned rs_slots = 512;                   // resident workgroups of k_rescale_out (each owns a stash slot)
     size_t scratch_mib = 4096;                 // scratch of the composed (unfused) paths: digits + intermediates of one chunk
                                                // (n = 2^16: 66.3 k op/s at 1 GiB, 73.3 k at 4 GiB, 77.7 k at 16 GiB -- small chunks leave CUs idle)
@@ -1028,6 +1030,7 @@ extern "C" int alch_ring_destroy(alch_ring* r) {
     if (r->ev0) (void)hipEventDestroy(r->ev0);
     if (r->ev1) (void)hipEventDestroy(r->ev1);
     if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
+    for (int e = 0; e < 2; ++e) { if (r->ev_pa[e]) (void)hipEventDestroy(r->ev_pa[e]); if (r->ev_pb[e]) (void)hipEventDestroy(r->ev_pb[e]); }
     if (r->ev_join) (void)hipEventDestroy(r->ev_join);
     if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamDestroy(r->aux); }
     if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
@@ -1058,6 +1061,7 @@ extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) 
     const std::string k(name);
     if (k == "chunk") { if (value < 8) return fail(ALCH_E_INVALID, "chunk must be >= 8"); r->chunk = (size_t)value; }
     else if (k == "one_stream") r->one_stream = value != 0;
+    else if (k == "pipe") r->pipe = value != 0;
     else if (k == "ks_grid") { if (value < 1) return fail(ALCH_E_INVALID, "ks_grid must be >= 1"); r->opts.ks_grid = (unsigned)value; }
     else if (k == "ti_grid") r->opts.ti_grid = (int)value;
     else if (k == "ti_split") { if (value < 0) return fail(ALCH_E_INVALID, "ti_split must be >= 0"); r->opts.ti_split = (int)value; }
@@ -1909,6 +1913,37 @@ static int do_mul_relin(alch_ring* r, const alch_hint* hint, const void* a, cons
         HIP_TRY(hipStreamWaitEvent(r->aux, r->ev_fork, 0));
     }
     size_t idx = 0;
+    if (two && r->pipe) {
+        // Anti-phase pipeline: every tensor kernel on the aux stream, every key-switch kernel on the ring's stream, the tensor
+        // kernel of chunk k+1 released as soon as chunk k-1's key switch has freed its digit scratch -- it shares the CUs with
+        // chunk k's key switch (a latency-bound kernel next to a VALU-bound one) instead of with another tensor kernel.
+        for (int e = 0; e < 2; ++e) {
+            if (!r->ev_pa[e]) HIP_TRY(hipEventCreateWithFlags(&r->ev_pa[e], hipEventDisableTiming));
+            if (!r->ev_pb[e]) HIP_TRY(hipEventCreateWithFlags(&r->ev_pb[e], hipEventDisableTiming));
+        }
+        for (size_t done = 0; done < batch; done += chunk, ++idx) {
+            const size_t now = std::min(chunk, batch - done);
+            const int par = (int)(idx & 1);
+            c.digits = reinterpret_cast<char*>(r->ws_digits) + (par ? dig_bytes : 0);
+            c.a = reinterpret_cast<const W*>(a) + done * ct_words;
+            c.b = reinterpret_cast<const W*>(b) + done * ct_words;
+            c.out = reinterpret_cast<W*>(out) + done * ct_words;
+            c.nct = now;
+            if (idx >= 2) HIP_TRY(hipStreamWaitEvent(r->aux, r->ev_pb[par], 0));
+            c.stream = r->aux;
+            c.op = OP_TENSOR_INTT;
+            hipError_t e = dispatch(r->logn, c);
+            if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("tensor_intt launch: ") + hipGetErrorString(e));
+            HIP_TRY(hipEventRecord(r->ev_pa[par], r->aux));
+            HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_pa[par], 0));
+            c.stream = r->stream;
+            c.op = OP_KS_ACCUM;
+            e = dispatch(r->logn, c);
+            if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("ks_accum launch: ") + hipGetErrorString(e));
+            HIP_TRY(hipEventRecord(r->ev_pb[par], r->stream));
+        }
+        return ALCH_OK;                                    // the last key switch is on the ring's stream, behind every tensor kernel
+    }
     for (size_t done = 0; done < batch; done += chunk, ++idx) {
         const size_t now = std::min(chunk, batch - done);
         const bool odd = two && (idx & 1);
@@ -2253,32 +2288,99 @@ static bool is_suffix_ring(const alch_ring* small, const alch_ring* big) {
 // own implementations.  modSwitch up is linear and the tensor product bilinear, so  modSwitch (a * b) = (up a) * (up b) / q_a  on the
 // old limbs and 0 on the added ones: both operands are switched up (alch_ct_mod_switch's kernel), the factor q_a^-1 rides on the
 // tensor product's scalar, then the BaseBGad key switch of alch_ct_mul_relin and the closing alch_ct_mod_switch.
-// A hint on FEWER limbs than the operands (what KSPNoise (BaseBGad 2) normally selects) would need the modSwitch of the quadratic
-// ciphertext (c0 on the decoding, c1 and c2 on the powerful basis) in front of the key switch: not served.
-template <typename W> static int do_mod_switch(alch_ring* rin, alch_ring* rout, const void* in, void* out, size_t batch, unsigned flags);
+// A hint on FEWER limbs than the operands (KSPNoise (BaseBGad 2) = p + KSAccumPNoise can sit one limb below the product's
+// p + MulPNoise): mul_full_base2_down below.
+template <typename W> static int do_mod_switch(alch_ring* rin, alch_ring* rout, const void* in, void* out, size_t batch, unsigned flags, int per = 2);
+
+// keySwitchQuadCirc's second half for BaseBGad 2, from a c2 that is already on the powerful basis of the hint's ring:
+// ks (c0, c1 on the CRT basis) += sum_d crt(digit_d(c2)) * hint_d.  The same kernels as do_mul_relin_unfused's base-2 branches.
+template <typename W>
+static int ks_base2_from_pow(alch_ring* r, const alch_hint* hint, void* ks, const void* c2pow, size_t batch) {
+    Scal<u32> first, kd;
+    const u32 D = (u32)base2_layout(r, first, kd);
+    const size_t eb = elem_bytes(r);
+    size_t chunk = std::min(batch, std::max<size_t>(1, (r->scratch_mib << 20) / ((size_t)D * eb)));
+    int rc = ensure_ws(&r->ws_digits, &r->ws_digits_bytes, chunk * D * eb);
+    if (rc != ALCH_OK) return rc;
+    char* dig = reinterpret_cast<char*>(r->ws_digits);
+    for (size_t done = 0; done < batch; done += chunk) {
+        const size_t now = std::min(chunk, batch - done);
+        const char* c2 = reinterpret_cast<const char*>(c2pow) + done * eb;
+        W* po = reinterpret_cast<W*>(reinterpret_cast<char*>(ks) + done * 2 * eb);
+        if (!split_ring(r) && !r->gen) {                             // digits computed in the transforms' loader
+            NttCall<W> dc{};
+            dc.op = OP_CRT_BASE2;
+            dc.ring = &dev_ring<W>(r);
+            dc.stream = r->stream;
+            dc.src = reinterpret_cast<const W*>(c2);
+            dc.data = reinterpret_cast<W*>(dig);
+            dc.npoly = now * (size_t)D * (size_t)r->L;
+            dc.b2_first = first; dc.b2_kd = kd; dc.b2_D = D;
+            hipError_t e = dispatch(r->logn, dc);
+            if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("crt_base2 launch: ") + hipGetErrorString(e));
+        } else {
+            for (size_t y0 = 0; y0 < now; y0 += 32768) {             // grid.y is 16-bit
+                const unsigned ny = (unsigned)std::min<size_t>(32768, now - y0);
+                hipLaunchKernelGGL((k_decompose_base2<W>), dim3(ew_grid(elem_words(r)), ny), dim3(256), 0, r->stream, dev_ring<W>(r),
+                                   reinterpret_cast<const W*>(c2 + y0 * eb), reinterpret_cast<W*>(dig + y0 * D * eb), first, kd, D);
+                HIP_TRY(hipGetLastError());
+            }
+            if ((rc = do_crt<W>(r, dig, 0, now * D, false)) != ALCH_OK) return rc;
+        }
+        launch_hint_mac<W>(r, r->stream, po, (const W*)dig, (const W*)hint->dptr, now, D);
+        HIP_TRY(hipGetLastError());
+    }
+    return ALCH_OK;
+}
+
+// mul_ under a BaseBGad 2 hint that lives on FEWER limbs than the operands (PT2CT.hs:140,164: the product sits at p + MulPNoise units
+// rounded up to whole limbs, the hint at p + KSAccumPNoise): the leading modSwitch goes DOWN on the quadratic ciphertext -- c0 on the
+// decoding basis, c1 and c2 on the powerful basis -- before the key switch.
+template <typename W>
+static int mul_full_base2_down(const alch_hint* hint, alch_ring* rin, alch_ring* rh, const void* a, const void* b, void* ks, size_t batch,
+                               const uint64_t* s_pre, alch_buf* t, alch_buf* c2, alch_buf* c2h) {
+    Scal<W> sr2;
+    scal_to_mont<W>(rin, s_pre, 2, sr2);
+    GTab<W> gt{};
+    if (rin->gen) for (int j = 0; j < rin->L; ++j) gt.p[j] = rin->gh.rad > 1 ? gen_dev<W>(rin).gcrt[j] : nullptr;
+    const size_t words = batch * elem_words(rin);
+    // the tensor product and both rescales run on the operands' stream, the key switch on the hint's
+    ALCH_LAUNCH_VW(k_tensor_ew, rin, words, rin->stream, dev_ring<W>(rin), (const W*)a, (const W*)b, (W*)t->dptr, (W*)c2->dptr, batch, sr2, 0,
+                   (W*)nullptr, gt);
+    HIP_TRY(hipGetLastError());
+    int rc;
+    if ((rc = do_mod_switch<W>(rin, rh, t->dptr, ks, batch, 0)) != ALCH_OK) return rc;
+    if ((rc = do_mod_switch<W>(rin, rh, c2->dptr, c2h->dptr, batch, ALCH_POW_OUT, 1)) != ALCH_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(rin->stream));
+    return ks_base2_from_pow<W>(rh, hint, ks, c2h->dptr, batch);
+}
 static int mul_full_base2(const alch_hint* hint, const alch_buf* a, const alch_buf* b, alch_buf* out, size_t batch, const uint64_t* s_pre,
                           unsigned flags) {
     alch_ring* rh = hint->ring;
     alch_ring* rin = a->ring;
     alch_ring* rout = out->ring;
-    if (rin->L > rh->L)
-        return fail(ALCH_E_UNSUPPORTED, "BaseBGad 2 hint on fewer limbs than the operands: mul_ would rescale the quadratic ciphertext first (not served)");
+    const bool in_down = rin->L > rh->L;                       // the leading modSwitch goes down, on the quadratic ciphertext
     auto same_ring = [](const alch_ring* x, const alch_ring* y) {           // another handle of the same (index, moduli)
         if (x->m != y->m || x->word != y->word || x->L != y->L) return false;
         for (int j = 0; j < x->L; ++j) if (x->q[j] != y->q[j]) return false;
         return true;
     };
-    if (!same_ring(rin, rh) && !is_suffix_ring(rin, rh)) return fail(ALCH_E_INVALID, "operand moduli must be the last limbs of the hint's ring (same word size)");
+    if (in_down ? !is_suffix_ring(rh, rin) : (!same_ring(rin, rh) && !is_suffix_ring(rin, rh)))
+        return fail(ALCH_E_INVALID, "operand moduli must be the last limbs of the hint's ring, or the hint's the last limbs of the operands' (same word size)");
+    if (in_down && !rin->has_crt) return fail(ALCH_E_NO_CRT, "the operands' ring has no CRT basis");
     if (!same_ring(rout, rh) && !is_suffix_ring(rout, rh)) return fail(ALCH_E_INVALID, "output moduli must be the last limbs of the hint's ring (same word size)");
     if (flags & ~(unsigned)ALCH_POW_OUT) return fail(ALCH_E_UNSUPPORTED, "only ALCH_POW_OUT is accepted");
     if (!rh->has_crt) return fail(ALCH_E_NO_CRT, "the hint's ring has no CRT basis");
     if (batch == 0) return ALCH_OK;
     if (a->n_elems < 2 * batch || b->n_elems < 2 * batch || out->n_elems < 2 * batch) return fail(ALCH_E_INVALID, "buffers must hold 2*batch ring elements");
     BIND(rh);
-    const int dup = rh->L - rin->L;
-    alch_buf *ua = nullptr, *ub = nullptr, *ks = nullptr;
+    const int dup = in_down ? 0 : rh->L - rin->L;
+    alch_buf *ua = nullptr, *ub = nullptr, *ks = nullptr, *c2h = nullptr;
     int rc = ALCH_OK;
-    auto done = [&](int code) { if (ua) alch_buf_free(ua); if (ub) alch_buf_free(ub); if (ks && ks != out) alch_buf_free(ks); return code; };
+    auto done = [&](int code) {
+        if (ua) alch_buf_free(ua); if (ub) alch_buf_free(ub); if (c2h) alch_buf_free(c2h); if (ks && ks != out) alch_buf_free(ks);
+        return code;
+    };
     // everything below is queued on ring_h's stream, behind the work of the other two rings
     HIP_TRY(hipStreamSynchronize(rin->stream));
     HIP_TRY(hipStreamSynchronize(rout->stream));
@@ -2301,6 +2403,14 @@ static int mul_full_base2(const alch_hint* hint, const alch_buf* a, const alch_b
     const bool down = rout->L < rh->L;
     if (down || (flags & ALCH_POW_OUT)) { if ((rc = alch_buf_alloc(rh, 2 * batch, &ks)) != ALCH_OK) return done(rc); }
     else ks = out;
+    if (in_down) {
+        // ua: the (c0, c1) pairs, ub: c2, both on the operands' ring; c2h: c2 on the hint's ring, powerful basis
+        if ((rc = alch_buf_alloc(rin, 2 * batch, &ua)) != ALCH_OK || (rc = alch_buf_alloc(rin, batch, &ub)) != ALCH_OK ||
+            (rc = alch_buf_alloc(rh, batch, &c2h)) != ALCH_OK) return done(rc);
+        HIP_TRY(hipStreamSynchronize(rh->stream));
+        rc = rh->word == 4 ? mul_full_base2_down<u32>(hint, rin, rh, a->dptr, b->dptr, ks->dptr, batch, s_pre, ua, ub, c2h)
+                           : mul_full_base2_down<u64>(hint, rin, rh, a->dptr, b->dptr, ks->dptr, batch, s_pre, ua, ub, c2h);
+    } else
     rc = rh->word == 4 ? do_mul_relin_unfused<u32>(rh, hint, pa->dptr, pb->dptr, ks->dptr, batch, s_eff)
                        : do_mul_relin_unfused<u64>(rh, hint, pa->dptr, pb->dptr, ks->dptr, batch, s_eff);
     if (rc != ALCH_OK) return done(rc);
@@ -2623,9 +2733,12 @@ extern "C" int alch_ct_tunnel(const alch_tunnel* t, const alch_buf* in, alch_buf
 // ------------------------------------------------------------------------------------------------------
 // SymmSHE modSwitch on batches of linear ciphertexts (Eval.hs:130; PT2CT.hs:177,224-229)
 // ------------------------------------------------------------------------------------------------------
+// per = 2: linear ciphertexts (c0 rescaled on the decoding basis, c1 on the powerful basis); per = 1: `batch` single ring elements, all on
+// the powerful basis (the c2 of a quadratic ciphertext: SymmSHE's modSwitch rescales every coefficient above c0 with rescalePow)
 template <typename W>
-static int do_mod_switch(alch_ring* rin, alch_ring* rout, const void* in, void* out, size_t batch, unsigned flags) {
+static int do_mod_switch(alch_ring* rin, alch_ring* rout, const void* in, void* out, size_t batch, unsigned flags, int per) {
     const size_t n = rin->n;
+    const size_t P = (size_t)per;
     if (rout->L > rin->L) {                                   // up: Rescale b -> (a, b), any basis
         const int dup = rout->L - rin->L;
         uint64_t mult[MAXL] = {0};
@@ -2636,58 +2749,58 @@ static int do_mod_switch(alch_ring* rin, alch_ring* rout, const void* in, void* 
         }
         Scal<W> sm;
         scal_to_mont<W>(rout, mult, 1, sm);
-        const size_t total = 2 * batch * elem_words(rout);
+        const size_t total = P * batch * elem_words(rout);
         hipLaunchKernelGGL((k_rescale_up<W>), dim3(ew_grid(total)), dim3(256), 0, rout->stream, dev_ring<W>(rout), (const W*)in, (W*)out,
-                           2 * batch, dup, sm);
+                           P * batch, dup, sm);
         HIP_TRY(hipGetLastError());
         return ALCH_OK;
     }
     // down: Pow basis (c0 on the Dec basis for a general index), one limb at a time, outermost first
     const int L = rin->L, ddn = L - rout->L;
     const size_t eb = elem_bytes(rin);
-    const bool dec_c0 = rin->gen && rin->gh.rad > 1;
+    const bool dec_c0 = per == 2 && rin->gen && rin->gh.rad > 1;
     if (rin->gen && rin->opts.rs_lin && ddn <= MAXDROP && !(flags & ALCH_POW_IN)) {
         // kept limbs stay in the CRT basis (k_gen_rescale_drop / k_gen_rescale_keep)
         DropTab<W> dt;
         fill_drop_tab<W>(rin, ddn, dt);
-        const size_t per = 2 * (size_t)ddn * n * sizeof(W);
-        size_t chunk = std::min(batch, std::max<size_t>(1, (rin->scratch_mib << 20) / per));
-        int rc = ensure_ws(&rin->ws_full, &rin->ws_full_bytes, chunk * per);
+        const size_t per_b = P * (size_t)ddn * n * sizeof(W);
+        size_t chunk = std::min(batch, std::max<size_t>(1, (rin->scratch_mib << 20) / per_b));
+        int rc = ensure_ws(&rin->ws_full, &rin->ws_full_bytes, chunk * per_b);
         if (rc != ALCH_OK) return rc;
         for (size_t done = 0; done < batch; done += chunk) {
             const size_t now = std::min(chunk, batch - done);
             hipError_t e = gen_rescale_lin_dispatch(dev_ring<W>(rin), gen_dev<W>(rin),
-                                                    reinterpret_cast<const W*>(reinterpret_cast<const char*>(in) + done * 2 * eb),
+                                                    reinterpret_cast<const W*>(reinterpret_cast<const char*>(in) + done * P * eb),
                                                     reinterpret_cast<W*>(rin->ws_full),
-                                                    reinterpret_cast<W*>(reinterpret_cast<char*>(out) + done * 2 * elem_bytes(rout)), dt,
-                                                    dec_c0 ? 1 : 0, 2 * now, rin->stream, (flags & ALCH_POW_OUT) != 0);
+                                                    reinterpret_cast<W*>(reinterpret_cast<char*>(out) + done * P * elem_bytes(rout)), dt,
+                                                    dec_c0 ? 1 : 0, P * now, rin->stream, (flags & ALCH_POW_OUT) != 0);
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("rescale launch: ") + hipGetErrorString(e));
         }
         return ALCH_OK;
     }
-    const size_t per_ct = 3 * 2 * eb;                          // Pow copy + ping + pong
+    const size_t per_ct = 3 * P * eb;                          // Pow copy + ping + pong
     size_t chunk = std::max<size_t>(1, (rin->scratch_mib << 20) / per_ct);
     chunk = std::min(chunk, batch);
     int rc = ensure_ws(&rin->ws_full, &rin->ws_full_bytes, chunk * per_ct);
     if (rc != ALCH_OK) return rc;
     char* cur0 = reinterpret_cast<char*>(rin->ws_full);
-    char* ping = cur0 + chunk * 2 * eb;
-    char* pong = ping + chunk * 2 * eb;
+    char* ping = cur0 + chunk * P * eb;
+    char* pong = ping + chunk * P * eb;
     auto suffix = [&](int u) {
         DevRing<W> d = dev_ring<W>(rin);
         d.L = L - u;
         for (int j = 0; j + u < L; ++j) d.mod[j] = d.mod[j + u];
         return d;
     };
-    const size_t in_bytes = 2 * eb, out_bytes = 2 * elem_bytes(rout);
+    const size_t in_bytes = P * eb, out_bytes = P * elem_bytes(rout);
     for (size_t done = 0; done < batch; done += chunk) {
         const size_t now = std::min(chunk, batch - done);
         const char* src = reinterpret_cast<const char*>(in) + done * in_bytes;
         if (flags & ALCH_POW_IN) HIP_TRY(hipMemcpyAsync(cur0, src, now * in_bytes, hipMemcpyDeviceToDevice, rin->stream));
-        else if (rin->gen || !split_ring(rin)) { if ((rc = do_crt<W>(rin, cur0, 0, 2 * now, true, src)) != ALCH_OK) return rc; }
+        else if (rin->gen || !split_ring(rin)) { if ((rc = do_crt<W>(rin, cur0, 0, P * now, true, src)) != ALCH_OK) return rc; }
         else {                                                 // split transforms work in place
             HIP_TRY(hipMemcpyAsync(cur0, src, now * in_bytes, hipMemcpyDeviceToDevice, rin->stream));
-            if ((rc = do_crt<W>(rin, cur0, 0, 2 * now, true)) != ALCH_OK) return rc;
+            if ((rc = do_crt<W>(rin, cur0, 0, P * now, true)) != ALCH_OK) return rc;
         }
         if (dec_c0 && (rc = do_columns<W>(rin, GEN_LINV, cur0, 0, now, 2)) != ALCH_OK) return rc;
         char* cur = cur0;
@@ -2701,13 +2814,13 @@ static int do_mod_switch(alch_ring* rin, alch_ring* rout, const void* in, void* 
                 const u64 qj = rin->q[u + j];
                 sm.v[j] = (W)h_mulmod(h_powmod(rin->q[u] % qj, qj - 2, qj), h_powmod(2, (u64)bits, qj), qj);
             }
-            const size_t total = 2 * now * (size_t)(rs.L - 1) * n;
-            hipLaunchKernelGGL((k_rescale_drop0<W>), dim3(ew_grid(total)), dim3(256), 0, rin->stream, rs, (const W*)cur, (W*)nxt, 2 * now, sm);
+            const size_t total = P * now * (size_t)(rs.L - 1) * n;
+            hipLaunchKernelGGL((k_rescale_drop0<W>), dim3(ew_grid(total)), dim3(256), 0, rin->stream, rs, (const W*)cur, (W*)nxt, P * now, sm);
             HIP_TRY(hipGetLastError());
             cur = nxt;
         }
         if (dec_c0 && (rc = do_columns<W>(rout, GEN_L, out, 2 * done, now, 2, rin->stream)) != ALCH_OK) return rc;
-        if (!(flags & ALCH_POW_OUT) && (rc = do_crt<W>(rout, out, 2 * done, 2 * now, false, nullptr, rin->stream)) != ALCH_OK) return rc;
+        if (!(flags & ALCH_POW_OUT) && (rc = do_crt<W>(rout, out, P * done, P * now, false, nullptr, rin->stream)) != ALCH_OK) return rc;
     }
     return ALCH_OK;
 }

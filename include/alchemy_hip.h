@@ -121,7 +121,8 @@ int alch_ring_n(const alch_ring *ring, uint32_t *n, int *L, int *word_bytes);
 int alch_ring_set_stream(alch_ring *ring, void *hip_stream);
 /* Launch-structure options of the fused hot-path kernels (results never depend on them; tests sweep them).  The
  * library reads no environment variable.  Names: "chunk" (ciphertexts per launch group, >= 8, default 1024),
- * "one_stream" (0/1: do not alternate chunks over two streams), "ks_grid" (persistent workgroups of the key-switch
+ * "one_stream" (0/1: do not alternate chunks over two streams), "pipe" (1 = tensor kernels on one stream, one chunk ahead of the
+ * key-switch kernels on the other; measured slower, default 0), "ks_grid" (persistent workgroups of the key-switch
  * kernel, default 4096), "ti_split" / "ti_grid" (form and grid of the tensor + crtInv kernel), "crt_half" (0 = whole-polynomial crt at 128 KiB), "rs_half" (1 = the closing rescale at n = 2^15 always as two launches of half-size workgroups), "tunnel_ep" (read by alch_tunnel_create on ring_s: 0 = transform
  * the embedded E'-coefficients at dimension phi(s') instead of phi(e')), "tunnel_fused" (alch_ct_tunnel with TrivGad hints: 2 or 4 = digit transforms and hint products in one kernel with that many digits side by side, 0 = through HBM), "gen_nt" (threads per workgroup of the general-index transform kernels: 128, 256, 512; 0 = by ring size), "rs_lin" / "gen_fused" (0 = the
  * composed forms of the closing rescale / the general-index key switch), "scratch_mib", "rs_slots" (resident
@@ -296,9 +297,11 @@ int alch_ct_mul_relin(alch_ring *ring, const alch_hint *hint, const alch_buf *a,
  * (p^-1 mod q when both operands are LSD), NULL = 1; the library itself multiplies in the added moduli
  * (Rescale b -> (a,b): x -> (0, q_a x)) and performs both later toMSD as the identities they are.
  * flags: ALCH_POW_OUT leaves the result in the Pow basis (what Lol's rescale produces); operands are CRT basis.
- * BaseBGad 2 hints: served when the hint's ring has at least as many limbs as the operands' (composed: both operands switched up,
- * the BaseBGad key switch of alch_ct_mul_relin, the closing modSwitch); a hint on FEWER limbs than the operands -- what
- * KSPNoise (BaseBGad 2) normally selects, PT2CT.hs:140 -- would rescale the quadratic ciphertext first: ALCH_E_UNSUPPORTED. */
+ * BaseBGad 2 hints (composed from the entry points' own kernels): when the hint's ring has at least as many limbs as the operands',
+ * both operands are switched up, then the BaseBGad key switch of alch_ct_mul_relin and the closing modSwitch.  When KSPNoise
+ * (BaseBGad 2) leaves the hint on FEWER limbs than the product (PT2CT.hs:140 against :164; ring_h = the last limbs of ring_in) the
+ * leading modSwitch goes down on the QUADRATIC ciphertext: tensor product on ring_in, c0 rescaled on the decoding basis, c1 and c2 on
+ * the powerful basis, BaseBGad 2 digits of c2 on ring_h, hint products, closing modSwitch to ring_out. */
 int alch_ct_mul_full(const alch_hint *hint, const alch_buf *a, const alch_buf *b, alch_buf *out, size_t batch,
                      const uint64_t *s_pre, unsigned flags);
 

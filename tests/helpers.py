@@ -78,6 +78,39 @@ def oracle_full_mul(oracle_lib, n, qs_h, l_in, l_out, hint_crt, a0, a1, b0, b1, 
     return out[0], out[1]
 
 
+def oracle_full_mul_base2_down(oracle_lib, n, qs_in, l_h, l_out, hint_crt, a0, a1, b0, b1, s_pre=None, pow_out=False, m=None):
+    """PT2CT's whole mul_ with a BaseBGad 2 hint on FEWER limbs than the operands (PT2CT.hs:140,164), from the C restatement's
+    primitives: (*) on the operands' ring qs_in (mulG on a general index m), modSwitch DOWN of the quadratic ciphertext to the last l_h
+    limbs (rescaleDec on c0, rescalePow on c1 and c2), BaseBGad 2 decomposition of c2, hint products, modSwitch down to l_out limbs."""
+    L = len(qs_in)
+    ring = (lambda qs: oracle_lib.GenRing(m, qs)) if m else (lambda qs: oracle_lib.Ring(n, qs))
+    o_in, o_h, o_out = ring(qs_in), ring(qs_in[L - l_h:]), ring(qs_in[L - l_out:])
+    s = list(s_pre) if s_pre is not None else [1] * L
+    c = [o_in.mul(a0, b0), o_in.add(o_in.mul(a0, b1), o_in.mul(a1, b0)), o_in.mul(a1, b1)]
+    c = [o_in.scale(o_in.mulg_crt(x) if m else x, s) for x in c]
+
+    def down(x_pow, l_from, l_to, dec):
+        cur = ring(qs_in[L - l_from:]).linv(x_pow) if dec else x_pow
+        for k in range(l_from, l_to, -1):
+            cur = ring(qs_in[L - k:]).rescale_drop0(cur)
+        return ring(qs_in[L - l_to:]).l(cur) if dec else cur
+
+    dec0 = bool(m)                                   # two-power index: the decoding basis is the powerful basis
+    low = [down(o_in.crtinv(x), L, l_h, dec0 and comp == 0) for comp, x in enumerate(c)]
+    digs = decompose_base2(low[2], qs_in[L - l_h:]) if m else o_h.decompose_base2(low[2])
+    assert 2 * len(digs) == len(hint_crt)
+    ks = [o_h.crt(low[0]), o_h.crt(low[1])]
+    for i, d in enumerate(digs):
+        dc = o_h.crt(d)
+        ks[0] = o_h.add(ks[0], o_h.mul(dc, hint_crt[2 * i]))
+        ks[1] = o_h.add(ks[1], o_h.mul(dc, hint_crt[2 * i + 1]))
+    out = []
+    for comp, x in enumerate(ks):
+        cur = down(o_h.crtinv(x), l_h, l_out, dec0 and comp == 0)
+        out.append(cur if pow_out else o_out.crt(cur))
+    return out[0], out[1]
+
+
 def oracle_mul_relin_base2(oracle_lib, n, qs, hint_crt, a0, a1, b0, b1, s_pre=None, pow_out=False):
     """keySwitchQuadCirc hint (a * b) with a BaseBGad 2 hint, composed from the C restatement's primitives
     (CRT-basis operands and hint).  Pinned to the exact model by tests/golden/mul_relin_base2_small.json."""

@@ -56,7 +56,7 @@ def test_full_mul_with_base2_hint(oracle_lib, logn, qs_h, l_in, l_out):
     """PT2CT's whole mul_ (modSwitch . keySwitchQuad hint . modSwitch $ a * b, PT2CT.hs:172-177) with a BaseBGad 2 hint
     (PT2CT.hs:140) whose ring has at least as many limbs as the operands': alch_ct_mul_full against the C restatement's
     op-by-op composition (tensor product on the operands' ring, modSwitch up of all three components, BaseBGad 2 decomposition of c2,
-    hint products, modSwitch down).  A hint on fewer limbs than the operands is refused (the quadratic modSwitch is not served)."""
+    hint products, modSwitch down)."""
     import alchemy_amd as A
     from alchemy_amd import capi
     n, L, batch = 1 << logn, len(qs_h), 2
@@ -78,8 +78,63 @@ def test_full_mul_with_base2_hint(oracle_lib, logn, qs_h, l_in, l_out):
             w0, w1 = oracle_full_mul(oracle_lib, n, qs_h, l_in, l_out, list(hint), a[2 * ct], a[2 * ct + 1], b[2 * ct], b[2 * ct + 1],
                                      s_pre, pow_out=pow_out, gadget="base2")
             assert np.array_equal(got[2 * ct], w0) and np.array_equal(got[2 * ct + 1], w1), (ct, pow_out)
-    if L > 1:                                           # hint on fewer limbs than the operands
-        small = A.Ring(2 * n, qs_h[1:])
-        hs = small.hint_load(rand(2 * small.gadget_digits(capi.ALCH_GAD_BASE2), qs_h[1:]), gadget=capi.ALCH_GAD_BASE2)
-        with pytest.raises(capi.AlchemyError):
-            capi.ct_mul_full(hs, rh.alloc(2), rh.alloc(2), small.alloc(2), 1)
+
+
+@pytest.mark.parametrize("logn,qs_in,l_h,l_out", [(6, ARITH_QS, 2, 2), (6, ARITH_QS, 2, 1), (6, ARITH_QS, 1, 1), (11, CFG3_QS[:3], 2, 1),
+                                                  (13, CFG3_QS[:2], 1, 1)])
+def test_full_mul_with_base2_hint_on_fewer_limbs(oracle_lib, logn, qs_in, l_h, l_out):
+    """The same mul_ when KSPNoise (BaseBGad 2) leaves the hint on FEWER limbs than the product (PT2CT.hs:140 against :164 -- the
+    product sits at p + MulPNoise units rounded up to whole limbs): the leading modSwitch then goes DOWN on the quadratic ciphertext,
+    c0 on the decoding basis, c1 and c2 on the powerful basis, before the key switch.  alch_ct_mul_full against the C restatement's
+    op-by-op composition."""
+    import alchemy_amd as A
+    from alchemy_amd import capi
+    from helpers import oracle_full_mul_base2_down
+    n, L, batch = 1 << logn, len(qs_in), 3
+    rng = np.random.default_rng(9300 + logn + l_h + l_out)
+    rin, rh, rout = A.Ring(2 * n, qs_in), A.Ring(2 * n, qs_in[L - l_h:]), A.Ring(2 * n, qs_in[L - l_out:])
+    D = rh.gadget_digits(capi.ALCH_GAD_BASE2)
+
+    def rand(count, qs):
+        return np.stack([np.stack([rng.integers(0, q, size=n, dtype=np.int64) for q in qs], axis=1) for _ in range(count)])
+
+    hint, a, b = rand(2 * D, qs_in[L - l_h:]), rand(2 * batch, qs_in), rand(2 * batch, qs_in)
+    s_pre = [int(rng.integers(1, q)) for q in qs_in]
+    gh = rh.hint_load(hint, gadget=capi.ALCH_GAD_BASE2)
+    for pow_out in (False, True):
+        out = rout.alloc(2 * batch)
+        capi.ct_mul_full(gh, rin.upload(a), rin.upload(b), out, batch, s_pre=s_pre, flags=capi.ALCH_POW_OUT if pow_out else 0)
+        got = out.download()
+        for ct in range(batch):
+            w0, w1 = oracle_full_mul_base2_down(oracle_lib, n, qs_in, l_h, l_out, list(hint), a[2 * ct], a[2 * ct + 1], b[2 * ct],
+                                                b[2 * ct + 1], s_pre, pow_out=pow_out)
+            assert np.array_equal(got[2 * ct], w0) and np.array_equal(got[2 * ct + 1], w1), (ct, pow_out)
+
+
+def test_full_mul_with_base2_hint_on_fewer_limbs_general_index(oracle_lib):
+    """The down-first mul_ on a general index (m = 2^2 * 3 * 5 * 7 = 420, phi = 96): mulG on the product, c0's rescales on the decoding basis."""
+    import alchemy_amd as A
+    from alchemy_amd import capi
+    from helpers import oracle_full_mul_base2_down, primes_1_mod
+    m, batch = 420, 2
+    qs_in = primes_1_mod(m, 3, lo=1 << 20)
+    rng = np.random.default_rng(9400)
+    rin, rh, rout = A.Ring(m, qs_in), A.Ring(m, qs_in[1:]), A.Ring(m, qs_in[2:])
+    n = rin.n
+    D = rh.gadget_digits(capi.ALCH_GAD_BASE2)
+
+    def rand(count, qs):
+        return np.stack([np.stack([rng.integers(0, q, size=n, dtype=np.int64) for q in qs], axis=1) for _ in range(count)])
+
+    hint, a, b = rand(2 * D, qs_in[1:]), rand(2 * batch, qs_in), rand(2 * batch, qs_in)
+    s_pre = [int(rng.integers(1, q)) for q in qs_in]
+    gh = rh.hint_load(hint, gadget=capi.ALCH_GAD_BASE2)
+    for l_out, ro in ((2, rh), (1, rout)):
+        for pow_out in (False, True):
+            out = ro.alloc(2 * batch)
+            capi.ct_mul_full(gh, rin.upload(a), rin.upload(b), out, batch, s_pre=s_pre, flags=capi.ALCH_POW_OUT if pow_out else 0)
+            got = out.download()
+            for ct in range(batch):
+                w0, w1 = oracle_full_mul_base2_down(oracle_lib, n, qs_in, 2, l_out, list(hint), a[2 * ct], a[2 * ct + 1], b[2 * ct],
+                                                    b[2 * ct + 1], s_pre, pow_out=pow_out, m=m)
+                assert np.array_equal(got[2 * ct], w0) and np.array_equal(got[2 * ct + 1], w1), (l_out, ct, pow_out)
