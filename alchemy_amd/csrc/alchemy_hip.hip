@@ -36,6 +36,7 @@ struct alch_ring {
     int logn = 0, L = 0, word = 0;            // word = 4 or 8 bytes per residue on the device
     u64 q[MAXL] = {0};
     bool balanced = false;
+    bool q30 = false;                          // 32-bit words and every modulus below 2^30 (4q fits a word)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -986,6 +987,7 @@ static int ring_create_impl(uint32_t m, int L, const uint64_t* q, bool nocrt, al
     u64 qmin = ~0ull, qmax = 0;
     for (int j = 0; j < L; ++j) { qmin = std::min(qmin, q[j]); qmax = std::max(qmax, q[j]); }
     r->balanced = qmax > 0 && (qmax - 1) / 2 < qmin;
+    r->q30 = r->word == 4 && qmax > 0 && qmax < ((u64)1 << 30);
     r->device = dev;
     hipError_t e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete r; return fail(ALCH_E_HIP, "hipStreamCreate failed"); }
@@ -1062,6 +1064,7 @@ extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) 
     if (k == "chunk") { if (value < 8) return fail(ALCH_E_INVALID, "chunk must be >= 8"); r->chunk = (size_t)value; }
     else if (k == "one_stream") r->one_stream = value != 0;
     else if (k == "pipe") r->pipe = value != 0;
+    else if (k == "q30") r->opts.q30 = value != 0;
     else if (k == "ks_grid") { if (value < 1) return fail(ALCH_E_INVALID, "ks_grid must be >= 1"); r->opts.ks_grid = (unsigned)value; }
     else if (k == "ti_grid") r->opts.ti_grid = (int)value;
     else if (k == "ti_split") { if (value < 0) return fail(ALCH_E_INVALID, "ti_split must be >= 0"); r->opts.ti_split = (int)value; }
@@ -1905,6 +1908,7 @@ static int do_mul_relin(alch_ring* r, const alch_hint* hint, const void* a, cons
     c.hint = reinterpret_cast<const W*>(hint->dptr);
     c.balanced = r->balanced;
     c.opts = r->opts;
+    c.q30 = r->q30 && r->opts.q30;
     scal_to_mont<W>(r, s_pre, 2, c.spre_r2);
     const size_t ct_words = 2 * elem_words(r);
     const bool two = batch > chunk && !r->one_stream;
@@ -2064,6 +2068,7 @@ static int do_mul_full(alch_ring* rh, alch_ring* rin, alch_ring* rout, const alc
     c.hint = reinterpret_cast<const W*>(hint->dptr);
     c.balanced = rh->balanced;
     c.opts = rh->opts;
+    c.q30 = rh->q30 && rh->opts.q30;
     scal_to_mont<W>(rin, s_eff, 2, c.spre_r2);
     fill_drop_tab<W>(rh, ddn, c.drop);
     c.stash_slots = slots;

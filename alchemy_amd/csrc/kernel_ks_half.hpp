@@ -13,6 +13,7 @@
 // the one-workgroup-per-CU form (k_ks_accum) idles the VALU during those phases.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "ntt_engine.hpp"
 
 // experiment switches (tools/build_variant.sh)
@@ -128,7 +129,10 @@ __device__ __forceinline__ void buf_st16(Rsrc r, u32 voff, u32 soff, u32 __attri
 // and q_added * x into the others (a scalar, folded into spre by the host), so an added limb j < dup starts
 // from c0 = c1 = 0, has a zero diagonal digit and transforms all L - dup digits; hint row of source digit i is
 // i + dup (the digits of the added limbs are zero and are skipped).
-template <int LOGN, bool BALANCED, int EPT = 32, bool UP = false>
+// Q30 (every modulus below 2^30, so 4q fits a word): Harvey's forward butterflies (8 instructions instead of 10, values lazy in [0,4q)
+// through pass G and the LDS passes -- the hint product takes any word), accumulators lazy in [0,2q) (one conditional subtraction per
+// product instead of two) and brought to [0,q) when they are stored.
+template <int LOGN, bool BALANCED, int EPT = 32, bool UP = false, bool Q30 = false>
 __global__ void __launch_bounds__((1 << (LOGN - 1)) / EPT, EPT == 32 ? 4 : 8)
 k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict__ b,
                 const int32_t* __restrict__ digits, const u32* __restrict__ hint, u32* __restrict__ out,
@@ -175,12 +179,16 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     u32 po0 = 0, po1 = 0;                          // byte offsets of the previous item's two result rows
     bool pending = false;
     int prot = 0;
+    W pq = 0;                                      // modulus of the previous item (Q30: its accumulators are reduced at the store)
     auto store_slice = [&](int r) {               // slice r of the previous item's results
         if (!pending) return;
         const u32 so = SLICE * (u32)((r + prot) & (EPT / 4 - 1));
         V v0, v1;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v0[e] = acc0[r * 4 + e]; v1[e] = acc1[r * 4 + e]; }
+        for (int e = 0; e < 4; ++e) {
+            v0[e] = Q30 ? csub(acc0[r * 4 + e], pq) : acc0[r * 4 + e];
+            v1[e] = Q30 ? csub(acc1[r * 4 + e], pq) : acc1[r * 4 + e];
+        }
         buf_st16(ro, lane16, po0 + so, v0);
         buf_st16(ro, lane16, po1 + so, v1);
     };
@@ -306,10 +314,11 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
                             xx = csub(mont_mul_lazy((W)((W)zx[e] + R.dig_off[j]), m.r1, q, qni), q);
                             yr = mont_mul_lazy((W)((W)zy[e] + R.dig_off[j]), m.r1, q, qni);
                         }
-                        const W t = tw_mul(yr, w1, q, qni);
 #if ALCH_USE_PLANTARD
+                        const W t = tw_mul(yr, w1, q, qni);
                         u[k][e] = hf ? xx + (q - t) : xx + t;
 #else
+                        const W t = Q30 ? mont_mul_lazy(yr, w1, q, qni) : tw_mul(yr, w1, q, qni);     // Q30: [0,2q), the sum below 3q
                         u[k][e] = xx + t;
 #endif
                     }
@@ -317,10 +326,17 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     W u0 = u[0][e], u1 = u[1][e], u2 = u[2][e], u3 = u[3][e];
+                    if constexpr (Q30) {
+                        bfly_fwd4(u0, u2, w2, q, qni);
+                        bfly_fwd4(u1, u3, w2, q, qni);
+                        bfly_fwd4(u0, u1, w3a, q, qni);
+                        bfly_fwd4(u2, u3, w3b, q, qni);
+                    } else {
                     bfly_fwd(u0, u2, w2, q, qni);
                     bfly_fwd(u1, u3, w2, q, qni);
                     bfly_fwd(u0, u1, w3a, q, qni);
                     bfly_fwd(u2, u3, w3b, q, qni);
+                    }
                     u[0][e] = u0; u[1][e] = u1; u[2][e] = u2; u[3][e] = u3;
                 }
 #pragma unroll
@@ -341,23 +357,25 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         const int prefix = 2 + hf;
         NoEpilogue none;
         constexpr int NP = (LOGM - 2) / 4;
+        typedef typename std::remove_cv<typename std::remove_pointer<decltype(twf)>::type>::type TWF;
+        typedef typename std::remove_cv<typename std::remove_pointer<decltype(twm)>::type>::type TWM;
         if constexpr (NP == 1) {
-            ntt_pass<LOGM, LT, W, 2, 4, false, false, true>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, none);
+            ntt_pass<LOGM, LT, W, 2, 4, false, false, true, TWM, NoEpilogue&, true, Q30>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, none);
         } else if constexpr (NP == 2) {
-            ntt_pass<LOGM, LT, W, 2, 4, false, false, ALCH_KS_SERIAL>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
+            ntt_pass<LOGM, LT, W, 2, 4, false, false, ALCH_KS_SERIAL, TWF, NoEpilogue&, true, Q30>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
             pair_sync<LOGM>();                    // LB = 4 -> LB = 0: the hand-off stays inside each wave
-            ntt_pass<LOGM, LT, W, 6, 4, false, false, true>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, none);
+            ntt_pass<LOGM, LT, W, 6, 4, false, false, true, TWM, NoEpilogue&, true, Q30>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, none);
         } else {
             static_assert(NP <= 3, "at most 3 LDS passes");
-            if (!KS_DBG(16u)) ntt_pass<LOGM, LT, W, 2, 4, false, false, ALCH_KS_SERIAL>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
+            if (!KS_DBG(16u)) ntt_pass<LOGM, LT, W, 2, 4, false, false, ALCH_KS_SERIAL, TWF, NoEpilogue&, true, Q30>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
             KS_STAMP(4);                          // LDS pass 1
             KS_SYNC();
             KS_STAMP(5);
-            if (!KS_DBG(32u)) ntt_pass<LOGM, LT, W, 6, 4, false, false, ALCH_KS_SERIAL>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
+            if (!KS_DBG(32u)) ntt_pass<LOGM, LT, W, 6, 4, false, false, ALCH_KS_SERIAL, TWF, NoEpilogue&, true, Q30>(lds, twf, q, qni, (W)0, (W)0, tid, prefix, none);
             KS_STAMP(6);                          // LDS pass 2
             pair_sync<LOGM>();                    // LB = 4 -> LB = 0: the hand-off stays inside each wave
             KS_STAMP(7);
-            if (!KS_DBG(64u)) ntt_pass<LOGM, LT, W, 10, 4, false, false, true>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, none);
+            if (!KS_DBG(64u)) ntt_pass<LOGM, LT, W, 10, 4, false, false, true, TWM, NoEpilogue&, true, Q30>(lds, twm, q, qni, (W)0, (W)0, tid, prefix, none);
         }
         // hint multiply-accumulate, in the lane-contiguous slot layout: the transform result goes through LDS
         // once more so that hint loads (and the tensor inputs / result stores, which share the layout) are
@@ -386,8 +404,13 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
             const V vh0 = ph0[r % HD], vh1 = ph1[r % HD];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                if constexpr (Q30) {                    // x in [0,4q), accumulators lazy in [0,2q)
+                    acc0[r * 4 + e] = csub(acc0[r * 4 + e] + mont_mul_lazy(x[e], vh0[e], q, qni), 2u * q);
+                    acc1[r * 4 + e] = csub(acc1[r * 4 + e] + mont_mul_lazy(x[e], vh1[e], q, qni), 2u * q);
+                } else {
                 acc0[r * 4 + e] = csub(acc0[r * 4 + e] + csub(mont_mul_lazy(x[e], vh0[e], q, qni), q), q);
                 acc1[r * 4 + e] = csub(acc1[r * 4 + e] + csub(mont_mul_lazy(x[e], vh1[e], q, qni), q), q);
+                }
             }
             if (r + HD < EPT / 4) hint_issue(r + HD, ph0[r % HD], ph1[r % HD]);
         }
@@ -401,6 +424,7 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         po1 = ((2 * cto + 1) * (u32)L + (u32)j) * ROW + slot0;
         pending = true;
         prot = rot;
+        pq = q;
     }
     KS_STAMP(10);                                 // result stores issued
     KS_STAMP_FLUSH();

@@ -18,7 +18,8 @@
 
 namespace alch {
 
-template <int LOGN>
+// Q30: every modulus below 2^30 -- 8-instruction inverse butterflies (bfly_inv4); values stay in [0,2q) as otherwise
+template <int LOGN, bool Q30 = false>
 __global__ void __launch_bounds__(1 << (LOGN - 6), 4)
 k_tensor_intt_split(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict__ b, int32_t* __restrict__ digits,
                     unsigned nitems, Scal<u32> spre) {
@@ -70,20 +71,20 @@ k_tensor_intt_split(DevRing<u32> R, const u32* __restrict__ a, const u32* __rest
 #if ALCH_TI_SPLIT_PASSES == 3
             // 14 stages as 5 + 5 + 4: three LDS round trips per half instead of four (radix-32 groups: 32 coefficients and
             // up to 31 per-lane twiddles in registers -- affordable here, there are no accumulators to keep)
-            ntt_pass<LOGM, LT, W, 9, 5, true, false, false, W, NoEpilogue&, false>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
+            ntt_pass<LOGM, LT, W, 9, 5, true, false, false, W, NoEpilogue&, false, Q30>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
             lds_barrier();
-            ntt_pass<LOGM, LT, W, 4, 5, true, false, false, W, NoEpilogue&, false>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
+            ntt_pass<LOGM, LT, W, 4, 5, true, false, false, W, NoEpilogue&, false, Q30>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
             lds_barrier();
-            ntt_pass<LOGM, LT, W, 0, 4, true, false, false, W, NoEpilogue&, false>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
+            ntt_pass<LOGM, LT, W, 0, 4, true, false, false, W, NoEpilogue&, false, Q30>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
             lds_barrier();
 #else
-            ntt_pass<LOGM, LT, W, 10, 4, true, false, false, W, NoEpilogue&, false>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
+            ntt_pass<LOGM, LT, W, 10, 4, true, false, false, W, NoEpilogue&, false, Q30>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
             pair_sync<LOGM>();
-            ntt_pass<LOGM, LT, W, 6, 4, true, false, false, W, NoEpilogue&, false>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
+            ntt_pass<LOGM, LT, W, 6, 4, true, false, false, W, NoEpilogue&, false, Q30>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
             lds_barrier();
-            ntt_pass<LOGM, LT, W, 2, 4, true, false, false, W, NoEpilogue&, false>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
+            ntt_pass<LOGM, LT, W, 2, 4, true, false, false, W, NoEpilogue&, false, Q30>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
             lds_barrier();
-            ntt_pass<LOGM, LT, W, 0, 2, true, false, false, W, NoEpilogue&, false>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
+            ntt_pass<LOGM, LT, W, 0, 2, true, false, false, W, NoEpilogue&, false, Q30>(lds, twi, q, qni, (W)0, (W)0, tid, prefix, none);
             lds_barrier();
 #endif
             if (half == 0) {

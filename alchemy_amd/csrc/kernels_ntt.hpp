@@ -98,6 +98,7 @@ struct LaunchOpts {
                              // recomputed from the stash per kept limb and costs what the second workgroup per CU gains
     int tunnel_ep = 1;       // alch_tunnel_create: 1 = transforms of the embedded E'-coefficients at dimension phi(e') (embedCRT replication), 0 = at phi(s')
     int rs_lin = 1;          // closing modSwitch: 1 = kept limbs stay in the CRT basis (k_rescale_out_lin), 0 = every limb through the Pow basis
+    int q30 = 1;             // 32-bit two-power rings whose moduli are all below 2^30: 1 = Harvey butterflies in the fused n = 2^15 / 2^11 kernels
     unsigned ks_grid = 4096; // persistent workgroups of k_ks_accum_half (measured, 1024-ciphertext chunks: 2048 -> 511k, 4096 -> 517k, 8192 -> 513k op/s)
 };
 
@@ -120,6 +121,7 @@ struct NttCall {
     size_t nct;            // ciphertexts in this launch (a, b, out, digits already offset to the first)
     Scal<W> spre_r2;       // s_j * R^2 mod q_j
     bool balanced;         // every |digit| < every q_j  ->  reduce is one add
+    bool q30;              // 32-bit ring, every modulus below 2^30: the Harvey-butterfly instantiations of the fused n = 2^15 kernels
     // full mul_ (modSwitch . keySwitchQuad . modSwitch): see kernel_rescale_out.hpp
     int dup;               // OP_KS_ACCUM: limbs the hint's ring has in front of the operands' ring
     DropTab<W> drop;       // OP_RESCALE_OUT: limbs to drop and the q_u^-1 tables
@@ -552,7 +554,7 @@ inline hipError_t run_call(const NttCall<W>& c) {
             // a value > 1 = that many persistent workgroups)
             const int split = c.opts.ti_split;
             if (split) {
-                auto k = k_tensor_intt_split<LOGN>;
+                auto k = c.q30 ? k_tensor_intt_split<LOGN, true> : k_tensor_intt_split<LOGN, false>;
                 const size_t half_lds = (size_t)lds_words<LOGN - 1>() * sizeof(W);
                 if ((e = set_lds(k, half_lds)) != hipSuccess) return e;
                 const unsigned nitems = (unsigned)(c.nct * (size_t)R.L);
@@ -602,7 +604,12 @@ inline hipError_t run_call(const NttCall<W>& c) {
             const unsigned grid = nitems < persist ? nitems : persist;
             constexpr int TH = 1 << (LOGN - 6);
             const size_t half_lds = (size_t)lds_words<LOGN - 1>() * sizeof(W);
-            if (c.dup > 0) {
+            if (c.q30 && c.balanced) {                       // every modulus below 2^30: Harvey butterflies, lazy accumulators
+                auto k = c.dup > 0 ? k_ks_accum_half<LOGN, true, 32, true, true> : k_ks_accum_half<LOGN, true, 32, false, true>;
+                if ((e = set_lds(k, half_lds)) != hipSuccess) return e;
+                hipLaunchKernelGGL(k, dim3(grid), dim3(TH), half_lds, c.stream, R, c.a, c.b, (const int32_t*)c.digits,
+                                   c.hint, c.out, (unsigned)c.nct, nitems, c.spre_r2, dbg_mask, c.dup);
+            } else if (c.dup > 0) {
                 if (c.balanced) {
                     auto k = k_ks_accum_half<LOGN, true, 32, true>;
                     if ((e = set_lds(k, half_lds)) != hipSuccess) return e;

@@ -145,8 +145,10 @@ struct NoEpilogue {
 // forward transform of 32-bit rings uses (bfly_fwd overloads pick the arithmetic from it).
 // FOLD: an inverse pass that contains stage 0 folds n^-1 into it; a sub-transform (prefix != 1) whose local
 // stage 0 is not the transform's stage 0 passes FOLD = false.
+// Q30 (32-bit rings whose moduli are all below 2^30, Montgomery twiddles): Harvey's butterflies -- forward values stay lazy in [0,4q)
+// from pass to pass (callers' epilogues multiply them, which takes any word, or reduce them), inverse values in [0,2q) as otherwise.
 template <int LOGN, int LOGT, typename W, int S0, int NS, bool INVERSE, bool KEEP, bool SERIAL, typename TW, typename Epi,
-          bool FOLD = true>
+          bool FOLD = true, bool Q30 = false>
 __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const TW* __restrict__ tw, W q, W qni,
                                          W ninv_m, W w1ninv_m, int t, int prefix, Epi&& epi) {
     typedef Geo<LOGN, LOGT> G;
@@ -201,7 +203,8 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const TW* __restri
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     if (k & half) continue;
-                    bfly_fwd_st(x[k], x[k + half], w[k >> (NS - r)], q, qni, r == 0, r == NS - 1);
+                    if constexpr (Q30) bfly_fwd4(x[k], x[k + half], w[k >> (NS - r)], q, qni);
+                    else bfly_fwd_st(x[k], x[k + half], w[k >> (NS - r)], q, qni, r == 0, r == NS - 1);
                 }
             }
         } else {
@@ -228,6 +231,8 @@ __device__ __forceinline__ void ntt_pass(W* __restrict__ lds, const TW* __restri
                         W a = csub(x[k], q), b = csub(x[k + half], q);
                         x[k] = mont_mul_lazy((W)(a + b), ninv_m, q, qni);
                         x[k + half] = mont_mul_lazy((W)(a - b + q), w1ninv_m, q, qni);
+                    } else if constexpr (Q30) {
+                        bfly_inv4(x[k], x[k + half], w[k >> (NS - r)], q, qni);
                     } else {
                         bfly_inv(x[k], x[k + half], w[k >> (NS - r)], q, qni);
                     }

@@ -161,6 +161,40 @@ def general_index_line():
             "out_checksum": f"{out.checksum(0, 2):016x}"}
 
 
+def q30_line(B):
+    """Extra line: the headline op (same shape, same seeds) on four moduli below 2^30 -- the size of the reference's Tunnel.hs moduli
+    ("good moduli, ~ 30 bits", examples/Tunnel.hs:34-39) and of HomomRLWR's rounding moduli (examples/HomomRLWR.hs:38-40).  4q fits a
+    32-bit word there, so the two fused kernels run Harvey's butterflies (8 VALU instructions instead of 10, values lazy in [0,4q),
+    accumulators in [0,2q)); `general_kernels_ops_per_s` is the same ring through the kernels the headline uses (option q30 = 0)."""
+    from alchemy_amd import Ring
+    qs = [1073479681, 1071513601, 1070727169, 1068236801]
+    n = 1 << LOGN
+    rates, check = {}, None
+    for q30 in (1, 0):
+        ring = Ring(2 * n, qs)
+        apply_opts(ring)
+        ring.set_option("q30", q30)
+        a, b, out, hs = ring.alloc(2 * B), ring.alloc(2 * B), ring.alloc(2 * B), ring.alloc(2 * ring.L)
+        a.fill_uniform(2026); b.fill_uniform(900_000_007); hs.fill_uniform(0xA1C4E5)
+        hint = ring.hint_from_buf(hs)
+        ring.ct_mul_relin(hint, a, b, out, B)
+        ring.sync()
+        ring.timer_start()
+        for _ in range(5):
+            ring.ct_mul_relin(hint, a, b, out, B)
+        rates[q30] = 5 * B / (ring.timer_stop() * 1e-3)
+        ref = golden_checksums().get("q30", {}).get("bench_mul_relin")
+        if ref is not None and ref["batch"] == B:
+            rec = assert_checksum(f"moduli below 2^30 (q30 = {q30})", out.checksum(), ref["checksum"], {"batch": B})
+            check = rec if q30 else check
+        del a, b, out, hs, hint, ring
+    algo = 6 * len(qs) * n * 8
+    return {"workload": "BASELINE config 3's op and shape (n=2^15, 4 limbs, TrivGad, CRT in/out) on moduli below 2^30: Harvey butterflies",
+            "moduli": qs, "batch": B, "ops_per_s": rates[1], "general_kernels_ops_per_s": rates[0], "batch_checksum": check,
+            "algorithmic_bytes_per_op": algo, "frac_of_hbm_peak": rates[1] * algo / 1e9 / HBM_PEAK_GBS,
+            "frac_at_device_word": rates[1] * algo / 2 / 1e9 / HBM_PEAK_GBS}
+
+
 def tunnel_hs_line():
     """Extra line: BASELINE config 5 at the reference's real parameters -- the five hops of examples/Tunnel.hs (BaseBGad 2 hints,
     its moduli, H0' .. H5'), each as modSwitch . tunnel hint . modSwitch on 256 resident ciphertexts (alchemy_amd/tunnelhops.py);
@@ -248,6 +282,8 @@ def main():
     ap.add_argument("--pipeline-batch", type=int, default=1024, help="ciphertexts per GPU in the HomomRLWR pipeline")
     ap.add_argument("--no-tunnel-hs", dest="tunnel_hs", action="store_false",
                     help="skip the examples/Tunnel.hs hops (BASELINE config 5: BaseBGad 2 hints, extra field `tunnel_hs`)")
+    ap.add_argument("--no-q30", dest="q30", action="store_false",
+                    help="skip the extra line: the headline op on moduli below 2^30 (Harvey-butterfly kernels)")
     ap.add_argument("--no-config2", dest="config2", action="store_false",
                     help="skip BASELINE config 2 (n = 2^14, one limb: transform and pointwise rates, extra field `config2`)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
@@ -418,10 +454,12 @@ def main():
     if args.general and rank == 0:
         general = general_index_line()
 
-    tunnel_hs = config2 = None
-    if rank == 0 and (args.tunnel_hs or args.config2):
+    tunnel_hs = config2 = q30 = None
+    if rank == 0 and (args.tunnel_hs or args.config2 or args.q30):
         del a, b, out
         a = b = out = None
+        if args.q30:
+            q30 = q30_line(B)
         if args.tunnel_hs:
             tunnel_hs = tunnel_hs_line()
         if args.config2:
@@ -540,6 +578,8 @@ def main():
             line["tunnel_hs"] = tunnel_hs
         if config2 is not None:
             line["config2"] = config2
+        if q30 is not None:
+            line["moduli_below_2_30"] = q30
         line["result_gather"] = gather
         if world == 1 and args.cpu_ops > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_ops)

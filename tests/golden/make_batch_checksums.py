@@ -12,10 +12,12 @@
      restatement; about an hour of CPU time split over the cores);
    * tunnel_hs: the five BaseBGad-2 hops of alchemy_amd/tunnelhops.py (examples/Tunnel.hs), one checksum per ciphertext of the
      B = 256 batches bench.py times.
+   * q30: the headline op on four moduli below 2^30 (Harvey-butterfly kernels), B = 8192 for bench.py's extra line and the ragged
+     test batch;
    Per-ciphertext lists let any prefix (a ragged test batch) be checked: sums are position-dependent, so they add.
 A result error confined to any chunk, stream or persistent-workgroup slot changes the sum.
 
-    python tests/golden/make_batch_checksums.py [two_power] [general] [homomrlwr] [tunnel_hs]     (default: all; sections not
+    python tests/golden/make_batch_checksums.py [two_power] [q30] [general] [homomrlwr] [tunnel_hs]     (default: all; sections not
     regenerated are kept from the existing file)"""
 import json
 import os
@@ -68,8 +70,11 @@ def run_ranges(fn, total):
     return sum(out) & MASK
 
 
-def relin_range(first, count):
-    return cref.Ring(N, CFG3_QS).mul_relin_checksum(SEED_A, SEED_B, SEED_H, first, count)
+def relin_range(first, count, qs=CFG3_QS):
+    return cref.Ring(N, qs).mul_relin_checksum(SEED_A, SEED_B, SEED_H, first, count)
+
+
+Q30_QS = [1073479681, 1071513601, 1070727169, 1068236801]          # the four largest primes < 2^30 that are 1 mod 2^17
 
 
 def full_range(first, count):
@@ -165,7 +170,14 @@ if __name__ == "__main__":
     cref.build()
     path = os.path.join(HERE, "batch_checksums.json")
     out = json.load(open(path)) if os.path.exists(path) else {}
-    want = set(sys.argv[1:]) or {"two_power", "general", "homomrlwr", "tunnel_hs", "config2"}
+    want = set(sys.argv[1:]) or {"two_power", "q30", "general", "homomrlwr", "tunnel_hs", "config2"}
+    if "q30" in want:
+        B_TEST, B_BENCH = 2 * 1024 + 37, 8192
+        head = run_ranges(lambda f, c: relin_range(f, c, Q30_QS), B_TEST)
+        tail = run_ranges(lambda f, c: relin_range(B_TEST + f, c, Q30_QS), B_BENCH - B_TEST)
+        out["q30"] = {"what": "the headline op (same seeds, n = 2^15, 4 limbs) on moduli below 2^30: the Harvey-butterfly kernels",
+                      "moduli": Q30_QS, "test_mul_relin": {"batch": B_TEST, "checksum": f"{head:016x}"},
+                      "bench_mul_relin": {"batch": B_BENCH, "checksum": f"{(head + tail) & MASK:016x}"}}
     if "two_power" in want:
         B_TEST, B_BENCH = 2 * 1024 + 37, 8192
         head = run_ranges(relin_range, B_TEST)

@@ -38,6 +38,26 @@ def test_mul_relin_bench_shape(oracle_lib):
         assert np.array_equal(got[0], w0) and np.array_equal(got[1], w1), ct
 
 
+def test_mul_relin_bench_shape_moduli_below_2_30(oracle_lib):
+    """The same batch on four moduli below 2^30 (bench.py's `moduli_below_2_30` line): the Harvey-butterfly instantiations of both
+    fused kernels at the default launch options, whole-batch checksum against the C restatement's, spot ciphertexts word for word."""
+    ref = load_golden("batch_checksums.json")
+    B, seeds, qs = ref["q30"]["test_mul_relin"]["batch"], ref["seeds"], ref["q30"]["moduli"]
+    assert max(qs) < 1 << 30 and B == 2 * 1024 + 37
+    g, o = A.Ring(2 * N, qs), oracle_lib.Ring(N, qs)
+    a, b, out, hs = g.alloc(2 * B), g.alloc(2 * B), g.alloc(2 * B), g.alloc(2 * g.L)
+    a.fill_uniform(seeds["a"]); b.fill_uniform(seeds["b"]); hs.fill_uniform(seeds["hint"])
+    hint = g.hint_from_buf(hs)
+    g.ct_mul_relin(hint, a, b, out, B)
+    assert f"{out.checksum():016x}" == ref["q30"]["test_mul_relin"]["checksum"]
+    hint_host = [o.fill_uniform(seeds["hint"], i) for i in range(2 * g.L)]
+    for ct in SPOTS[::3]:
+        got = out.download(2 * ct, 2)
+        w0, w1 = o.ct_mul_relin(hint_host, o.fill_uniform(seeds["a"], 2 * ct), o.fill_uniform(seeds["a"], 2 * ct + 1),
+                                o.fill_uniform(seeds["b"], 2 * ct), o.fill_uniform(seeds["b"], 2 * ct + 1))
+        assert np.array_equal(got[0], w0) and np.array_equal(got[1], w1), ct
+
+
 def test_mul_full_bench_shape(oracle_lib):
     ref = load_golden("batch_checksums.json")
     B, seeds = ref["test_mul_full"]["batch"], ref["seeds"]

@@ -4,7 +4,7 @@ restatement's composition of the same steps (helpers.oracle_full_mul).  Bit-exac
 import numpy as np
 import pytest
 
-from conftest import CFG3_QS
+from conftest import CFG3_QS, Q30_QS
 from helpers import from_aos, hint_to_crt_aos, load_golden, oracle_full_mul, to_aos
 
 pytestmark = pytest.mark.gpu
@@ -71,6 +71,8 @@ def _case(oracle_lib, logn, qs_h, l_in, l_out, batch, seed, s_pre=None, pow_out=
     (15, [2147352577, 65537, 786433, 2146959361], 3, 2, 2),   # n = 2^15, two dropped, unbalanced: same kernels, general reduce
     # n = 2^16 (split transforms): the same entry point composes the op from element-wise kernels and batched transforms
     (16, SIX_QS, 5, 4, 2), (16, SIX_QS[:4], 2, 1, 3),
+    # every modulus below 2^30: Harvey-butterfly instantiations of the tensor and key-switch kernels (here with added limbs)
+    (11, Q30_QS[:5], 4, 3, 9), (15, Q30_QS[:5], 4, 3, 3), (15, Q30_QS, 4, 3, 2), (15, Q30_QS[:3], 2, 2, 2),
 ])
 def test_full_mul_matches_oracle(oracle_lib, logn, qs_h, l_in, l_out, batch):
     _case(oracle_lib, logn, qs_h, l_in, l_out, batch, seed=5000 + logn)

@@ -3,7 +3,7 @@ seeded inputs.  Bit-exact (integer arithmetic)."""
 import numpy as np
 import pytest
 
-from conftest import ARITH_QS, CFG2_Q60, CFG3_QS
+from conftest import ARITH_QS, CFG2_Q60, CFG3_QS, Q30_QS
 
 pytestmark = pytest.mark.gpu
 
@@ -106,15 +106,36 @@ def _mul_relin_case(oracle_lib, n, qs, batch, seed, s_pre=None, pow_basis=False)
     # n = 2^16: split transforms + unfused key switch (configs 4 / 5 stand-in: six primes = 1 mod 2^17)
     (16, SIX_QS_17, 2), (16, SIX_QS_17[:2], 3),
     (15, [1152921504606584833, 1152921504598720513], 2),      # 60-bit residues, n = 2^15: the same on 8-byte words
+    # every modulus below 2^30: the Harvey-butterfly instantiations of the two fused kernels (values lazy in [0,4q), accumulators in [0,2q))
+    (11, Q30_QS[:4], 9), (15, Q30_QS[:4], 2), (15, Q30_QS[:4], 11), (15, Q30_QS[:1], 3), (11, Q30_QS, 3), (15, Q30_QS[1:3], 5),
+    (11, [786433, 1073479681], 3),                            # below 2^30 but unbalanced: the general kernels
 ])
 def test_ct_mul_relin_crt_basis(oracle_lib, logn, qs, batch):
     _mul_relin_case(oracle_lib, 1 << logn, qs, batch, seed=1000 + logn)
 
 
 @pytest.mark.parametrize("logn,qs,batch", [(4, ARITH_QS, 2), (8, ARITH_QS, 3), (12, CFG3_QS, 1), (15, CFG3_QS, 1),
-                                           (16, SIX_QS_17[:3], 1)])
+                                           (16, SIX_QS_17[:3], 1), (15, Q30_QS[:3], 2)])
 def test_ct_mul_relin_pow_basis(oracle_lib, logn, qs, batch):
     _mul_relin_case(oracle_lib, 1 << logn, qs, batch, seed=2000 + logn, pow_basis=True)
+
+
+def test_harvey_kernels_agree_with_the_general_ones():
+    """Option q30 = 0 sends a ring with moduli below 2^30 through the general (lazy [0,2q)) kernels: same words, whole batch."""
+    import alchemy_amd as A
+    n, qs, batch = 1 << 15, Q30_QS[:4], 40
+    outs = []
+    for q30 in (1, 0):
+        g = A.Ring(2 * n, qs)
+        g.set_option("q30", q30)
+        g.set_option("chunk", 16)
+        rng = np.random.default_rng(4242)
+        hint, a, b = _rand_elems(rng, 8, n, qs), _rand_elems(rng, 2 * batch, n, qs), _rand_elems(rng, 2 * batch, n, qs)
+        out = g.alloc(2 * batch)
+        g.ct_mul_relin(g.hint_load(hint), g.upload(a), g.upload(b), out, batch, s_pre=[3, 5, 7, 11])
+        outs.append(out.download())
+    assert np.array_equal(outs[0], outs[1])
+    assert int(outs[0].max()) < max(qs) and int(outs[0].min()) >= 0
 
 
 def test_ct_mul_relin_with_encoding_scalar(oracle_lib):
