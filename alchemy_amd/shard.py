@@ -39,8 +39,10 @@ def env_rank():
 def init_distributed(backend: str | None = None):
     """Initialise torch.distributed when WORLD_SIZE > 1.  Returns (rank, local_rank, world, dist or None)."""
     rank, local_rank, world = env_rank()
-    if world == 1:
+    if world == 1 and not os.environ.get("ALCH_DIST_FORCE"):
         return rank, local_rank, world, None
+    # ALCH_DIST_FORCE=1 (tests): a one-rank process group, so that every collective of the N > 1 path runs through the real
+    # backend (nccl = RCCL) on a one-GPU box
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")

@@ -50,3 +50,22 @@ def test_failed_broadcast_is_fatal():
     out = _run({"ALCH_TEST_FAIL_BROADCAST": "1"})
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")], "no result line may be printed"
+
+
+def test_one_rank_process_group_runs_every_collective_through_rccl():
+    """The N > 1 code path with the REAL backend (nccl = RCCL) as far as a one-GPU box allows: a one-rank process group
+    (ALCH_DIST_FORCE=1), so the hint broadcast (int64 on the device), the MAX / SUM all-reduces, the barrier and the
+    all_gather_into_tensor on a zero-copy view of the library's result buffer all go through RCCL's API."""
+    env = dict(os.environ, ALCH_DIST_FORCE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1")
+    env.pop("ALCH_DIST_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "64", "--cpu-ops", "0",
+           "--no-full", "--no-pow", "--no-general", "--no-tunnel-hs", "--no-config2", "--no-q30", "--pipeline-batch", "16"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["hint"].startswith("rccl broadcast"), d["config"]
+    assert d["result_gather"]["backend"] == "rccl" and d["result_gather"]["own_slice_intact"] is True
+    assert d["homomrlwr"]["pipelines_per_s"] > 0
