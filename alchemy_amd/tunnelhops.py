@@ -69,11 +69,12 @@ class Hop:
             return self.out
         return self.mid
 
-    def measure(self):
+    def measure(self, reps=1):
         self.run(); self.rs.sync()
         self.rs.timer_start()
-        res = self.run()
-        return self.B / (self.rs.timer_stop() * 1e-3), res
+        for _ in range(reps):
+            res = self.run()
+        return reps * self.B / (self.rs.timer_stop() * 1e-3), res
 
     def algorithmic_bytes(self):
         """Compulsory bytes of one hop at the reference's 8-byte word: one linear ciphertext in (L_in limbs over H_k'), one out

@@ -201,7 +201,7 @@ if __name__ == "__main__":
                                     "one-limb result buffer over H5'), per ciphertext", "batch": B_P,
                             "per_ciphertext": [f"{v:016x}" for v in sums], "checksum": prefix(sums, B_P)}
     if "tunnel_hs" in want:
-        B_T = 256
+        B_T = int(os.environ.get("ALCH_TUNNEL_BATCH", "2048"))
         hops = []
         for k in range(5):
             sums = pool_map(hop_ct, [(k, ct) for ct in range(B_T)])

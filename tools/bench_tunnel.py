@@ -10,7 +10,7 @@ from alchemy_amd import capi
 
 QS = [537264001, 539884801, 555609601, 560851201, 566092801]          # examples/Tunnel.hs:34-39, Zqs order
 HP = [11648, 29120, 43680, 54600, 27300, 20475]
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 
 _rings = {}
 def ring(m, L):
