@@ -1078,7 +1078,7 @@ extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) 
         if (value != 0 && value != 128 && value != 256 && value != 512) return fail(ALCH_E_INVALID, "gen_nt must be 0 (by ring size), 128, 256 or 512");
         r->g32.nt = (int)value; r->g64.nt = (int)value;
     }
-    else if (k == "split_fused") r->opts.split_fused = value != 0;
+    else if (k == "split_fused") { if (value < 0 || value > 2) return fail(ALCH_E_INVALID, "split_fused: 0, 1 or 2"); r->opts.split_fused = (int)value; }
     else if (k == "scratch_mib") { if (value < 1 || value > 65536) return fail(ALCH_E_INVALID, "scratch_mib must be 1 .. 65536"); r->scratch_mib = (size_t)value; }
     else if (k == "rs_slots") { if (value < 1) return fail(ALCH_E_INVALID, "rs_slots must be >= 1"); r->rs_slots = (unsigned)value; }
     else return fail(ALCH_E_INVALID, "unknown option '" + k + "'");
@@ -2002,7 +2002,10 @@ extern "C" int alch_ct_mul_relin(alch_ring* r, const alch_hint* hint, const alch
         pa = wa;
         pb = wb;
     }
-    if (hint->gadget == ALCH_GAD_BASE2 || split_ring(r) || r->gen)
+    // split rings (a limb-polynomial is twice an LDS-resident transform), TrivGad: the same two-launch structure as the LDS-resident sizes
+    // since round 3 (k_tensor_crtinv_split + k_ks_accum_split<FROM_OPS>); option split_fused < 2 keeps the composed forms
+    const bool split_two = split_ring(r) && !r->gen && hint->gadget == ALCH_GAD_TRIV && r->opts.split_fused >= 2;
+    if (!split_two && (hint->gadget == ALCH_GAD_BASE2 || split_ring(r) || r->gen))
         rc = r->word == 4 ? do_mul_relin_unfused<u32>(r, hint, pa, pb, out->dptr, batch, s_pre)
                           : do_mul_relin_unfused<u64>(r, hint, pa, pb, out->dptr, batch, s_pre);
     else

@@ -110,6 +110,77 @@ __global__ void __launch_bounds__(Geo<LOGN - 1>::T) k_crt_split(DevRing<W> R, W*
     }
 }
 
+// Kernel A for split rings (round 3): c2 = a1 b1 s for limb i of one ciphertext with the product formed in the inverse transform's
+// loader, crtInv as k_crt_split's inverse (two half-size sub-transforms, stage 0 + n^-1 s last), canonical Pow-basis residues to
+// c2pow[ct][L][n] -- the element-wise tensor kernel, the CRT-basis copy of c2 and the separate crtInv launch of the composed path are
+// gone (6 MiB written and 4.5 MiB re-read per op at n = 2^16, L = 6).  spre = s R^2 per limb; the scalar rides on the n^-1 constants.
+template <int LOGN, typename W>
+__global__ void __launch_bounds__(Geo<LOGN - 1>::T) k_tensor_crtinv_split(DevRing<W> R, const W* __restrict__ a, const W* __restrict__ b,
+                                                                          W* __restrict__ c2pow, Scal<W> spre) {
+    constexpr int LOGM = LOGN - 1;
+    typedef Geo<LOGM> G;
+    typedef typename Vec4<W>::type V;
+    constexpr int VL = Vec4<W>::LANES;
+    constexpr int M = G::N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    W* lds = reinterpret_cast<W*>(smem);
+    const int L = R.L;
+    const size_t p = blockIdx.x, ct = p / (size_t)L;
+    const int j = (int)(p % (size_t)L);
+    const size_t n = (size_t)(2 * M);
+    const W* a1 = a + ((2 * ct + 1) * (size_t)L + j) * n;
+    const W* b1 = b + ((2 * ct + 1) * (size_t)L + j) * n;
+    W* lo = c2pow + p * n;
+    W* hi = lo + M;
+    const ModP<W> m = R.mod[j];
+    const W q = m.q, qni = m.qni;
+    const int tid = threadIdx.x;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const W* sa = a1 + (size_t)half * M;
+        const W* sb = b1 + (size_t)half * M;
+        stage_in<LOGM, W>(lds, [&](int idx) {
+            const V va = *reinterpret_cast<const V*>(sa + idx), vb = *reinterpret_cast<const V*>(sb + idx);
+            V v;
+#pragma unroll
+            for (int e = 0; e < VL; ++e) v[e] = mont_mul_lazy(va[e], vb[e], q, qni);        // a1 b1 R^-1, lazy
+            return v;
+        });
+        lds_barrier();
+        int t2 = tid;
+        asm volatile("" : "+v"(t2));
+        ntt_inverse<LOGM, W, false, false, false>(lds, inv_tw(R, j), q, qni, (W)0, (W)0, t2, NoEpilogue(), NoHook(), 2 + half);
+        if (half == 0) {
+#pragma unroll
+            for (int r = 0; r < G::E / VL; ++r) {
+                const int idx = (t2 + G::T * r) * VL;
+                V v = *reinterpret_cast<const V*>(&lds[swz<LOGM>(idx)]);
+#pragma unroll
+                for (int e = 0; e < VL; ++e) v[e] = csub(v[e], q);
+                *reinterpret_cast<V*>(lo + idx) = v;
+            }
+            lds_barrier();
+        }
+    }
+    // stage 0 with n^-1 s R^2 folded in (the product above carries R^-1, the Montgomery product another)
+    const W ninv = mont_mul(R.ninv_m[j], spre.v[j], m), w1ninv = mont_mul(R.w1ninv_m[j], spre.v[j], m);
+#pragma unroll
+    for (int r = 0; r < G::E / VL; ++r) {
+        const int idx = (tid + G::T * r) * VL;
+        const V x = *reinterpret_cast<const V*>(lo + idx);
+        const V yy = *reinterpret_cast<const V*>(&lds[swz<LOGM>(idx)]);
+        V c0, c1;
+#pragma unroll
+        for (int e = 0; e < VL; ++e) {
+            const W y = csub(yy[e], q);
+            c0[e] = csub(mont_mul_lazy((W)(x[e] + y), ninv, q, qni), q);
+            c1[e] = csub(mont_mul_lazy((W)(x[e] - y + q), w1ninv, q, qni), q);
+        }
+        *reinterpret_cast<V*>(lo + idx) = c0;
+        *reinterpret_cast<V*>(hi + idx) = c1;
+    }
+}
+
 // crt of the reduced TrivGad digits for the unfused key switch on split rings, decompose fused into the loader:
 // workgroup p = (ciphertext, digit i, target limb j) reads limb i of c2 (Pow basis, [0, q_i)), takes the centred
 // lift, reduces it mod q_j on the fly (Lol: decompose, then reduce) and runs the forward transform of limb j into
@@ -188,10 +259,12 @@ __global__ void __launch_bounds__(Geo<LOGN - 1>::T) k_crt_split_digits(DevRing<W
 // in LDS; the closing pass's epilogue multiplies by the hint rows.  out holds c0, c1 on entry (element-wise tensor product) and
 // the diagonal digit comes from c2's CRT-basis copy, as in the composed path this replaces (k_crt_split_digits + k_hint_mac:
 // L (L-1) limb-polynomials of 256 KiB written and read back per ciphertext).  dup: leading limbs added by modSwitch (their c2 is 0).
-template <int LOGN, typename W, bool BALANCED>
+// FROM_OPS (round 3, with k_tensor_crtinv_split in front): c0 = a0 b0 s, c1 = (a0 b1 + a1 b0) s and the diagonal digit c2_j = a1 b1 s are
+// formed here from the operands (opa, opb: [ct][2][L][n], CRT basis; spre = s R^2 per limb) instead of being read back from out / c2crt.
+template <int LOGN, typename W, bool BALANCED, bool FROM_OPS = false>
 __global__ void __launch_bounds__(Geo<LOGN - 1>::T)
 k_ks_accum_split(DevRing<W> R, const W* __restrict__ c2pow, const W* __restrict__ c2crt, const W* __restrict__ hint, W* __restrict__ out,
-                 unsigned nct, int dup) {
+                 unsigned nct, int dup, const W* __restrict__ opa, const W* __restrict__ opb, Scal<W> spre) {
     constexpr int LOGM = LOGN - 1;
     typedef Geo<LOGM> G;
     typedef typename Vec4<W>::type V;
@@ -213,7 +286,33 @@ k_ks_accum_split(DevRing<W> R, const W* __restrict__ c2pow, const W* __restrict_
     W* o0 = out + ((2 * ct) * (size_t)L + j) * n + hoff;
     W* o1 = out + ((2 * ct + 1) * (size_t)L + j) * n + hoff;
     W acc0[G::E], acc1[G::E];
-    {   // c0, c1 (already in out) + the diagonal digit c2_j * hint_j
+    if constexpr (FROM_OPS) {   // the tensor product itself, from the operands
+        const W* a0 = opa + ((2 * ct) * (size_t)L + j) * n + hoff;
+        const W* a1 = opa + ((2 * ct + 1) * (size_t)L + j) * n + hoff;
+        const W* b0 = opb + ((2 * ct) * (size_t)L + j) * n + hoff;
+        const W* b1 = opb + ((2 * ct + 1) * (size_t)L + j) * n + hoff;
+        const W* h0 = hj + (size_t)(2 * j) * Ln;
+        const W* h1 = hj + (size_t)(2 * j + 1) * Ln;
+        const W s2 = spre.v[j];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int k = 0; k < 16; k += VL) {
+                const int idx = (threadIdx.x + G::T * g) * 16 + k;
+                const V va0 = *reinterpret_cast<const V*>(a0 + idx), va1 = *reinterpret_cast<const V*>(a1 + idx);
+                const V vb0 = *reinterpret_cast<const V*>(b0 + idx), vb1 = *reinterpret_cast<const V*>(b1 + idx);
+                const V vh0 = *reinterpret_cast<const V*>(h0 + idx), vh1 = *reinterpret_cast<const V*>(h1 + idx);
+#pragma unroll
+                for (int e = 0; e < VL; ++e) {
+                    const W x0 = mont_mul(va0[e], s2, m), x1 = mont_mul(va1[e], s2, m);          // a s R
+                    const W c2 = mont_mul(vb1[e], x1, m);
+                    acc0[g * 16 + k + e] = add_mod(mont_mul(vb0[e], x0, m), mont_mul(c2, vh0[e], m), q);
+                    acc1[g * 16 + k + e] = add_mod(add_mod(mont_mul(vb1[e], x0, m), mont_mul(vb0[e], x1, m), q), mont_mul(c2, vh1[e], m), q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {   // c0, c1 (already in out) + the diagonal digit c2_j * hint_j
         const W* d = c2crt + (ct * (size_t)L + j) * n + hoff;
         const W* h0 = hj + (size_t)(2 * j) * Ln;
         const W* h1 = hj + (size_t)(2 * j + 1) * Ln;
@@ -310,14 +409,36 @@ inline hipError_t run_call_split(const NttCall<W>& c) {
         if (c.balanced) {
             auto k = k_ks_accum_split<LOGN, W, true>;
             if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
-            hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), lds_bytes, c.stream, *c.ring, c.src, c.a, c.hint, c.out, (unsigned)c.nct, c.dup);
+            hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), lds_bytes, c.stream, *c.ring, c.src, c.a, c.hint, c.out, (unsigned)c.nct, c.dup,
+                               (const W*)nullptr, (const W*)nullptr, Scal<W>{});
         } else {
             auto k = k_ks_accum_split<LOGN, W, false>;
             if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
-            hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), lds_bytes, c.stream, *c.ring, c.src, c.a, c.hint, c.out, (unsigned)c.nct, c.dup);
+            hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), lds_bytes, c.stream, *c.ring, c.src, c.a, c.hint, c.out, (unsigned)c.nct, c.dup,
+                               (const W*)nullptr, (const W*)nullptr, Scal<W>{});
+        }
+    } else if (c.op == OP_TENSOR_INTT) {   // split rings: tensor product in the inverse transform's loader (digits = canonical Pow residues)
+        auto k = k_tensor_crtinv_split<LOGN, W>;
+        if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3((unsigned)(c.nct * (size_t)c.ring->L)), dim3(G::T), lds_bytes, c.stream, *c.ring, c.a, c.b, (W*)c.digits,
+                           c.spre_r2);
+    } else if (c.op == OP_KS_ACCUM) {      // ... and the key switch with the tensor part from the operands
+        if (c.dup != 0) return hipErrorInvalidValue;
+        const size_t groups = (c.nct + 7) / 8;
+        const unsigned grid = (unsigned)(groups * 16 * (size_t)c.ring->L);
+        if (c.balanced) {
+            auto k = k_ks_accum_split<LOGN, W, true, true>;
+            if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
+            hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), lds_bytes, c.stream, *c.ring, (const W*)c.digits, (const W*)nullptr, c.hint, c.out,
+                               (unsigned)c.nct, 0, c.a, c.b, c.spre_r2);
+        } else {
+            auto k = k_ks_accum_split<LOGN, W, false, true>;
+            if ((e = set_lds(k, lds_bytes)) != hipSuccess) return e;
+            hipLaunchKernelGGL(k, dim3(grid), dim3(G::T), lds_bytes, c.stream, *c.ring, (const W*)c.digits, (const W*)nullptr, c.hint, c.out,
+                               (unsigned)c.nct, 0, c.a, c.b, c.spre_r2);
         }
     } else {
-        return hipErrorInvalidValue;        // the two-launch fused kernels exist for LDS-resident sizes only
+        return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }

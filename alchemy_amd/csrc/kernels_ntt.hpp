@@ -82,7 +82,10 @@ struct DropTab {
 struct LaunchOpts {
     int ti_split = 1;        // n = 2^15 tensor kernel: 1 = split form, one workgroup per item; 0 = whole-polynomial kernel; > 1 = that many persistent workgroups
     int ti_grid = -1;        // whole-polynomial tensor kernel: -1 = one resident set of persistent workgroups, 0 = one workgroup per item, n > 0 = n workgroups
-    int split_fused = 1;     // n = 2^16 (32-bit) / 2^15 (64-bit): digit transforms + hint products in one kernel (k_ks_accum_split)
+    int split_fused = 2;     // n = 2^16 (32-bit) / 2^15 (64-bit) key switch: 2 = two launches per chunk, tensor product in the loaders
+                             // (k_tensor_crtinv_split + k_ks_accum_split<FROM_OPS>; alch_ct_mul_relin with TrivGad hints), 1 = element-wise tensor
+                             // kernel + crtInv + digit transforms and hint products in one kernel (k_ks_accum_split; what alch_ct_mul_full
+                             // uses), 0 = every step its own kernel
     int gen_fused = 1;       // general index: 1 = fused tensor + key switch kernels (kernel_gen.hpp).  Round 2 measured 0.69-0.82x the composed
                              // path (48 accumulators + the CRT_13 pass matrices in VGPRs spilled); with the pass matrices in SGPRs (round 3) the
                              // kernel needs 127 VGPRs, no scratch: 1.13x on H5', 1.24x on H3', 1.08x on H1', 0.99x on H0'  (key switch, L = 4)

@@ -196,6 +196,34 @@ def q30_line(B):
             "frac_at_device_word": rates[1] * algo / 2 / 1e9 / HBM_PEAK_GBS}
 
 
+def n16_line():
+    """Extra line: the headline op at n = 2^16 on six limbs (SURVEY 8d's two-power stand-in for BASELINE configs 4 / 5's wording, six primes
+    that are 1 mod 2^17): a limb-polynomial is 256 KiB, twice an LDS-resident transform, so the transforms are split (kernel_crt_split.hpp);
+    two launches per chunk since round 3 (k_tensor_crtinv_split, k_ks_accum_split<FROM_OPS>).  Whole batch asserted against the oracle."""
+    from alchemy_amd import Ring
+    qs = [2147352577, 2146959361, 2146041857, 2144468993, 2142502913, 2135818241]
+    n, B = 1 << 16, 2048
+    ring = Ring(2 * n, qs)
+    apply_opts(ring)
+    a, b, out, hs = ring.alloc(2 * B), ring.alloc(2 * B), ring.alloc(2 * B), ring.alloc(2 * ring.L)
+    a.fill_uniform(2026); b.fill_uniform(900_000_007); hs.fill_uniform(0xA1C4E5)
+    hint = ring.hint_from_buf(hs)
+    ring.ct_mul_relin(hint, a, b, out, B)
+    ring.sync()
+    ring.timer_start()
+    for _ in range(3):
+        ring.ct_mul_relin(hint, a, b, out, B)
+    ops = 3 * B / (ring.timer_stop() * 1e-3)
+    ref = golden_checksums().get("n16", {}).get("bench_mul_relin")
+    check = None
+    if ref is not None and ref["batch"] == B:
+        check = assert_checksum("n = 2^16, six limbs", out.checksum(), ref["checksum"], {"batch": B})
+    algo = 6 * len(qs) * n * 8
+    return {"workload": "keySwitchQuadCirc(hint, a*b), n=2^16, 6 limbs (31-bit primes = 1 mod 2^17), TrivGad, CRT in/out, split transforms",
+            "ops_per_s": ops, "batch": B, "batch_checksum": check, "algorithmic_bytes_per_op": algo, "achieved_GBs": ops * algo / 1e9,
+            "frac_of_hbm_peak": ops * algo / 1e9 / HBM_PEAK_GBS, "frac_at_device_word": ops * algo / 2 / 1e9 / HBM_PEAK_GBS}
+
+
 def tunnel_hs_line():
     """Extra line: BASELINE config 5 at the reference's real parameters -- the five hops of examples/Tunnel.hs (BaseBGad 2 hints,
     its moduli, H0' .. H5'), each as modSwitch . tunnel hint . modSwitch on 2048 resident ciphertexts (alchemy_amd/tunnelhops.py);
@@ -287,6 +315,8 @@ def main():
     ap.add_argument("--pipeline-batch", type=int, default=1024, help="ciphertexts per GPU in the HomomRLWR pipeline")
     ap.add_argument("--no-tunnel-hs", dest="tunnel_hs", action="store_false",
                     help="skip the examples/Tunnel.hs hops (BASELINE config 5: BaseBGad 2 hints, extra field `tunnel_hs`)")
+    ap.add_argument("--no-n16", dest="n16", action="store_false",
+                    help="skip the extra line: the headline op at n = 2^16 on six limbs (split transforms)")
     ap.add_argument("--no-q30", dest="q30", action="store_false",
                     help="skip the extra line: the headline op on moduli below 2^30 (Harvey-butterfly kernels)")
     ap.add_argument("--no-config2", dest="config2", action="store_false",
@@ -459,12 +489,14 @@ def main():
     if args.general and rank == 0:
         general = general_index_line()
 
-    tunnel_hs = config2 = q30 = None
-    if rank == 0 and (args.tunnel_hs or args.config2 or args.q30):
+    tunnel_hs = config2 = q30 = n16 = None
+    if rank == 0 and (args.tunnel_hs or args.config2 or args.q30 or args.n16):
         del a, b, out
         a = b = out = None
         if args.q30:
             q30 = q30_line(B)
+        if args.n16:
+            n16 = n16_line()
         if args.tunnel_hs:
             tunnel_hs = tunnel_hs_line()
         if args.config2:
@@ -585,6 +617,8 @@ def main():
             line["config2"] = config2
         if q30 is not None:
             line["moduli_below_2_30"] = q30
+        if n16 is not None:
+            line["n16_six_limbs"] = n16
         line["result_gather"] = gather
         if world == 1 and args.cpu_ops > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_ops)

@@ -12,12 +12,13 @@
      restatement; about an hour of CPU time split over the cores);
    * tunnel_hs: the five BaseBGad-2 hops of alchemy_amd/tunnelhops.py (examples/Tunnel.hs), one checksum per ciphertext of the
      B = 256 batches bench.py times.
+   * n16: the headline op at n = 2^16 on six limbs (split transforms), B = 2048 for bench.py's extra line and a ragged test batch;
    * q30: the headline op on four moduli below 2^30 (Harvey-butterfly kernels), B = 8192 for bench.py's extra line and the ragged
      test batch;
    Per-ciphertext lists let any prefix (a ragged test batch) be checked: sums are position-dependent, so they add.
 A result error confined to any chunk, stream or persistent-workgroup slot changes the sum.
 
-    python tests/golden/make_batch_checksums.py [two_power] [q30] [general] [homomrlwr] [tunnel_hs]     (default: all; sections not
+    python tests/golden/make_batch_checksums.py [two_power] [q30] [n16] [general] [homomrlwr] [tunnel_hs]     (default: all; sections not
     regenerated are kept from the existing file)"""
 import json
 import os
@@ -70,8 +71,11 @@ def run_ranges(fn, total):
     return sum(out) & MASK
 
 
-def relin_range(first, count, qs=CFG3_QS):
-    return cref.Ring(N, qs).mul_relin_checksum(SEED_A, SEED_B, SEED_H, first, count)
+def relin_range(first, count, qs=CFG3_QS, n=N):
+    return cref.Ring(n, qs).mul_relin_checksum(SEED_A, SEED_B, SEED_H, first, count)
+
+
+SIX_QS_17 = [2147352577, 2146959361, 2146041857, 2144468993, 2142502913, 2135818241]   # six primes < 2^31 that are 1 mod 2^17
 
 
 Q30_QS = [1073479681, 1071513601, 1070727169, 1068236801]          # the four largest primes < 2^30 that are 1 mod 2^17
@@ -170,7 +174,7 @@ if __name__ == "__main__":
     cref.build()
     path = os.path.join(HERE, "batch_checksums.json")
     out = json.load(open(path)) if os.path.exists(path) else {}
-    want = set(sys.argv[1:]) or {"two_power", "q30", "general", "homomrlwr", "tunnel_hs", "config2"}
+    want = set(sys.argv[1:]) or {"two_power", "q30", "n16", "general", "homomrlwr", "tunnel_hs", "config2"}
     if "q30" in want:
         B_TEST, B_BENCH = 2 * 1024 + 37, 8192
         head = run_ranges(lambda f, c: relin_range(f, c, Q30_QS), B_TEST)
@@ -188,6 +192,14 @@ if __name__ == "__main__":
                     "test_mul_relin": {"batch": B_TEST, "checksum": f"{head:016x}"},
                     "bench_mul_relin": {"batch": B_BENCH, "checksum": f"{(head + tail) & MASK:016x}"},
                     "test_mul_full": {"batch": B_TEST, "limbs": "4 -> 5 -> 3", "checksum": f"{full:016x}"}})
+    if "n16" in want:
+        B_TEST, B_BENCH = 1024 + 37, 2048
+        head = run_ranges(lambda f, c: relin_range(f, c, SIX_QS_17, 1 << 16), B_TEST)
+        tail = run_ranges(lambda f, c: relin_range(B_TEST + f, c, SIX_QS_17, 1 << 16), B_BENCH - B_TEST)
+        out["n16"] = {"what": "the headline op (same seeds) at n = 2^16 on SURVEY 8d's six primes that are 1 mod 2^17 (the two-power stand-in for "
+                              "BASELINE configs 4 / 5's wording): split transforms", "n": 1 << 16, "moduli": SIX_QS_17,
+                      "test_mul_relin": {"batch": B_TEST, "checksum": f"{head:016x}"},
+                      "bench_mul_relin": {"batch": B_BENCH, "checksum": f"{(head + tail) & MASK:016x}"}}
     if "general" in want:
         B_G, B_GT = 4096, 533
         sums = pool_map(general_ct, list(range(B_G)))

@@ -58,6 +58,31 @@ def test_mul_relin_bench_shape_moduli_below_2_30(oracle_lib):
         assert np.array_equal(got[0], w0) and np.array_equal(got[1], w1), ct
 
 
+def test_mul_relin_n16_six_limbs_ragged_batch(oracle_lib):
+    """bench.py's `n16_six_limbs` line at a ragged batch (one full 1024-ciphertext chunk + 37): n = 2^16, six limbs, the split-ring
+    kernels (k_tensor_crtinv_split, k_ks_accum_split<FROM_OPS>) on two streams; whole-batch checksum against the C restatement's, three
+    ciphertexts word for word, and the composed forms (split_fused = 1, 0) give the same words."""
+    ref = load_golden("batch_checksums.json")
+    B, seeds, qs, n = ref["n16"]["test_mul_relin"]["batch"], ref["seeds"], ref["n16"]["moduli"], ref["n16"]["n"]
+    g, o = A.Ring(2 * n, qs), oracle_lib.Ring(n, qs)
+    a, b, out, hs = g.alloc(2 * B), g.alloc(2 * B), g.alloc(2 * B), g.alloc(2 * g.L)
+    a.fill_uniform(seeds["a"]); b.fill_uniform(seeds["b"]); hs.fill_uniform(seeds["hint"])
+    hint = g.hint_from_buf(hs)
+    g.ct_mul_relin(hint, a, b, out, B)
+    assert f"{out.checksum():016x}" == ref["n16"]["test_mul_relin"]["checksum"]
+    hint_host = [o.fill_uniform(seeds["hint"], i) for i in range(2 * g.L)]
+    for ct in (0, 1023, 1060):
+        got = out.download(2 * ct, 2)
+        w0, w1 = o.ct_mul_relin(hint_host, o.fill_uniform(seeds["a"], 2 * ct), o.fill_uniform(seeds["a"], 2 * ct + 1),
+                                o.fill_uniform(seeds["b"], 2 * ct), o.fill_uniform(seeds["b"], 2 * ct + 1))
+        assert np.array_equal(got[0], w0) and np.array_equal(got[1], w1), ct
+    for mode in (1, 0):
+        g.set_option("split_fused", mode)
+        out2 = g.alloc(2 * 70)
+        g.ct_mul_relin(hint, a, b, out2, 70)
+        assert out2.checksum() == out.checksum(0, 2 * 70), mode
+
+
 def test_mul_full_bench_shape(oracle_lib):
     ref = load_golden("batch_checksums.json")
     B, seeds = ref["test_mul_full"]["batch"], ref["seeds"]

@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 CTRS="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 run() { name=$1; shift; echo "== $name: rocprofv3 --kernel-trace --pmc $CTRS -- $*" >> "$out/commands.txt";
         timeout -k 10 400 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d "$out" -o "$name" -- "$@" > "$out/$name.log" 2>&1 || echo "$name failed" >> "$out/commands.txt"; }
-run headline  python3 $root/bench.py --steps 1 --warmup 0 --batch 2048 --cpu-ops 0 --no-full --no-pow --no-general --no-pipeline --no-tunnel-hs --no-config2 --no-q30 --opt one_stream=1
+run headline  python3 $root/bench.py --steps 1 --warmup 0 --batch 2048 --cpu-ops 0 --no-full --no-pow --no-general --no-pipeline --no-tunnel-hs --no-config2 --no-q30 --no-n16 --opt one_stream=1
 run general   python3 $root/tools/bench_general.py 20475
 run homomrlwr python3 $root/tools/bench_homomrlwr.py 1024
 cd "$root"

@@ -14,7 +14,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-HEAD="--cpu-ops 0 --no-full --no-pow --no-general --no-pipeline --no-tunnel-hs --no-config2 --no-q30"
+HEAD="--cpu-ops 0 --no-full --no-pow --no-general --no-pipeline --no-tunnel-hs --no-config2 --no-q30 --no-n16"
 run() { name=$1; shift; echo "== $name: $*" >> "$out/commands.txt"; timeout -k 10 300 "$@" > "$out/$name.log" 2>&1 || echo "$name failed" >> "$out/commands.txt"; }
 run stats   rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o stats -- python3 $root/bench.py --steps 5 --warmup 1 $HEAD
 run stats1  rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o stats1 -- python3 $root/bench.py --steps 5 --warmup 1 --cpu-ops 0 --no-tunnel-hs --no-config2 --opt one_stream=1

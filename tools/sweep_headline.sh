@@ -4,7 +4,7 @@
 mkdir -p gpurun_out
 out=gpurun_out/sweep_headline.jsonl
 : > "$out"
-F="--no-pow --no-full --no-general --no-pipeline --no-tunnel-hs --no-config2 --no-q30 --cpu-ops 0 --steps 10 --warmup 2"
+F="--no-pow --no-full --no-general --no-pipeline --no-tunnel-hs --no-config2 --no-q30 --no-n16 --cpu-ops 0 --steps 10 --warmup 2"
 for v in "$@"; do
     opts=""
     for kv in $v; do opts="$opts --opt $kv"; done
