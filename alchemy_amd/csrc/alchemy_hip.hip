@@ -60,6 +60,9 @@ struct alch_ring {
     int device = 0;                            // HIP device the ring's streams, tables and buffers live on
     LaunchOpts opts;                           // launch-structure options (alch_ring_set_option)
     bool one_stream = false;
+    int nstreams = 2;                          // alch_ct_mul_relin: independent (tensor, key switch) pipelines the chunks rotate over (1 .. 4)
+    hipStream_t xs[2] = {nullptr, nullptr};    // pipelines 3 and 4, created on first use
+    hipEvent_t ev_xs[2] = {nullptr, nullptr};
     int pipe = 0;                              // alch_ct_mul_relin: 1 = tensor kernels on the aux stream one chunk ahead of the key-switch kernels
     hipEvent_t ev_pa[2] = {nullptr, nullptr}, ev_pb[2] = {nullptr, nullptr};
     unsigned rs_slots = 512;                   // resident workgroups of k_rescale_out (each owns a stash slot)
@@ -1035,6 +1038,10 @@ extern "C" int alch_ring_destroy(alch_ring* r) {
     for (int e = 0; e < 2; ++e) { if (r->ev_pa[e]) (void)hipEventDestroy(r->ev_pa[e]); if (r->ev_pb[e]) (void)hipEventDestroy(r->ev_pb[e]); }
     if (r->ev_join) (void)hipEventDestroy(r->ev_join);
     if (r->aux) { (void)hipStreamSynchronize(r->aux); (void)hipStreamDestroy(r->aux); }
+    for (int e = 0; e < 2; ++e) {
+        if (r->xs[e]) { (void)hipStreamSynchronize(r->xs[e]); (void)hipStreamDestroy(r->xs[e]); }
+        if (r->ev_xs[e]) (void)hipEventDestroy(r->ev_xs[e]);
+    }
     if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
     delete r;
     return ALCH_OK;
@@ -1064,6 +1071,7 @@ extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) 
     if (k == "chunk") { if (value < 8) return fail(ALCH_E_INVALID, "chunk must be >= 8"); r->chunk = (size_t)value; }
     else if (k == "one_stream") r->one_stream = value != 0;
     else if (k == "pipe") r->pipe = value != 0;
+    else if (k == "nstreams") { if (value < 1 || value > 4) return fail(ALCH_E_INVALID, "nstreams: 1 .. 4"); r->nstreams = (int)value; }
     else if (k == "q30") r->opts.q30 = value != 0;
     else if (k == "ks_grid") { if (value < 1) return fail(ALCH_E_INVALID, "ks_grid must be >= 1"); r->opts.ks_grid = (unsigned)value; }
     else if (k == "ti_grid") r->opts.ti_grid = (int)value;
@@ -1901,8 +1909,14 @@ static int do_mul_relin(alch_ring* r, const alch_hint* hint, const void* a, cons
     const size_t cap = std::max<size_t>(8, (((size_t)1 << 32) - 1) / (2 * elem_bytes(r)) / 8 * 8);
     const size_t chunk = std::min(std::min(r->chunk, cap), (batch + 7) / 8 * 8);
     const size_t dig_bytes = chunk * elem_words(r) * sizeof(SW);
-    int rc = ensure_ws(&r->ws_digits, &r->ws_digits_bytes, 2 * dig_bytes);
+    const int ns = r->one_stream ? 1 : r->nstreams;
+    int rc = ensure_ws(&r->ws_digits, &r->ws_digits_bytes, (size_t)std::max(2, ns) * dig_bytes);
     if (rc != ALCH_OK) return rc;
+    for (int e = 0; e + 2 < ns; ++e) {
+        if (!r->xs[e]) HIP_TRY(hipStreamCreateWithFlags(&r->xs[e], hipStreamNonBlocking));
+        if (!r->ev_xs[e]) HIP_TRY(hipEventCreateWithFlags(&r->ev_xs[e], hipEventDisableTiming));
+    }
+    hipStream_t lanes[4] = {r->stream, r->aux, r->xs[0], r->xs[1]};
     NttCall<W> c{};
     c.ring = &dev_ring<W>(r);
     c.hint = reinterpret_cast<const W*>(hint->dptr);
@@ -1914,7 +1928,7 @@ static int do_mul_relin(alch_ring* r, const alch_hint* hint, const void* a, cons
     const bool two = batch > chunk && !r->one_stream;
     if (two) {
         HIP_TRY(hipEventRecord(r->ev_fork, r->stream));
-        HIP_TRY(hipStreamWaitEvent(r->aux, r->ev_fork, 0));
+        for (int e = 1; e < ns; ++e) HIP_TRY(hipStreamWaitEvent(lanes[e], r->ev_fork, 0));
     }
     size_t idx = 0;
     if (two && r->pipe) {
@@ -1950,9 +1964,9 @@ static int do_mul_relin(alch_ring* r, const alch_hint* hint, const void* a, cons
     }
     for (size_t done = 0; done < batch; done += chunk, ++idx) {
         const size_t now = std::min(chunk, batch - done);
-        const bool odd = two && (idx & 1);
-        c.stream = odd ? r->aux : r->stream;
-        c.digits = reinterpret_cast<char*>(r->ws_digits) + (odd ? dig_bytes : 0);
+        const int lane = two ? (int)(idx % (size_t)ns) : 0;
+        c.stream = lanes[lane];
+        c.digits = reinterpret_cast<char*>(r->ws_digits) + (size_t)lane * dig_bytes;
         c.a = reinterpret_cast<const W*>(a) + done * ct_words;
         c.b = reinterpret_cast<const W*>(b) + done * ct_words;
         c.out = reinterpret_cast<W*>(out) + done * ct_words;
@@ -1967,6 +1981,10 @@ static int do_mul_relin(alch_ring* r, const alch_hint* hint, const void* a, cons
     if (two) {
         HIP_TRY(hipEventRecord(r->ev_join, r->aux));
         HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_join, 0));
+        for (int e = 2; e < ns; ++e) {
+            HIP_TRY(hipEventRecord(r->ev_xs[e - 2], lanes[e]));
+            HIP_TRY(hipStreamWaitEvent(r->stream, r->ev_xs[e - 2], 0));
+        }
     }
     return ALCH_OK;
 }
