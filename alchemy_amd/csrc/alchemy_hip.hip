@@ -813,6 +813,10 @@ static int build_gen_ring(alch_ring* r, DevRing<W>& d, GenDev<W>& g) {
     g.plain = (!r->has_crt && !r->zdom) ? 1 : 0;
     g.smallq = r->has_crt ? 1 : 0;
     for (int j = 0; j < L; ++j) if (r->q[j] >= 1753413056ull) g.smallq = 0;      // 6 q^2 < 2^64
+    if (g.smallq) {                                                                // 6 q < 2^32: examples/Tunnel.hs's moduli
+        g.smallq = 2;
+        for (int j = 0; j < L; ++j) if (r->q[j] >= 715827882ull) g.smallq = 1;
+    }
     u64 maxhalf = 0;
     for (int j = 0; j < L; ++j) maxhalf = std::max(maxhalf, r->q[j] ? (r->q[j] - 1) / 2 : 0);
     if (!r->has_crt) {

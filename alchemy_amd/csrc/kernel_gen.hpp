@@ -68,7 +68,8 @@ struct GenDev {
     const W* gcrt_inv[MAXL];
     W radinv_m[MAXL];                    // (odd radical of m)^-1 mod q_j in Montgomery form; 0 = not a unit (divG fails)
     u32 rad;
-    int smallq;                          // every modulus < 2^32 / sqrt(6): six-term lazy accumulation in the p = 13 passes (dense_row)
+    int smallq;                          // 1: every modulus < 2^32 / sqrt(6): six-term lazy accumulation in the p = 13 passes (dense_row);
+                                         // 2: every modulus < 2^32 / 6 as well: no conditional subtraction in front of the reductions
     int nt;                              // host side: threads per workgroup of the transform kernels (0 = by ring size: gen_threads)
     int plain;                           // ring without CRT over an arbitrary modulus 2 <= q < 2^31 (Lol: a plaintext ring
                                          // Z_p): no Montgomery constants, products by `%`; radinv_m is then a plain residue
@@ -118,28 +119,33 @@ hipError_t gen_ks_dispatch(const DevRing<u64>& R, const GenDev<u64>& G, const Ge
 // 32-bit words: four products are summed in 64 bits before one reduction -- 4 q^2 < 2^64, the sum's high word is < 2q, one
 // conditional subtraction brings the sum below q 2^32, then a single Montgomery reduction: 10 instructions per four terms
 // instead of 20.  64-bit words: one product at a time.
-// SMALLQ (every modulus of the ring below 2^32 / sqrt(6) = 1 753 413 056: all of the reference's): up to SIX products are summed
+// LVL 1 (every modulus of the ring below 2^32 / sqrt(6) = 1 753 413 056: all of the reference's): up to SIX products are summed
 // before one reduction -- 6 q^2 < 2^64, the sum's high word is < 2.2 q and takes two conditional subtractions (2q, q).  One
 // Montgomery reduction per row of a CRT_13 / DFT_13 half-matrix instead of two: 14 instructions per row instead of 21.
-template <int R, bool SMALLQ = false, typename MP>
+// LVL 2 (every modulus below 2^32 / 6 = 715 827 882: all of examples/Tunnel.hs's): six q^2 stay below q 2^32, the sum's high word is
+// already below q -- no conditional subtraction in front of the reduction (10 instructions per six-term row instead of 14).  Any level:
+// a chunk of one or two products needs none either (2 q^2 < q 2^32 for every q < 2^31).
+template <int R, int LVL = 0, typename MP>
 __device__ __forceinline__ u32 dense_row(const u32* x, MP M, u32 q, u32 qni) {
-    constexpr int CH = SMALLQ ? 6 : 4;
+    constexpr int CH = LVL ? 6 : 4;
     u32 acc = 0;
 #pragma unroll
     for (int t0 = 0; t0 < R; t0 += CH) {
+        const int terms = (R - t0 < CH) ? R - t0 : CH;
         u64 p = (u64)x[t0] * M[t0];
 #pragma unroll
         for (int t = t0 + 1; t < t0 + CH && t < R; ++t) p += (u64)x[t] * M[t];
         u32 hi = (u32)(p >> 32);
-        if (SMALLQ && R - t0 > 4) hi = csub(hi, 2u * q);                        // more than four terms: high word < 2.2 q
-        const u64 pr = ((u64)csub(hi, q) << 32) | (u32)p;                        // high word < 2q -> < q
+        if (LVL == 1 && terms > 4) hi = csub(hi, 2u * q);                       // more than four terms: high word < 2.2 q
+        if (terms > 2 && LVL != 2) hi = csub(hi, q);                             // high word < 2q -> < q
+        const u64 pr = ((u64)hi << 32) | (u32)p;
         const u32 m = (u32)pr * qni;
         const u32 v = csub((u32)((pr + (u64)m * q) >> 32), q);
         acc = t0 ? csub(acc + v, q) : v;
     }
     return acc;
 }
-template <int R, bool SMALLQ = false, typename MP>
+template <int R, int LVL = 0, typename MP>
 __device__ __forceinline__ u64 dense_row(const u64* x, MP M, u64 q, u64 qni) {
     u64 acc = csub(mont_mul_lazy(x[0], M[0], q, qni), q);
 #pragma unroll
@@ -147,7 +153,8 @@ __device__ __forceinline__ u64 dense_row(const u64* x, MP M, u64 q, u64 qni) {
     return acc;
 }
 template <typename W> __device__ __forceinline__ W gadd(W a, W b, W q) { return csub((W)(a + b), q); }
-template <typename W> __device__ __forceinline__ W gsub(W a, W b, W q) { return csub((W)(a + (q - b)), q); }
+// a - b mod q for canonical a, b: the difference wraps to a huge word exactly when a < b, and then adding q wraps back below it
+template <typename W> __device__ __forceinline__ W gsub(W a, W b, W q) { const W d = a - b, e = d + q; return e < d ? e : d; }
 template <typename W> __device__ __forceinline__ W gmul(W a, W b, W q, W qni) { return csub(mont_mul_lazy(a, b, q, qni), q); }
 
 // CRT_p and DFT_p through the symmetry  w^(i (p-j)) = w^(-i j):  with u_j = x_j + x_{p-j}, v_j = x_j - x_{p-j} (j = 1..h,
@@ -158,7 +165,7 @@ template <typename W> __device__ __forceinline__ W gmul(W a, W b, W q, W qni) { 
 //   forward CRT_p : inputs x_0..x_{p-2} (x_{p-1} = 0), outputs y_1..y_{p-1} at slots 0..p-2
 //   inverse CRT_p : y_0 = -sum_i y_i w^i (the condition x_{p-1} = 0), then the inverse DFT_p (w -> w^-1, a, b, carry 1/p)
 //   forward DFT_p : y_0 = sum_j x_j as well;  inverse DFT_p : the same with w^-1 and 1/p
-template <typename W, int NT, int P, bool IS_DFT, bool INV, bool SMALLQ = false>
+template <typename W, int NT, int P, bool IS_DFT, bool INV, int SMALLQ = 0>
 __device__ __forceinline__ void gen_sym_pass(W* __restrict__ lds, const GenPass& Ps, const W* __restrict__ tab, u32 n, W q, W qni, u32 tid) {
     constexpr int H = (P - 1) / 2, R = IS_DFT ? P : P - 1;
     // CRT_p passes never carry twiddles, DFT_p passes always do (gen_plan): a compile-time fact, so the per-element loads below are
@@ -322,10 +329,14 @@ __device__ __forceinline__ void gen_run_pass(W* lds, const GenPass& P, const W* 
         switch (p) {
         case 3: gen_sym_pass<W, NT, 3, false, INV>(lds, P, tab, n, q, qni, tid); break;
         case 5: gen_sym_pass<W, NT, 5, false, INV>(lds, P, tab, n, q, qni, tid); break;
-        case 7: gen_sym_pass<W, NT, 7, false, INV>(lds, P, tab, n, q, qni, tid); break;
+        case 7:
+            if (sizeof(W) == 4 && smallq == 2) gen_sym_pass<W, NT, 7, false, INV, 2>(lds, P, tab, n, q, qni, tid);
+            else gen_sym_pass<W, NT, 7, false, INV>(lds, P, tab, n, q, qni, tid);
+            break;
         case 11: gen_sym_pass<W, NT, 11, false, INV>(lds, P, tab, n, q, qni, tid); break;
         case 13:                                   // (wave-uniform: the ring's moduli decide)
-            if (sizeof(W) == 4 && smallq) gen_sym_pass<W, NT, 13, false, INV, true>(lds, P, tab, n, q, qni, tid);
+            if (sizeof(W) == 4 && smallq == 2) gen_sym_pass<W, NT, 13, false, INV, 2>(lds, P, tab, n, q, qni, tid);
+            else if (sizeof(W) == 4 && smallq) gen_sym_pass<W, NT, 13, false, INV, 1>(lds, P, tab, n, q, qni, tid);
             else gen_sym_pass<W, NT, 13, false, INV>(lds, P, tab, n, q, qni, tid);
             break;
         default: break;                            // the host refuses indices with other odd primes
@@ -334,10 +345,14 @@ __device__ __forceinline__ void gen_run_pass(W* lds, const GenPass& P, const W* 
         switch (p) {
         case 3: gen_sym_pass<W, NT, 3, true, INV>(lds, P, tab, n, q, qni, tid); break;
         case 5: gen_sym_pass<W, NT, 5, true, INV>(lds, P, tab, n, q, qni, tid); break;
-        case 7: gen_sym_pass<W, NT, 7, true, INV>(lds, P, tab, n, q, qni, tid); break;
+        case 7:
+            if (sizeof(W) == 4 && smallq == 2) gen_sym_pass<W, NT, 7, true, INV, 2>(lds, P, tab, n, q, qni, tid);
+            else gen_sym_pass<W, NT, 7, true, INV>(lds, P, tab, n, q, qni, tid);
+            break;
         case 11: gen_sym_pass<W, NT, 11, true, INV>(lds, P, tab, n, q, qni, tid); break;
         case 13:
-            if (sizeof(W) == 4 && smallq) gen_sym_pass<W, NT, 13, true, INV, true>(lds, P, tab, n, q, qni, tid);
+            if (sizeof(W) == 4 && smallq == 2) gen_sym_pass<W, NT, 13, true, INV, 2>(lds, P, tab, n, q, qni, tid);
+            else if (sizeof(W) == 4 && smallq) gen_sym_pass<W, NT, 13, true, INV, 1>(lds, P, tab, n, q, qni, tid);
             else gen_sym_pass<W, NT, 13, true, INV>(lds, P, tab, n, q, qni, tid);
             break;
         default: break;
