@@ -109,14 +109,23 @@ __device__ __forceinline__ u32 mont_red_lazy(u64 p, u32 q, u32 qni) {       // p
 // item, limb, slice rotation) is scalar and travels in the instruction's SGPR offset.  With flat loads the same
 // addresses cost ~150 VALU instructions of 64-bit pointer arithmetic per digit transform.  All byte offsets are
 // below 2^32 (the host caps the chunk size accordingly).
-template <typename Rsrc>
+// CP: cache policy bits of the instruction (gfx940+: 1 = sc0, 2 = nt, 16 = sc1).  The tensor inputs and the results stream through once:
+// marked non-temporal they do not displace the digits and hint rows (read by six items each) in L2 -- +1.7 % on the headline
+// (same-box A/B, tools/ab_variants.sh: 532 k -> 541 k op/s; inputs alone +1 %, results alone +-0; the same on kernel A's operand loads +-0).
+#ifndef ALCH_KS_NT_IN
+#define ALCH_KS_NT_IN 2
+#endif
+#ifndef ALCH_KS_NT_OUT
+#define ALCH_KS_NT_OUT 2
+#endif
+template <int CP = 0, typename Rsrc>
 __device__ __forceinline__ u32 __attribute__((ext_vector_type(4))) buf_ld16(Rsrc r, u32 voff, u32 soff) {
     typedef u32 V4 __attribute__((ext_vector_type(4)));
-    return __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, CP));
 }
-template <typename Rsrc>
+template <int CP = 0, typename Rsrc>
 __device__ __forceinline__ void buf_st16(Rsrc r, u32 voff, u32 soff, u32 __attribute__((ext_vector_type(4))) v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)), v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(r, 0, 0, 0)), v), r, voff, soff, CP);
     ALCH_STORE_GUARD(v);
 }
 
@@ -189,8 +198,8 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
             v0[e] = Q30 ? csub(acc0[r * 4 + e], pq) : acc0[r * 4 + e];
             v1[e] = Q30 ? csub(acc1[r * 4 + e], pq) : acc1[r * 4 + e];
         }
-        buf_st16(ro, lane16, po0 + so, v0);
-        buf_st16(ro, lane16, po1 + so, v1);
+        buf_st16<ALCH_KS_NT_OUT>(ro, lane16, po0 + so, v0);
+        buf_st16<ALCH_KS_NT_OUT>(ro, lane16, po1 + so, v1);
     };
     auto flush_stores = [&]() {
 #pragma unroll
@@ -232,8 +241,8 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
         V in[ID][6];
         auto issue = [&](int s, V (&v)[6]) {
             const u32 so = SLICE * (u32)((s + rot) & (EPT / 4 - 1));               // lane-contiguous 16-byte pieces
-            v[0] = buf_ld16(ra, lane16, a0 + so); v[1] = buf_ld16(ra, lane16, a1 + so);
-            v[2] = buf_ld16(rb, lane16, a0 + so); v[3] = buf_ld16(rb, lane16, a1 + so);
+            v[0] = buf_ld16<ALCH_KS_NT_IN>(ra, lane16, a0 + so); v[1] = buf_ld16<ALCH_KS_NT_IN>(ra, lane16, a1 + so);
+            v[2] = buf_ld16<ALCH_KS_NT_IN>(rb, lane16, a0 + so); v[3] = buf_ld16<ALCH_KS_NT_IN>(rb, lane16, a1 + so);
             v[4] = buf_ld16(rh, lane16, h0 + so); v[5] = buf_ld16(rh, lane16, h1 + so);
         };
         issue(0, in[0]);

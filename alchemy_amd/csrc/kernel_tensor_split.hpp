@@ -16,6 +16,11 @@
 #define ALCH_TI_SPLIT_PASSES 4
 #endif
 
+// experiment switch: cache policy of the operand loads (2 = non-temporal: read once by this kernel)
+#ifndef ALCH_TI_NT_IN
+#define ALCH_TI_NT_IN 0
+#endif
+
 namespace alch {
 
 // Q30: every modulus below 2^30 -- 8-instruction inverse butterflies (bfly_inv4); values stay in [0,2q) as otherwise
@@ -58,8 +63,8 @@ k_tensor_intt_split(DevRing<u32> R, const u32* __restrict__ a, const u32* __rest
 #pragma unroll
             for (int r = 0; r < NV; ++r) {
                 const u32 so = row + (u32)half * HALF + SLICE * (u32)((r + rot) & (NV - 1));
-                const V va = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(ra, lane16, so, 0));
-                const V vb = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rb, lane16, so, 0));
+                const V va = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(ra, lane16, so, ALCH_TI_NT_IN));
+                const V vb = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rb, lane16, so, ALCH_TI_NT_IN));
                 V v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = mont_mul_lazy(va[e], vb[e], q, qni);
