@@ -173,7 +173,18 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     // Item numbering is XCD-aware (speed only): the 2L items of one ciphertext agree mod 8, and gridDim is a
     // multiple of 8, so they run on one XCD and its L2 serves the digits they all read.
     const unsigned per = 16u * (unsigned)L;
+    // dbg_mask bit 31 (launch option ks_map = 1, L | 8 only): limb-per-XCD numbering instead -- XCD x = item mod 8 serves limb x mod L
+    // of every (8 / L)-th ciphertext, so an XCD's L2 sees the hint rows of ONE limb (1 MiB at L = 4) at the price of each digit being
+    // fetched by the L - 1 XCDs that transform it.
+    const bool limb_map = (dbg_mask >> 31) != 0;
     auto decode = [&](unsigned item, int& j_, int& hf_, size_t& ct_) {
+        if (limb_map) {
+            const unsigned x = item & 7u, t = item >> 3, pl = 8u / (unsigned)L;
+            j_ = (int)(x % (unsigned)L);
+            hf_ = (int)(t & 1u);
+            ct_ = (size_t)(t >> 1) * pl + x / (unsigned)L;
+            return;
+        }
         const unsigned grp = item / per, rem = item % per;
         const unsigned which = rem >> 3;
         j_ = (int)(which >> 1);
