@@ -19,6 +19,12 @@
 #include <type_traits>
 #include "ntt_engine.hpp"
 
+// cache policy of k_rescale_out_lin's global accesses.  2 = non-temporal was measured at -15 % on the full mul_ (272 k -> 233 k op/s, same box):
+// the limbs it reads were just written by the key-switch kernel and are still served from L2 / Infinity Cache under the default policy.
+#ifndef ALCH_RS_NT
+#define ALCH_RS_NT 0
+#endif
+
 namespace alch {
 
 template <typename W, typename Rsrc>
@@ -167,7 +173,7 @@ k_rescale_out_lin(DevRing<W> R, const W* __restrict__ src, W* __restrict__ out, 
 #pragma unroll
             for (int r = 0; r < G::E / VL; ++r)
                 *reinterpret_cast<V*>(&lds[swz<LOGN>((tid + G::T * r) * VL)]) =
-                    __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, x + (u32)u * ROW + (u32)(G::T * r) * 16u, 0));
+                    __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, x + (u32)u * ROW + (u32)(G::T * r) * 16u, ALCH_RS_NT));
             lds_barrier();
             auto epi = [&](int g, int, W* v) {
 #pragma unroll
@@ -217,7 +223,7 @@ k_rescale_out_lin(DevRing<W> R, const W* __restrict__ src, W* __restrict__ out, 
             ntt_forward<LOGN, W, true, true>(lds, twf, twm, q, qni, tid, [&](int, int base, W* v) {
 #pragma unroll
                 for (int k = 0; k < 16; k += VL) {
-                    const V xin = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, (u32)(base + k) * (u32)sizeof(W), xt, 0));
+                    const V xin = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, (u32)(base + k) * (u32)sizeof(W), xt, ALCH_RS_NT));
                     V res;
 #pragma unroll
                     for (int e = 0; e < VL; ++e) {
@@ -226,7 +232,7 @@ k_rescale_out_lin(DevRing<W> R, const W* __restrict__ src, W* __restrict__ out, 
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(
                         __builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(rout, 0, 0, 0)), res), rout,
-                        (u32)(base + k) * (u32)sizeof(W), ot, 0);
+                        (u32)(base + k) * (u32)sizeof(W), ot, ALCH_RS_NT);
                     // see ALCH_STORE_GUARD (ntt_engine.hpp): this is the store the hazard was found on
                     asm volatile("s_nop 1" ::"v"(res));
                 }
