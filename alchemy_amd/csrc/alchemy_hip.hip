@@ -1076,6 +1076,7 @@ extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) 
     else if (k == "one_stream") r->one_stream = value != 0;
     else if (k == "pipe") r->pipe = value != 0;
     else if (k == "ks_map") r->opts.ks_map = value != 0;
+    else if (k == "ks_rev") r->opts.ks_rev = value != 0;
     else if (k == "nstreams") { if (value < 1 || value > 4) return fail(ALCH_E_INVALID, "nstreams: 1 .. 4"); r->nstreams = (int)value; }
     else if (k == "q30") r->opts.q30 = value != 0;
     else if (k == "ks_grid") { if (value < 1) return fail(ALCH_E_INVALID, "ks_grid must be >= 1"); r->opts.ks_grid = (unsigned)value; }

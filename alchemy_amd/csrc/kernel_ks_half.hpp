@@ -177,7 +177,11 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     // of every (8 / L)-th ciphertext, so an XCD's L2 sees the hint rows of ONE limb (1 MiB at L = 4) at the price of each digit being
     // fetched by the L - 1 XCDs that transform it.
     const bool limb_map = (dbg_mask >> 31) != 0;
+    // dbg_mask bit 30 (launch option ks_rev = 1): walk the items from the last ciphertext of the chunk to the first -- the digits the
+    // tensor kernel wrote last are the ones still in the Infinity Cache
+    const bool rev = ((dbg_mask >> 30) & 1u) != 0;
     auto decode = [&](unsigned item, int& j_, int& hf_, size_t& ct_) {
+        if (rev) item = nitems - 1u - item;
         if (limb_map) {
             const unsigned x = item & 7u, t = item >> 3, pl = 8u / (unsigned)L;
             j_ = (int)(x % (unsigned)L);

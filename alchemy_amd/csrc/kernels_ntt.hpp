@@ -102,6 +102,7 @@ struct LaunchOpts {
     int tunnel_ep = 1;       // alch_tunnel_create: 1 = transforms of the embedded E'-coefficients at dimension phi(e') (embedCRT replication), 0 = at phi(s')
     int rs_lin = 1;          // closing modSwitch: 1 = kept limbs stay in the CRT basis (k_rescale_out_lin), 0 = every limb through the Pow basis
     int ks_map = 0;          // k_ks_accum_half item numbering: 0 = the items of a ciphertext share an XCD (digits in its L2), 1 = a limb per XCD (hint rows in its L2)
+    int ks_rev = 0;          // k_ks_accum_half: 1 = items from the chunk's last ciphertext to its first
     int q30 = 1;             // 32-bit two-power rings whose moduli are all below 2^30: 1 = Harvey butterflies in the fused n = 2^15 / 2^11 kernels
     unsigned ks_grid = 4096; // persistent workgroups of k_ks_accum_half (measured, 1024-ciphertext chunks: 2048 -> 511k, 4096 -> 517k, 8192 -> 513k op/s)
 };
@@ -601,7 +602,7 @@ inline hipError_t run_call(const NttCall<W>& c) {
 #else
             constexpr unsigned dbg_env = 0u;
 #endif
-            const unsigned dbg_mask = dbg_env | ((c.opts.ks_map && 8 % R.L == 0) ? 0x80000000u : 0u);
+            const unsigned dbg_mask = dbg_env | ((c.opts.ks_map && 8 % R.L == 0) ? 0x80000000u : 0u) | (c.opts.ks_rev ? 0x40000000u : 0u);
             if ((size_t)c.nct * 2 * (size_t)R.L * G::N * sizeof(W) >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // 32-bit byte offsets
             const size_t groups = (c.nct + 7) / 8;
             const unsigned nitems = (unsigned)(groups * 16 * (size_t)R.L);

@@ -51,6 +51,7 @@ WORKER = textwrap.dedent("""
     ({"pipe": 1, "chunk": 8}, 11, 37),                   # tensor kernels one chunk ahead of the key-switch kernels, 5 chunks, ragged tail
     ({"pipe": 1, "chunk": 8}, 15, 17),
     ({"ks_map": 1, "chunk": 16}, 11, 37), ({"ks_map": 1}, 15, 11),        # limb-per-XCD item numbering (L = 4 divides 8)
+    ({"ks_rev": 1, "chunk": 16, "ks_grid": 24}, 11, 37), ({"ks_rev": 1}, 15, 11),   # items from the chunk's last ciphertext to its first
     ({"nstreams": 3, "chunk": 8}, 11, 37), ({"nstreams": 4, "chunk": 8}, 15, 33), ({"nstreams": 1, "chunk": 8}, 11, 21),   # pipelines the chunks rotate over
 ])
 def test_launch_structure_does_not_change_results(opts, logn, batch):
