@@ -510,6 +510,10 @@ __global__ void __launch_bounds__(NT, 4) k_gen_crt_base2_digits(DevRing<W> R, Ge
 // HBM-bound element-wise kernels and the digit round trip through HBM (L (L-1) limb-polynomials written and read per op).
 // `dup` > 0: the operands live dup limbs below the hint's ring (PT2CT's mul_, see k_ks_accum_half).
 // ------------------------------------------------------------------------------------------------------
+// experiment switch: non-temporal cache policy for k_gen_ks's operand loads and result stores (they stream through once)
+#ifndef ALCH_GEN_NT
+#define ALCH_GEN_NT 0
+#endif
 constexpr int GEN_KS_T = 512;
 constexpr int GEN_KS_NPT = 24;              // slots per lane: n <= 12288 (every index of the reference)
 
@@ -599,6 +603,13 @@ __global__ void __launch_bounds__(GEN_KS_T, 2) k_gen_ks(DevRing<W> R, GenDev<W> 
             for (int e = 0; e < VL; ++e) o[e] = v[e];
         } else o[0] = p[s];
     };
+    auto ld_once = [&](const W* p, u32 s, W (&o)[VL]) {       // the same for data this kernel reads once (the operands)
+        if constexpr (VEC && ALCH_GEN_NT) {
+            const V v = __builtin_nontemporal_load(reinterpret_cast<const V*>(p + s));
+#pragma unroll
+            for (int e = 0; e < VL; ++e) o[e] = v[e];
+        } else ld(p, s, o);
+    };
     W acc0[NP][VL], acc1[NP][VL];
 #pragma unroll
     for (int kk = 0; kk < NP; ++kk)
@@ -619,7 +630,7 @@ __global__ void __launch_bounds__(GEN_KS_T, 2) k_gen_ks(DevRing<W> R, GenDev<W> 
             const u32 s = (threadIdx.x + (u32)kk * GEN_KS_T) * VL;
             if (s < n) {
                 W va0[VL], va1[VL], vb0[VL], vb1[VL], vg[VL], vh0[VL], vh1[VL];
-                ld(a0, s, va0); ld(a1, s, va1); ld(b0, s, vb0); ld(b1, s, vb1); ld(h0, s, vh0); ld(h1, s, vh1);
+                ld_once(a0, s, va0); ld_once(a1, s, va1); ld_once(b0, s, vb0); ld_once(b1, s, vb1); ld(h0, s, vh0); ld(h1, s, vh1);
                 if (A.use_g) ld(g, s, vg);
 #pragma unroll
                 for (int e = 0; e < VL; ++e) {
@@ -686,8 +697,13 @@ __global__ void __launch_bounds__(GEN_KS_T, 2) k_gen_ks(DevRing<W> R, GenDev<W> 
                 V v0, v1;
 #pragma unroll
                 for (int e = 0; e < VL; ++e) { v0[e] = acc0[kk][e]; v1[e] = acc1[kk][e]; }
-                *reinterpret_cast<V*>(o0 + s) = v0;
-                *reinterpret_cast<V*>(o1 + s) = v1;
+                if constexpr (ALCH_GEN_NT) {
+                    __builtin_nontemporal_store(v0, reinterpret_cast<V*>(o0 + s));
+                    __builtin_nontemporal_store(v1, reinterpret_cast<V*>(o1 + s));
+                } else {
+                    *reinterpret_cast<V*>(o0 + s) = v0;
+                    *reinterpret_cast<V*>(o1 + s) = v1;
+                }
             } else { o0[s] = acc0[kk][0]; o1[s] = acc1[kk][0]; }
         }
     }
