@@ -138,3 +138,36 @@ def test_full_mul_with_base2_hint_on_fewer_limbs_general_index(oracle_lib):
                 w0, w1 = oracle_full_mul_base2_down(oracle_lib, n, qs_in, 2, l_out, list(hint), a[2 * ct], a[2 * ct + 1], b[2 * ct],
                                                     b[2 * ct + 1], s_pre, pow_out=pow_out, m=m)
                 assert np.array_equal(got[2 * ct], w0) and np.array_equal(got[2 * ct + 1], w1), (l_out, ct, pow_out)
+
+
+def test_full_mul_with_base2_hint_on_fewer_limbs_decrypts_to_the_product():
+    """Semantic check of the down-first mul_ on a VALID instance (exact model as the Haskell host: key, encryptions, a BaseBGad 2 hint at
+    the last two of three limbs, r = 3.0): the device result equals the model's
+        modSwitch . keySwitchQuadCirc hint . modSwitch $ x * y
+    (the model rescales every coefficient of the quadratic ciphertext) bit for bit, and the model decrypts it to the product of the
+    plaintexts."""
+    import random
+    import alchemy_amd as A
+    from alchemy_amd import capi
+    from oracle import model as M
+    from helpers import primes_1_mod, to_aos, from_aos
+    rng = random.Random(4177)
+    n, npt, p = 64, 8, 7
+    qs = primes_1_mod(2 * n, 3, lo=1 << 29)
+    sk = M.gen_sk(n, 3.0, rng)
+    pt1, pt2 = [rng.randrange(p) for _ in range(npt)], [rng.randrange(p) for _ in range(npt)]
+    x, y = M.encrypt(sk, pt1, p, qs, 3.0, rng), M.encrypt(sk, pt2, p, qs, 3.0, rng)
+    hint = M.ks_quad_circ_hint(sk, qs[1:], 3.0, rng, gadget="base2")
+    for l_out in (2, 1):
+        want = M.mod_switch_down(M.key_switch_quad_circ(hint, M.mod_switch_down(M.ct_mul(x, y), 1)), 2 - l_out)
+        assert M.decrypt(sk, want, npt) == M.negacyclic_mul(pt1, pt2, p)
+        rin, rh, rout = A.Ring(2 * n, qs), A.Ring(2 * n, qs[1:]), A.Ring(2 * n, qs[3 - l_out:])
+        hb = rh.upload(np.stack([to_aos(h) for pair in hint.h for h in pair])); hb.crt()
+        gh = rh.hint_from_buf(hb, gadget=capi.ALCH_GAD_BASE2)
+        a = rin.upload(np.stack([to_aos(c) for c in x.c])); a.crt()
+        b = rin.upload(np.stack([to_aos(c) for c in y.c])); b.crt()
+        out = rout.alloc(2)
+        # fresh encryptions are LSD already; the product's toMSD scalar p^-1 is the only one (PT2CT.hs:172-177, SymmSHE toMSD)
+        capi.ct_mul_full(gh, a, b, out, 1, s_pre=[pow(p, -1, q) for q in qs], flags=capi.ALCH_POW_OUT)
+        got = out.download()
+        assert [from_aos(got[0]), from_aos(got[1])] == want.c, l_out
