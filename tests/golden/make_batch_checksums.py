@@ -180,7 +180,8 @@ if __name__ == "__main__":
         head = run_ranges(lambda f, c: relin_range(f, c, Q30_QS), B_TEST)
         tail = run_ranges(lambda f, c: relin_range(B_TEST + f, c, Q30_QS), B_BENCH - B_TEST)
         out["q30"] = {"what": "the headline op (same seeds, n = 2^15, 4 limbs) on moduli below 2^30: the Harvey-butterfly kernels",
-                      "moduli": Q30_QS, "test_mul_relin": {"batch": B_TEST, "checksum": f"{head:016x}"},
+                      "moduli": Q30_QS, "first_2": f"{relin_range(0, 2, Q30_QS):016x}",
+                      "test_mul_relin": {"batch": B_TEST, "checksum": f"{head:016x}"},
                       "bench_mul_relin": {"batch": B_BENCH, "checksum": f"{(head + tail) & MASK:016x}"}}
     if "two_power" in want:
         B_TEST, B_BENCH = 2 * 1024 + 37, 8192
@@ -188,6 +189,7 @@ if __name__ == "__main__":
         tail = run_ranges(lambda f, c: relin_range(B_TEST + f, c), B_BENCH - B_TEST)
         full = run_ranges(full_range, B_TEST)
         out.update({"n": N, "moduli": CFG3_QS, "full_extra_modulus": FULL_EXTRA_Q, "seeds": {"a": SEED_A, "b": SEED_B, "hint": SEED_H},
+                    "first_2": f"{relin_range(0, 2):016x}",
                     "rule": "sum over result words of splitmix64(w ^ value << 20), w = limb-major word position (alch_buf_checksum)",
                     "test_mul_relin": {"batch": B_TEST, "checksum": f"{head:016x}"},
                     "bench_mul_relin": {"batch": B_BENCH, "checksum": f"{(head + tail) & MASK:016x}"},
@@ -198,6 +200,7 @@ if __name__ == "__main__":
         tail = run_ranges(lambda f, c: relin_range(B_TEST + f, c, SIX_QS_17, 1 << 16), B_BENCH - B_TEST)
         out["n16"] = {"what": "the headline op (same seeds) at n = 2^16 on SURVEY 8d's six primes that are 1 mod 2^17 (the two-power stand-in for "
                               "BASELINE configs 4 / 5's wording): split transforms", "n": 1 << 16, "moduli": SIX_QS_17,
+                      "first_2": f"{relin_range(0, 2, SIX_QS_17, 1 << 16):016x}",
                       "test_mul_relin": {"batch": B_TEST, "checksum": f"{head:016x}"},
                       "bench_mul_relin": {"batch": B_BENCH, "checksum": f"{(head + tail) & MASK:016x}"}}
     if "general" in want:

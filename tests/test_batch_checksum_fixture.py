@@ -42,3 +42,13 @@ def test_general_index_and_config2_fixtures_are_current(gen):
         sums = [gen.config2_poly((label, e)) for e in range(2)]
         assert [f"{sum(a for a, _ in sums) & gen.MASK:016x}", f"{sum(b for _, b in sums) & gen.MASK:016x}"] == c2[label]["first_2"]
         assert c2[label]["modulus"] == gen.C2_QS[label]
+
+
+def test_two_power_fixtures_are_current(gen):
+    """The headline, < 2^30-moduli and n = 2^16 sections: the checksum of the first two results, recomputed on the C restatement."""
+    ref = load_golden("batch_checksums.json")
+    assert f"{gen.relin_range(0, 2):016x}" == ref["first_2"]
+    assert ref["q30"]["moduli"] == gen.Q30_QS and max(gen.Q30_QS) < 1 << 30
+    assert f"{gen.relin_range(0, 2, gen.Q30_QS):016x}" == ref["q30"]["first_2"]
+    assert ref["n16"]["moduli"] == gen.SIX_QS_17 and ref["n16"]["n"] == 1 << 16
+    assert f"{gen.relin_range(0, 2, gen.SIX_QS_17, 1 << 16):016x}" == ref["n16"]["first_2"]
