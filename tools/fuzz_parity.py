@@ -31,6 +31,7 @@ def main():
         L = rng.randint(1, 6)
         qs = rng.sample(pool, L) if rng.random() < 0.5 else pool[:L]
         batch = rng.randint(1, 40 if logn <= 13 else (12 if logn <= 14 else 5))
+        if logn >= 15 and rng.random() < 0.25: batch = rng.randint(9, 30)          # several chunks of 8 .. 24 at the fused kernels' sizes
         opts = {k: rng.choice(v) for k, v in OPTS.items() if rng.random() < 0.4}
         full = L >= 2 and rng.random() < 0.4
         rnd = lambda c, q_: np.stack([np.stack([nprng.integers(0, q, size=n, dtype=np.int64) for q in q_], axis=1) for _ in range(c)])
