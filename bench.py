@@ -302,7 +302,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8192, help="ciphertext pairs per GPU per step (weak scaling)")
-    ap.add_argument("--cpu-ops", type=int, default=384, help="ops in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-ops", type=int, default=768, help="ops in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-pow", dest="pow", action="store_false",
                     help="skip the Pow-basis in/out variant (SURVEY 8d's COEFF line; extra field, after the timed region)")
     ap.add_argument("--no-full", dest="full", action="store_false",
