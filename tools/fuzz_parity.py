@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU box: alch_ct_mul_relin and alch_ct_mul_full on two-power rings of random size, limb count, moduli
-class (31-bit, below 2^30), batch and launch options, every result word compared with the C restatement (oracle/ is the checker, as in
+class (31-bit, below 2^30), gadget (TrivGad; BaseBGad 2 at small sizes, hint at, above or below the operands' limb count), batch and launch options, every result word compared with the C restatement (oracle/ is the checker, as in
 tests/).  usage: tools/fuzz_parity.py [seconds] [seed]   -- prints one line per case class and a final tally; exits non-zero on a mismatch."""
 import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +9,7 @@ import numpy as np
 import alchemy_amd as A
 from alchemy_amd import capi
 from oracle import cref
-from helpers import oracle_full_mul
+from helpers import oracle_full_mul, oracle_full_mul_base2_down, oracle_mul_relin_base2
 
 SIX31 = [2147352577, 2146959361, 2146041857, 2144468993, 2142502913, 2135818241]          # = 1 mod 2^17
 SIX30 = [1073479681, 1071513601, 1070727169, 1068236801, 1065484289, 1064697857]          # = 1 mod 2^17, below 2^30
@@ -37,6 +37,47 @@ def main():
         rnd = lambda c, q_: np.stack([np.stack([nprng.integers(0, q, size=n, dtype=np.int64) for q in q_], axis=1) for _ in range(c)])
         s_pre = None if rng.random() < 0.5 else [rng.randrange(1, q) for q in qs]
         key = ("full" if full else "relin", logn, "q30" if pool is SIX30 else "q31")
+        if logn <= 11 and L <= 3 and rng.random() < 0.25:              # BaseBGad 2 hints (small sizes: 30 digits per limb)
+            batch = min(batch, 4)
+            kind = rng.choice(["relin", "full_up", "full_down"]) if L >= 2 else "relin"
+            key = ("base2_" + kind, logn, key[2])
+            if kind == "relin":
+                g = A.Ring(2 * n, qs)
+                for k, v in opts.items(): g.set_option(k, v)
+                D = g.gadget_digits(capi.ALCH_GAD_BASE2)
+                hint, a, b = rnd(2 * D, qs), rnd(2 * batch, qs), rnd(2 * batch, qs)
+                out = g.alloc(2 * batch)
+                g.ct_mul_relin(g.hint_load(hint, gadget=capi.ALCH_GAD_BASE2), g.upload(a), g.upload(b), out, batch, s_pre=s_pre)
+                got = out.download()
+                want = [oracle_mul_relin_base2(cref, n, qs, list(hint), a[2 * c], a[2 * c + 1], b[2 * c], b[2 * c + 1], s_pre) for c in range(batch)]
+            elif kind == "full_up":                                     # hint's ring at least as long as the operands'
+                l_in, l_out = rng.randint(1, L), rng.randint(1, L)
+                rh, rin, rout = A.Ring(2 * n, qs), A.Ring(2 * n, qs[L - l_in:]), A.Ring(2 * n, qs[L - l_out:])
+                D = rh.gadget_digits(capi.ALCH_GAD_BASE2)
+                hint, a, b = rnd(2 * D, qs), rnd(2 * batch, qs[L - l_in:]), rnd(2 * batch, qs[L - l_in:])
+                sp = None if s_pre is None else s_pre[L - l_in:]
+                out = rout.alloc(2 * batch)
+                capi.ct_mul_full(rh.hint_load(hint, gadget=capi.ALCH_GAD_BASE2), rin.upload(a), rin.upload(b), out, batch, s_pre=sp)
+                got = out.download()
+                want = [oracle_full_mul(cref, n, qs, l_in, l_out, list(hint), a[2 * c], a[2 * c + 1], b[2 * c], b[2 * c + 1], sp, gadget="base2")
+                        for c in range(batch)]
+            else:                                                       # hint on fewer limbs than the operands
+                l_h = rng.randint(1, L - 1)
+                l_out = rng.randint(1, l_h)
+                rin, rh, rout = A.Ring(2 * n, qs), A.Ring(2 * n, qs[L - l_h:]), A.Ring(2 * n, qs[L - l_out:])
+                D = rh.gadget_digits(capi.ALCH_GAD_BASE2)
+                hint, a, b = rnd(2 * D, qs[L - l_h:]), rnd(2 * batch, qs), rnd(2 * batch, qs)
+                out = rout.alloc(2 * batch)
+                capi.ct_mul_full(rh.hint_load(hint, gadget=capi.ALCH_GAD_BASE2), rin.upload(a), rin.upload(b), out, batch, s_pre=s_pre)
+                got = out.download()
+                want = [oracle_full_mul_base2_down(cref, n, qs, l_h, l_out, list(hint), a[2 * c], a[2 * c + 1], b[2 * c], b[2 * c + 1], s_pre)
+                        for c in range(batch)]
+            for c in range(batch):
+                if not (np.array_equal(got[2 * c], want[c][0]) and np.array_equal(got[2 * c + 1], want[c][1])):
+                    print("MISMATCH", key, dict(qs=qs, batch=batch, opts=opts, ct=c, seed=seed)); return 1
+            cases += 1
+            tally[key] = tally.get(key, 0) + 1
+            continue
         if not full:
             g, o = A.Ring(2 * n, qs), cref.Ring(n, qs)
             for k, v in opts.items(): g.set_option(k, v)
