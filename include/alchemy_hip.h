@@ -323,6 +323,9 @@ int alch_ct_mul_full(const alch_hint *hint, const alch_buf *a, const alch_buf *b
  * alch_ct_tunnel: out[b] = (f'(c0), 0) + sum_i switch(hint_i, embed(coeffsPow(c1)_i)) for linear ciphertexts with k = 0
  * (elements (2b, 2b+1)); s_pre = toMSD's per-limb scalar (NULL = 1).  CRT basis in and out unless ALCH_POW_IN /
  * ALCH_POW_OUT.  Runs on ring_s's stream; the input is not modified.
+ * k > 0 (a ciphertext that has been multiplied): SymmSHE's `tunnel` runs absorbGFactors first -- every component times the element
+ * reduce(liftPow(g^-k in R'_p)), a public multiplication (alch_buf_mul_public) that leaves k = 0 -- and then this call; the host mirror
+ * (alchemy_amd/host/symmshe_gen.hpp, `tunnel`) and tests/test_gpu_tunnel.py do exactly that.
  * `in` may also belong to a ring holding only the LAST limbs of ring_r (same index): PT2CT emits
  * modSwitch_ .: tunnel_ hint .: modSwitch_ (PT2CT.hs:224-229) and the leading modSwitch up, x -> (0, q_a x), is then part of
  * this call -- the added limbs are zero, so their transforms, digits and hint products are skipped (same results as
