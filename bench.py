@@ -189,8 +189,28 @@ def q30_line(B):
             rec = assert_checksum(f"moduli below 2^30 (q30 = {q30})", out.checksum(), ref["checksum"], {"batch": B})
             check = rec if q30 else check
         del a, b, out, hs, hint, ring
+    # PT2CT's whole mul_ (4 -> 5 -> 3 limbs) on the same moduli: the UP instantiation of the Harvey key-switch kernel
+    full, fref = None, golden_checksums().get("q30", {}).get("full_mul")
+    if fref is not None:
+        from alchemy_amd import capi
+        qs_h, Bf = fref["moduli_hint"], fref["batch"]
+        rh, rin, rout = Ring(2 * n, qs_h), Ring(2 * n, qs_h[1:]), Ring(2 * n, qs_h[2:])
+        apply_opts(rh, rin, rout)
+        a, b, fout, hs = rin.alloc(2 * Bf), rin.alloc(2 * Bf), rout.alloc(2 * Bf), rh.alloc(2 * rh.L)
+        a.fill_uniform(2026); b.fill_uniform(900_000_007); hs.fill_uniform(0xA1C4E5)
+        hint_h = rh.hint_from_buf(hs)
+        capi.ct_mul_full(hint_h, a, b, fout, Bf)
+        rh.sync()
+        rh.timer_start()
+        for _ in range(3):
+            capi.ct_mul_full(hint_h, a, b, fout, Bf)
+        fops = 3 * Bf / (rh.timer_stop() * 1e-3)
+        full = {"ops_per_s": fops, "limbs": fref["limbs"], "batch": Bf,
+                "batch_checksum": assert_checksum("mul_ on moduli below 2^30", fout.checksum(), fref["checksum"], {"batch": Bf})}
+        del a, b, fout, hs, hint_h, rh, rin, rout
     algo = 6 * len(qs) * n * 8
-    return {"workload": "BASELINE config 3's op and shape (n=2^15, 4 limbs, TrivGad, CRT in/out) on moduli below 2^30: Harvey butterflies",
+    return {"full_mul": full,
+            "workload": "BASELINE config 3's op and shape (n=2^15, 4 limbs, TrivGad, CRT in/out) on moduli below 2^30: Harvey butterflies",
             "moduli": qs, "batch": B, "ops_per_s": rates[1], "general_kernels_ops_per_s": rates[0], "batch_checksum": check,
             "algorithmic_bytes_per_op": algo, "frac_of_hbm_peak": rates[1] * algo / 1e9 / HBM_PEAK_GBS,
             "frac_at_device_word": rates[1] * algo / 2 / 1e9 / HBM_PEAK_GBS}

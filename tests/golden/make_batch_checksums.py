@@ -81,9 +81,9 @@ SIX_QS_17 = [2147352577, 2146959361, 2146041857, 2144468993, 2142502913, 2135818
 Q30_QS = [1073479681, 1071513601, 1070727169, 1068236801]          # the four largest primes < 2^30 that are 1 mod 2^17
 
 
-def full_range(first, count):
-    qs_h = [FULL_EXTRA_Q] + CFG3_QS
-    o_in, o_h = cref.Ring(N, CFG3_QS), cref.Ring(N, qs_h)
+def full_range(first, count, qs_h=None):
+    qs_h = qs_h or [FULL_EXTRA_Q] + CFG3_QS
+    o_in, o_h = cref.Ring(N, qs_h[1:]), cref.Ring(N, qs_h)
     hint = [o_h.fill_uniform(SEED_H, i) for i in range(2 * len(qs_h))]
     s = 0
     for ct in range(first, first + count):
@@ -179,7 +179,10 @@ if __name__ == "__main__":
         B_TEST, B_BENCH = 2 * 1024 + 37, 8192
         head = run_ranges(lambda f, c: relin_range(f, c, Q30_QS), B_TEST)
         tail = run_ranges(lambda f, c: relin_range(B_TEST + f, c, Q30_QS), B_BENCH - B_TEST)
+        Q30_FULL = [1065484289] + Q30_QS                               # the hint's extra limb: the next prime of the same family
+        fullq = run_ranges(lambda f, c: full_range(f, c, Q30_FULL), 2048)
         out["q30"] = {"what": "the headline op (same seeds, n = 2^15, 4 limbs) on moduli below 2^30: the Harvey-butterfly kernels",
+                      "full_mul": {"batch": 2048, "limbs": "4 -> 5 -> 3", "moduli_hint": Q30_FULL, "checksum": f"{fullq:016x}"},
                       "moduli": Q30_QS, "first_2": f"{relin_range(0, 2, Q30_QS):016x}",
                       "test_mul_relin": {"batch": B_TEST, "checksum": f"{head:016x}"},
                       "bench_mul_relin": {"batch": B_BENCH, "checksum": f"{(head + tail) & MASK:016x}"}}
