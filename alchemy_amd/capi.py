@@ -16,6 +16,9 @@ ALCH_POW_IN, ALCH_POW_OUT = 1, 2
 ALCH_GAD_TRIV, ALCH_GAD_BASE2 = 0, 1
 ALCH_NOT_DIVISIBLE = 1
 ALCH_BASIS_POW, ALCH_BASIS_DEC, ALCH_BASIS_CRT = 0, 1, 2
+# ops of alch_buf_tensor_op (the unary Tensor methods on device-resident elements)
+(ALCH_T_CRT, ALCH_T_CRTINV, ALCH_T_L, ALCH_T_LINV, ALCH_T_MULG_POW, ALCH_T_MULG_DEC, ALCH_T_MULG_CRT, ALCH_T_DIVG_POW,
+ ALCH_T_DIVG_DEC, ALCH_T_DIVG_CRT) = range(10)
 
 # every symbol include/alchemy_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
@@ -32,6 +35,7 @@ SYMBOLS = [
     "alch_tunnel_info", "alch_tunnel_create", "alch_tunnel_free", "alch_ct_tunnel", "alch_ct_mod_switch",
     "alch_buf_embed", "alch_buf_twace", "alch_buf_coeffs", "alch_embed_pow", "alch_embed_dec", "alch_embed_crt",
     "alch_twace_pow_dec", "alch_twace_crt", "alch_coeffs", "alch_ext_table", "alch_crt_set_dec", "alch_ct_add_public",
+    "alch_ring_share_stream", "alch_buf_copy", "alch_buf_tensor_op", "alch_buf_view",
 ]
 
 
@@ -105,6 +109,10 @@ def load_library():
         "alch_host_root": [C.c_uint32, C.c_uint64, PU64, PU64],
         "alch_ring_n": [VP, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "alch_ring_set_stream": [VP, VP],
+        "alch_ring_share_stream": [VP, VP],
+        "alch_buf_copy": [VP, C.c_size_t, VP, C.c_size_t, C.c_size_t],
+        "alch_buf_tensor_op": [VP, C.c_size_t, VP, C.c_size_t, C.c_size_t, C.c_int],
+        "alch_buf_view": [VP, C.c_size_t, C.c_size_t, C.POINTER(VP)],
         "alch_sync": [VP],
         "alch_ring_set_option": [VP, C.c_char_p, C.c_long],
         "alch_timer_start": [VP],
@@ -238,6 +246,10 @@ class Ring:
     # --- stream / timing
     def set_stream(self, hip_stream: int):
         _check(self._l.alch_ring_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def share_stream(self, other: "Ring"):
+        """Queue this ring's work on `other`'s stream from now on (operations between the two rings then need no events)."""
+        _check(self._l.alch_ring_share_stream(self._h, other._h))
 
     def sync(self):
         _check(self._l.alch_sync(self._h))
@@ -433,6 +445,21 @@ class Buf:
 
     def fill_uniform(self, seed: int):
         _check(self.ring._l.alch_buf_fill_uniform(self._h, C.c_uint64(seed)))
+
+    def copy_from(self, src: "Buf", count: int, dst_first: int = 0, src_first: int = 0):
+        _check(self.ring._l.alch_buf_copy(self._h, dst_first, src._h, src_first, count))
+
+    def tensor_op(self, src: "Buf", op: int, count: int = 1, dst_first: int = 0, src_first: int = 0) -> bool:
+        """self[dst_first + i] = op(src[src_first + i]) (ALCH_T_*); False = Lol's Nothing (divG family)."""
+        return _check(self.ring._l.alch_buf_tensor_op(self._h, dst_first, src._h, src_first, count, op)) == ALCH_OK
+
+    def view(self, first: int, count: int = 1) -> "Buf":
+        """Non-owning alias of elements [first, first + count); keeps this buffer alive."""
+        h = C.c_void_p()
+        _check(self.ring._l.alch_buf_view(self._h, first, count, C.byref(h)))
+        v = Buf.__new__(Buf)
+        v.ring, v.n_elems, v._h, v._parent = self.ring, int(count), h, self
+        return v
 
     def device_ptr(self):
         """(address, bytes) of the device allocation."""

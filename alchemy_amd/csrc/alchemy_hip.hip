@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -79,12 +80,29 @@ struct alch_ring {
     void* gen_tables = nullptr;
     int* d_flag = nullptr;                     // divG failure flag
     std::deque<std::pair<u32, ExtTab>> ext;    // extension tables towards sub-rings of index .first (same moduli)
+    // Free list of small device buffers: alch_buf_alloc / alch_buf_free of single ring elements are the allocation pattern of a
+    // device-resident Tensor value (one buffer per `GT` value), and hipMalloc / hipFree cost 50-200 us and synchronise the device.
+    // Reuse is stream-ordered: every consumer of a buffer on another ring's stream makes the owner's stream wait for it (ext_order,
+    // alch_ct_mod_switch, alch_ct_tunnel, alch_ct_mul_full), so work queued later on the owner's stream may overwrite it.
+    std::vector<std::pair<size_t, void*>> pool;                 // (n_elems, device pointer)
+    size_t pool_bytes = 0;
+    std::mutex pool_mu;                                         // alch_buf_free may come from a finalizer thread (Haskell ForeignPtr)
+    // Pinned host staging of small transfers (alch_buf_upload / alch_buf_download of a few ring elements): no pageable-memory copy
+    // inside the HIP runtime, no synchronisation on upload, exactly one on download.
+    struct Pin { void* p = nullptr; size_t bytes = 0; hipEvent_t ev = nullptr; bool busy = false; };
+    Pin pin[4];
+    int pin_next = 0;
 };
+
+static const size_t POOL_MAX_BUF = (size_t)32 << 20;           // buffers up to 32 MiB are recycled
+static const size_t POOL_CAP = (size_t)1 << 30;                // at most 1 GiB parked per ring
+static const size_t PIN_MAX = (size_t)8 << 20;                 // transfers up to 8 MiB of int64 go through pinned staging
 
 struct alch_buf {
     alch_ring* ring;
     size_t n_elems;
     void* dptr;
+    bool view = false;                         // alch_buf_view: a non-owning alias into another buffer
 };
 
 struct alch_tunnel {
@@ -138,7 +156,7 @@ static int fail(int code, const std::string& msg) {
     } while (0)
 
 extern "C" const char* alch_last_error(void) { return g_err.c_str(); }
-extern "C" uint32_t alch_version(void) { return (1u << 16) | 4u; }   // 1.4: general cyclotomic indices, l / lInv, real mulG / divG, mulPublic / addPublic, alch_ring_set_option; 1.3: + alch_decompose_base2, BaseBGad hints, alch_ct_mul_full, alch_buf_device_ptr, n = 2^16
+extern "C" uint32_t alch_version(void) { return (1u << 16) | 5u; }   // 1.5: device-resident Tensor values (alch_buf_tensor_op, alch_buf_copy, alch_ring_share_stream, pooled small buffers, pinned staging), status order of alch_ring_create; 1.4: general cyclotomic indices, l / lInv, real mulG / divG, mulPublic / addPublic, alch_ring_set_option; 1.3: + alch_decompose_base2, BaseBGad hints, alch_ct_mul_full, alch_buf_device_ptr, n = 2^16
 
 // ------------------------------------------------------------------------------------------------------
 // element-wise kernels (HBM-bound; 16 B per lane, grid-stride, ~2048 workgroups)
@@ -861,10 +879,38 @@ static int build_gen_ring(alch_ring* r, DevRing<W>& d, GenDev<W>& g) {
 
 static bool two_power_engine(uint32_t m) { return m >= 32 && (m & (m - 1)) == 0; }
 
+// Status order of alch_ring_create (the order a Lol host needs, haskell/.../GT.hs `ringFor`):
+//   1. malformed arguments                                  -> ALCH_E_INVALID
+//   2. NO CRT BASIS over the base ring -- a modulus that is composite, 2, or a prime that is not 1 mod m: the cases in which Lol's
+//      `crtFuncs` / `crtInfo` answer Nothing for ZqBasic (CRTrans Maybe needs a prime q with m | q - 1; pairs need both) -> ALCH_E_NO_CRT,
+//      whatever the index: it is a property of (m, q), not of this backend; the caller falls back to alch_ring_create_nocrt
+//   3. a CRT basis exists but this backend does not serve the ring (prime factor of m above 13, a limb-polynomial larger than the
+//      LDS, q >= 2^62)                                      -> ALCH_E_UNSUPPORTED: the caller keeps that (m, r) on lol-cpp as a whole
+// ALCH_E_NOT_PRIME is only returned by alch_host_root.
+static int classify_crt_moduli(uint32_t m, int L, const uint64_t* q) {
+    if (!q || L < 1 || L > MAXL) return fail(ALCH_E_INVALID, "alch_ring_create: need 1 <= L <= 8 moduli");
+    if (m < 1) return fail(ALCH_E_INVALID, "cyclotomic index must be >= 1");
+    for (int j = 0; j < L; ++j) {
+        if (q[j] < 2) return fail(ALCH_E_INVALID, "alch_ring_create: moduli must be >= 2 (the integers: alch_ring_create_nocrt with q = 0)");
+        for (int i = 0; i < j; ++i)
+            if (q[i] == q[j]) return fail(ALCH_E_INVALID, "RNS moduli must be distinct");
+    }
+    for (int j = 0; j < L; ++j) {
+        if (q[j] >= (1ull << 62)) continue;                     // classified below as unsupported (primality is not tested up there)
+        if (q[j] < 3 || !h_is_prime(q[j]))
+            return fail(ALCH_E_NO_CRT, "modulus " + std::to_string(q[j]) + " is not an odd prime: no CRT basis over Z_q (Lol: crtFuncs = Nothing)");
+        if ((q[j] - 1) % m) return fail(ALCH_E_NO_CRT, "modulus " + std::to_string(q[j]) + " is not 1 mod m: no CRT basis (Lol: crtFuncs = Nothing)");
+    }
+    for (int j = 0; j < L; ++j)
+        if (q[j] >= (1ull << 62)) return fail(ALCH_E_UNSUPPORTED, "modulus must be below 2^62");
+    return ALCH_OK;
+}
+
 // Argument checks of a general-index ring (or of a ring without CRT basis).  Fills gh; word size out.
 static int validate_gen_args(uint32_t m, int L, const uint64_t* q, bool nocrt, GenHost& gh, int* word_out, bool* zdom_out) {
     if (!q || L < 1 || L > MAXL) return fail(ALCH_E_INVALID, "alch_ring_create: need 1 <= L <= 8 moduli");
     if (m < 1) return fail(ALCH_E_INVALID, "cyclotomic index must be >= 1");
+    if (!nocrt) { const int rc = classify_crt_moduli(m, L, q); if (rc != ALCH_OK) return rc; }
     if (!gen_plan(m, gh)) return fail(ALCH_E_UNSUPPORTED, "cyclotomic index " + std::to_string(m) + ": " + gh.error);
     bool all32 = true, zdom = false;
     for (int j = 0; j < L; ++j) {
@@ -873,12 +919,7 @@ static int validate_gen_args(uint32_t m, int L, const uint64_t* q, bool nocrt, G
             if (q[j] < 2 || q[j] >= (1ull << 31)) return fail(ALCH_E_UNSUPPORTED, "a ring without CRT basis takes moduli 2 <= q < 2^31, or 0 for the integers");
             continue;
         }
-        if (q[j] >= (1ull << 62)) return fail(ALCH_E_UNSUPPORTED, "modulus must be below 2^62");
         if (q[j] >= (1ull << 31)) all32 = false;
-        if (q[j] < 3 || !h_is_prime(q[j])) return fail(ALCH_E_NOT_PRIME, "modulus " + std::to_string(q[j]) + " is not prime");
-        if ((q[j] - 1) % m) return fail(ALCH_E_NO_CRT, "modulus " + std::to_string(q[j]) + " is not 1 mod m: no CRT basis (Lol: crtFuncs = Nothing)");
-        for (int i = 0; i < j; ++i)
-            if (q[i] == q[j]) return fail(ALCH_E_INVALID, "RNS moduli must be distinct");
     }
     if (zdom) for (int j = 0; j < L; ++j) if (q[j] != 0) return fail(ALCH_E_INVALID, "modulus 0 (the integers) cannot be mixed with other moduli");
     const int word = (zdom || !all32) ? 8 : 4;
@@ -889,19 +930,13 @@ static int validate_gen_args(uint32_t m, int L, const uint64_t* q, bool nocrt, G
 }
 
 static int validate_ring_args(uint32_t m, int L, const uint64_t* q, int* logn_out, int* word_out) {
-    if (!q || L < 1 || L > MAXL) return fail(ALCH_E_INVALID, "alch_ring_create: need 1 <= L <= 8 moduli");
     if (!two_power_engine(m)) return fail(ALCH_E_UNSUPPORTED, "internal: not a two-power index >= 32");
+    const int rc = classify_crt_moduli(m, L, q);
+    if (rc != ALCH_OK) return rc;
     int logn = 0;
     while ((1u << logn) < m / 2) ++logn;
     bool all32 = true;
-    for (int j = 0; j < L; ++j) {
-        if (q[j] >= (1ull << 62)) return fail(ALCH_E_UNSUPPORTED, "modulus must be below 2^62");
-        if (q[j] >= (1ull << 31)) all32 = false;
-        if (q[j] < 3 || !h_is_prime(q[j])) return fail(ALCH_E_NOT_PRIME, "modulus " + std::to_string(q[j]) + " is not prime");
-        if ((q[j] - 1) % m) return fail(ALCH_E_NO_CRT, "modulus " + std::to_string(q[j]) + " is not 1 mod m: no CRT basis (Lol: crtFuncs = Nothing)");
-        for (int i = 0; i < j; ++i)
-            if (q[i] == q[j]) return fail(ALCH_E_INVALID, "RNS moduli must be distinct");
-    }
+    for (int j = 0; j < L; ++j) if (q[j] >= (1ull << 31)) all32 = false;
     const int word = all32 ? 4 : 8;
     const int maxlog = all32 ? 16 : 15;        // the top size of each word runs as two LDS-resident halves
     if (logn > maxlog) return fail(ALCH_E_UNSUPPORTED, "ring dimension too large (n <= 2^16 for 32-bit, 2^15 for 64-bit residues)");
@@ -954,7 +989,8 @@ extern "C" int alch_select_limbs(const uint64_t* moduli, int n_moduli, int op, i
 }
 
 extern "C" int alch_host_root(uint32_t m, uint64_t q, uint64_t* psi, uint64_t* generator) {
-    if (m < 1 || q < 3 || !h_is_prime(q)) return fail(ALCH_E_INVALID, "alch_host_root: bad (m, q)");
+    if (m < 1 || q < 2) return fail(ALCH_E_INVALID, "alch_host_root: bad (m, q)");
+    if (q < 3 || !h_is_prime(q)) return fail(ALCH_E_NOT_PRIME, "alch_host_root: q is not an odd prime");
     if ((q - 1) % m) return fail(ALCH_E_NO_CRT, "q is not 1 mod m");
     if (generator) *generator = h_smallest_generator(q);
     if (psi) *psi = h_root(q, m);
@@ -1020,6 +1056,9 @@ extern "C" int alch_ring_destroy(alch_ring* r) {
     (void)hipSetDevice(r->device);
     if (r->scratch) { alch_buf* b = r->scratch; r->scratch = nullptr; (void)hipFree(b->dptr); delete b; }
     if (r->stream) (void)hipStreamSynchronize(r->stream);
+    for (auto& e : r->pool) (void)hipFree(e.second);
+    r->pool.clear();
+    for (auto& pn : r->pin) { if (pn.p) (void)hipHostFree(pn.p); if (pn.ev) (void)hipEventDestroy(pn.ev); pn = alch_ring::Pin(); }
     if (r->tables) (void)hipFree(r->tables);
     if (r->gen_tables) (void)hipFree(r->gen_tables);
     if (r->d_flag) (void)hipFree(r->d_flag);
@@ -1125,6 +1164,7 @@ extern "C" int alch_timer_stop(alch_ring* r, float* ms) {
 // ------------------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------------------
+static inline bool split_ring_fwd(const alch_ring* r) { return !r->gen && r->logn > (r->word == 4 ? 15 : 14); }   // == split_ring()
 static inline size_t elem_words(const alch_ring* r) { return (size_t)r->L * r->n; }
 static inline size_t elem_bytes(const alch_ring* r) { return elem_words(r) * (size_t)r->word; }
 
@@ -1213,17 +1253,60 @@ extern "C" int alch_buf_alloc(alch_ring* r, size_t n_elems, alch_buf** out) {
     if (!r || !out || n_elems == 0) return fail(ALCH_E_INVALID, "alch_buf_alloc: bad argument");
     if (n_elems > (size_t)-1 / elem_bytes(r)) return fail(ALCH_E_INVALID, "alch_buf_alloc: n_elems * element size overflows size_t");
     BIND(r);
+    const size_t bytes = n_elems * elem_bytes(r);
+    if (bytes <= POOL_MAX_BUF) {
+        std::lock_guard<std::mutex> lk(r->pool_mu);
+        for (size_t i = r->pool.size(); i-- > 0;)
+            if (r->pool[i].first == n_elems) {                     // stream-ordered reuse (see alch_ring::pool)
+                void* p = r->pool[i].second;
+                r->pool[i] = r->pool.back();
+                r->pool.pop_back();
+                r->pool_bytes -= bytes;
+                *out = new alch_buf{r, n_elems, p};
+                return ALCH_OK;
+            }
+    }
     void* p = nullptr;
-    if (hipMalloc(&p, n_elems * elem_bytes(r)) != hipSuccess)
-        return fail(ALCH_E_NOMEM, "hipMalloc of " + std::to_string(n_elems * elem_bytes(r)) + " bytes failed");
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        // parked buffers may be what exhausts the device: release them and try once more
+        std::vector<std::pair<size_t, void*>> parked;
+        { std::lock_guard<std::mutex> lk(r->pool_mu); parked.swap(r->pool); r->pool_bytes = 0; }
+        if (!parked.empty()) {
+            (void)hipStreamSynchronize(r->stream);
+            for (auto& e : parked) (void)hipFree(e.second);
+            if (hipMalloc(&p, bytes) != hipSuccess) p = nullptr;
+        }
+        if (!p) return fail(ALCH_E_NOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed");
+    }
     *out = new alch_buf{r, n_elems, p};
+    return ALCH_OK;
+}
+
+extern "C" int alch_buf_view(const alch_buf* parent, size_t first, size_t count, alch_buf** out) {
+    if (!parent || !out || count == 0) return fail(ALCH_E_INVALID, "alch_buf_view: bad argument");
+    if (first + count > parent->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
+    alch_buf* v = new alch_buf{parent->ring, count, reinterpret_cast<char*>(parent->dptr) + first * elem_bytes(parent->ring)};
+    v->view = true;
+    *out = v;
     return ALCH_OK;
 }
 
 extern "C" int alch_buf_free(alch_buf* b) {
     if (!b) return ALCH_OK;
-    (void)hipSetDevice(b->ring->device);
-    (void)hipStreamSynchronize(b->ring->stream);
+    if (b->view) { delete b; return ALCH_OK; }                      // an alias owns nothing
+    alch_ring* r = b->ring;
+    const size_t bytes = b->n_elems * elem_bytes(r);
+    if (bytes <= POOL_MAX_BUF) {
+        std::lock_guard<std::mutex> lk(r->pool_mu);
+        if (r->pool_bytes + bytes <= POOL_CAP) {
+            r->pool.emplace_back(b->n_elems, b->dptr);             // no synchronisation: reuse is ordered on the ring's stream
+            r->pool_bytes += bytes;
+            delete b;
+            return ALCH_OK;
+        }
+    }
+    (void)hipSetDevice(r->device);
+    (void)hipStreamSynchronize(r->stream);
     (void)hipFree(b->dptr);
     delete b;
     return ALCH_OK;
@@ -1249,6 +1332,35 @@ static int do_transfer(alch_ring* r, void* dev, size_t count, int64_t* host, boo
     if (rc != ALCH_OK) return rc;
     int64_t* stage = reinterpret_cast<int64_t*>(r->ws_host);
     const size_t total = count * elem_words(r);
+    if (bytes <= PIN_MAX) {
+        // small transfer (the per-Tensor-call path moves one ring element at a time): through a pinned slot
+        alch_ring::Pin& pn = r->pin[r->pin_next];
+        r->pin_next = (r->pin_next + 1) % 4;
+        if (pn.busy) { HIP_TRY(hipEventSynchronize(pn.ev)); pn.busy = false; }     // the slot's last upload has left it (long ago, normally)
+        if (pn.bytes < bytes) {
+            if (pn.p) { (void)hipHostFree(pn.p); pn.p = nullptr; pn.bytes = 0; }
+            if (hipHostMalloc(&pn.p, bytes, hipHostMallocDefault) != hipSuccess) return fail(ALCH_E_NOMEM, "hipHostMalloc(" + std::to_string(bytes) + ") failed");
+            pn.bytes = bytes;
+        }
+        if (!pn.ev) HIP_TRY(hipEventCreateWithFlags(&pn.ev, hipEventDisableTiming));
+        if (to_device) {
+            memcpy(pn.p, host, bytes);                             // the caller's buffer is consumed here: no synchronisation needed
+            HIP_TRY(hipMemcpyAsync(stage, pn.p, bytes, hipMemcpyHostToDevice, r->stream));
+            hipLaunchKernelGGL((k_transpose<W, true>), dim3(ew_grid(total)), dim3(256), 0, r->stream, dev_ring<W>(r),
+                               reinterpret_cast<W*>(dev), stage, count);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(pn.ev, r->stream));
+            pn.busy = true;
+        } else {
+            hipLaunchKernelGGL((k_transpose<W, false>), dim3(ew_grid(total)), dim3(256), 0, r->stream, dev_ring<W>(r),
+                               reinterpret_cast<W*>(dev), stage, count);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(pn.p, stage, bytes, hipMemcpyDeviceToHost, r->stream));
+            HIP_TRY(hipStreamSynchronize(r->stream));              // the one synchronisation of a download
+            memcpy(host, pn.p, bytes);
+        }
+        return ALCH_OK;
+    }
     if (to_device) {
         HIP_TRY(hipMemcpyAsync(stage, host, bytes, hipMemcpyHostToDevice, r->stream));
         hipLaunchKernelGGL((k_transpose<W, true>), dim3(ew_grid(total)), dim3(256), 0, r->stream, dev_ring<W>(r),
@@ -1632,9 +1744,12 @@ extern "C" int alch_ct_add_public(alch_buf* dst, const alch_buf* src, size_t bat
 // ------------------------------------------------------------------------------------------------------
 // Runs one column operator (kernel_gen.hpp) on elements first, first + stride, ... (count of them) of `data`.
 template <typename W>
-static int do_columns(alch_ring* r, GenOp op, void* data, size_t first, size_t count, size_t stride, hipStream_t stream = nullptr) {
+static int do_columns(alch_ring* r, GenOp op, void* data, size_t first, size_t count, size_t stride, hipStream_t stream = nullptr,
+                      const void* src = nullptr) {
+    // src != null: out of place, src[e] -> data[e] (same element layout and stride)
     if (count == 0) return ALCH_OK;
     GenCall<W> g{};
+    g.src = reinterpret_cast<const W*>(src);
     g.op = op;
     g.ring = &dev_ring<W>(r);
     g.gen = &gen_dev<W>(r);
@@ -1654,8 +1769,10 @@ static int do_columns(alch_ring* r, GenOp op, void* data, size_t first, size_t c
     return ALCH_OK;
 }
 
-static int columns(alch_ring* r, GenOp op, void* data, size_t first, size_t count, size_t stride, hipStream_t stream = nullptr) {
-    return r->word == 4 ? do_columns<u32>(r, op, data, first, count, stride, stream) : do_columns<u64>(r, op, data, first, count, stride, stream);
+static int columns(alch_ring* r, GenOp op, void* data, size_t first, size_t count, size_t stride, hipStream_t stream = nullptr,
+                   const void* src = nullptr) {
+    return r->word == 4 ? do_columns<u32>(r, op, data, first, count, stride, stream, src)
+                        : do_columns<u64>(r, op, data, first, count, stride, stream, src);
 }
 
 // mulG (divide = false) or divG on elements [first, first + count) of a buffer, basis ALCH_BASIS_*.
@@ -1706,6 +1823,94 @@ static int buf_l(alch_buf* b, size_t first, size_t count, bool inverse) {
 }
 extern "C" int alch_buf_l(alch_buf* b, size_t first, size_t count) { return buf_l(b, first, count, false); }
 extern "C" int alch_buf_linv(alch_buf* b, size_t first, size_t count) { return buf_l(b, first, count, true); }
+
+// ------------------------------------------------------------------------------------------------------
+// device-resident Tensor values: what a `GT m r` holds when it stays on the GPU between Tensor calls
+// ------------------------------------------------------------------------------------------------------
+// E issues one Lol call per op (Crypto/Alchemy/Interpreter/Eval.hs:120-134) and Lol one Tensor call per basis change, so a
+// ciphertext operation reaches this library as a chain of single-element calls.  With the host-buffer entry points every link
+// of that chain crosses PCIe twice; with these the element stays in HBM and a link costs one kernel launch.
+extern "C" int alch_ring_share_stream(alch_ring* r, alch_ring* with) {
+    if (!r || !with) return fail(ALCH_E_INVALID, "null ring");
+    if (r->device != with->device) return fail(ALCH_E_INVALID, "alch_ring_share_stream: the rings live on different devices");
+    if (r == with || r->stream == with->stream) return ALCH_OK;
+    BIND(r);
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
+    r->stream = with->stream;
+    r->own_stream = false;
+    return ALCH_OK;
+}
+
+extern "C" int alch_buf_copy(alch_buf* dst, size_t dst_first, const alch_buf* src, size_t src_first, size_t count) {
+    if (!dst || !src) return fail(ALCH_E_INVALID, "null buffer");
+    if (dst->ring != src->ring) return fail(ALCH_E_INVALID, "buffers belong to different rings");
+    if (dst_first + count > dst->n_elems || src_first + count > src->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
+    if (count == 0) return ALCH_OK;
+    alch_ring* r = dst->ring;
+    BIND(r);
+    char* d = reinterpret_cast<char*>(dst->dptr) + dst_first * elem_bytes(r);
+    const char* f = reinterpret_cast<const char*>(src->dptr) + src_first * elem_bytes(r);
+    if (d == f) return ALCH_OK;
+    if ((d < f ? f - d : d - f) < (ptrdiff_t)(count * elem_bytes(r))) return fail(ALCH_E_INVALID, "alch_buf_copy: overlapping ranges");
+    HIP_TRY(hipMemcpyAsync(d, f, count * elem_bytes(r), hipMemcpyDeviceToDevice, r->stream));
+    return ALCH_OK;
+}
+
+// dst[dst_first + i] = op(src[src_first + i]), i < count.  Transforms and column operators read `src` and write `dst` in one
+// kernel; the CRT-basis g products copy first.  dst and src may be the same range (in place).
+extern "C" int alch_buf_tensor_op(alch_buf* dst, size_t dst_first, const alch_buf* src, size_t src_first, size_t count, int op) {
+    if (!dst || !src) return fail(ALCH_E_INVALID, "null buffer");
+    if (dst->ring != src->ring) return fail(ALCH_E_INVALID, "buffers belong to different rings");
+    if (dst_first + count > dst->n_elems || src_first + count > src->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
+    if (op < ALCH_T_CRT || op > ALCH_T_DIVG_CRT) return fail(ALCH_E_INVALID, "alch_buf_tensor_op: unknown op");
+    alch_ring* r = dst->ring;
+    BIND(r);
+    const bool needs_crt = op == ALCH_T_CRT || op == ALCH_T_CRTINV || op == ALCH_T_MULG_CRT || op == ALCH_T_DIVG_CRT;
+    if (needs_crt && !r->has_crt) return fail(ALCH_E_NO_CRT, "this ring has no CRT basis (created with alch_ring_create_nocrt)");
+    if (count == 0) return ALCH_OK;
+    char* d = reinterpret_cast<char*>(dst->dptr) + dst_first * elem_bytes(r);
+    const char* f = reinterpret_cast<const char*>(src->dptr) + src_first * elem_bytes(r);
+    const bool in_place = d == f;
+    if (!in_place && (d < f ? f - d : d - f) < (ptrdiff_t)(count * elem_bytes(r))) return fail(ALCH_E_INVALID, "alch_buf_tensor_op: overlapping ranges");
+    auto copy_first = [&]() -> int {
+        if (!in_place) HIP_TRY(hipMemcpyAsync(d, f, count * elem_bytes(r), hipMemcpyDeviceToDevice, r->stream));
+        return ALCH_OK;
+    };
+    int rc;
+    if (op == ALCH_T_CRT || op == ALCH_T_CRTINV) {
+        const bool inv = op == ALCH_T_CRTINV;
+        if (in_place || split_ring_fwd(r)) {                       // the split transforms (n = 2^16 / 64-bit 2^15) work in place only
+            if ((rc = copy_first()) != ALCH_OK) return rc;
+            return r->word == 4 ? do_crt<u32>(r, d, 0, count, inv) : do_crt<u64>(r, d, 0, count, inv);
+        }
+        return r->word == 4 ? do_crt<u32>(r, d, 0, count, inv, f) : do_crt<u64>(r, d, 0, count, inv, f);
+    }
+    const bool trivial = !r->gen || r->gh.rad == 1;                   // two-power index: g = 1, L = identity
+    if (trivial) return copy_first();
+    if (op == ALCH_T_MULG_CRT || op == ALCH_T_DIVG_CRT) {
+        if ((rc = copy_first()) != ALCH_OK) return rc;
+        alch_buf view{r, count, d};
+        return buf_mulg_divg(&view, 0, count, ALCH_BASIS_CRT, op == ALCH_T_DIVG_CRT);
+    }
+    GenOp g = GEN_L;
+    bool divide = false;
+    switch (op) {
+    case ALCH_T_L: g = GEN_L; break;
+    case ALCH_T_LINV: g = GEN_LINV; break;
+    case ALCH_T_MULG_POW: g = GEN_MULG_POW; break;
+    case ALCH_T_MULG_DEC: g = GEN_MULG_DEC; break;
+    case ALCH_T_DIVG_POW: g = GEN_DIVG_POW; divide = true; break;
+    default: g = GEN_DIVG_DEC; divide = true; break;
+    }
+    if (divide) HIP_TRY(hipMemsetAsync(r->d_flag, 0, sizeof(int), r->stream));
+    rc = columns(r, g, d, 0, count, 1, nullptr, in_place ? nullptr : f);
+    if (rc != ALCH_OK || !divide) return rc;
+    int flag = 0;                                                     // Lol's Maybe: the answer is needed now
+    HIP_TRY(hipMemcpyAsync(&flag, r->d_flag, sizeof(int), hipMemcpyDeviceToHost, r->stream));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return flag ? ALCH_NOT_DIVISIBLE : ALCH_OK;
+}
 
 extern "C" int alch_buf_mul_public(alch_buf* dst, const alch_buf* src, const alch_buf* pub, size_t pub_index, size_t count) {
     if (!dst || !src || !pub) return fail(ALCH_E_INVALID, "null buffer");
@@ -1945,6 +2150,9 @@ static int do_mul_relin(alch_ring* r, const alch_hint* hint, const void* a, cons
             if (!r->ev_pa[e]) HIP_TRY(hipEventCreateWithFlags(&r->ev_pa[e], hipEventDisableTiming));
             if (!r->ev_pb[e]) HIP_TRY(hipEventCreateWithFlags(&r->ev_pb[e], hipEventDisableTiming));
         }
+        // the tensor kernels run on the aux stream whatever `nstreams` says: order it behind everything queued on the ring's stream
+        // (the producers of a and b, and the previous call's key-switch kernels, which still read the digit scratch)
+        if (ns < 2) HIP_TRY(hipStreamWaitEvent(r->aux, r->ev_fork, 0));
         for (size_t done = 0; done < batch; done += chunk, ++idx) {
             const size_t now = std::min(chunk, batch - done);
             const int par = (int)(idx & 1);

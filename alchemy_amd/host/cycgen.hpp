@@ -15,7 +15,19 @@
 //                      examples/Common.hs:65-75;  evalLin
 //
 // Everything numeric on ring elements goes through the C ABI; this file sequences calls, keeps bases and does the scalar /
-// sampling work a Lol host does in Haskell.  Setup-time code: clarity over speed (every call stages one element through the GPU).
+// sampling work a Lol host does in Haskell.
+//
+// Three execution modes of the per-element layer (alchemy::gen::mode()), mirroring the representations of `GT` in
+// haskell/Crypto/Lol/Cyclotomic/Tensor/GT.hs:
+//   HostBuffers       a ring element is a host vector; every Tensor call stages it through the GPU (GT's constructor GTHost with
+//                     the host-buffer entry points alch_crt, alch_mul, ...: two PCIe crossings and two synchronisations per call)
+//   Resident          a ring element lives in HBM (GTDev: one pooled alch_buf element); a Tensor call is one asynchronous kernel
+//                     launch (alch_buf_tensor_op, alch_buf_embed / twace / coeffs, alch_buf_mul / add / sub / scale,
+//                     alch_buf_decompose_triv); the host sees data only when it asks (data(), lifts) -- what a Lol whose Cyc
+//                     routes its pointwise ring operations to GT's mulGT / addGT / subGT gets
+//   ResidentZipHost   the same, but pointwise operations run on the HOST as Lol's unchanged UCyc issues them (zipWithT / fmapT
+//                     with an opaque Haskell function: GT downloads, lol-cpp computes; here plain C++ stands in for lol-cpp),
+//                     so every product costs two downloads and its result a later upload
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -96,21 +108,55 @@ public:
     const Ring& get(uint32_t m, const std::vector<uint64_t>& qs, bool crt = true) {
         auto key = std::make_tuple(m, qs, crt);
         auto it = rings_.find(key);
-        if (it == rings_.end()) it = rings_.emplace(key, std::unique_ptr<Ring>(new Ring(m, qs, crt))).first;
+        if (it == rings_.end()) {
+            it = rings_.emplace(key, std::unique_ptr<Ring>(new Ring(m, qs, crt))).first;
+            // one Tensor call at a time: all rings queue on one stream, so calls between two rings need no events
+            if (!first_) first_ = it->second.get();
+            else check(alch_ring_share_stream(it->second->handle(), first_->handle()), "alch_ring_share_stream");
+        }
         return *it->second;
     }
 
 private:
     std::map<std::tuple<uint32_t, std::vector<uint64_t>, bool>, std::unique_ptr<Ring>> rings_;
+    const Ring* first_ = nullptr;
 };
 
 enum class Basis { Pow, Dec, CRT };
 
+enum class Mode { HostBuffers, Resident, ResidentZipHost };
+inline Mode& mode() { static Mode m = Mode::HostBuffers; return m; }
+inline bool resident() { return mode() != Mode::HostBuffers; }
+
+// One ring element (or a run of them) resident in HBM.  Buffers come from the library's per-ring free list; a view aliases part of
+// a bigger buffer (the d_rel results of coeffs, the L digits of decompose) and keeps it alive.
+struct DevElem {
+    alch_buf* b = nullptr;
+    std::shared_ptr<DevElem> parent;
+    DevElem() {}
+    DevElem(const DevElem&) = delete;
+    DevElem& operator=(const DevElem&) = delete;
+    ~DevElem() { if (b) alch_buf_free(b); }
+    static std::shared_ptr<DevElem> make(alch_ring* r, size_t elems = 1) {
+        auto d = std::make_shared<DevElem>();
+        check(alch_buf_alloc(r, elems, &d->b), "alch_buf_alloc");
+        return d;
+    }
+    static std::shared_ptr<DevElem> view(const std::shared_ptr<DevElem>& p, size_t first) {
+        auto d = std::make_shared<DevElem>();
+        check(alch_buf_view(p->b, first, 1, &d->b), "alch_buf_view");
+        d->parent = p;
+        return d;
+    }
+};
+
 // ---- ring element ------------------------------------------------------------------------------------------------
+// Immutable value semantics like Lol's UCyc: every operation returns a new element.  An element has a host copy (Lol's
+// tuple-interleaved int64 vector), a device copy (one alch_buf element), or both; each is produced from the other on demand.
 class Cyc {
 public:
     Cyc() : r_(nullptr), basis_(Basis::Pow) {}
-    Cyc(const Ring& r, Basis b) : r_(&r), basis_(b), v_(r.words(), 0) {}
+    Cyc(const Ring& r, Basis b) : r_(&r), basis_(b), hp_(std::make_shared<std::vector<int64_t>>(r.words(), 0)) {}
     // `reduce` of an integer vector given on basis b (Pow or Dec)
     static Cyc fromIntegers(const Ring& r, const std::vector<int64_t>& z, Basis b = Basis::Pow) {
         if (z.size() != r.n()) throw std::runtime_error("fromIntegers: wrong dimension");
@@ -119,7 +165,7 @@ public:
             for (int j = 0; j < r.L(); ++j) {
                 const int64_t q = (int64_t)r.qs()[j];
                 int64_t v = q ? z[k] % q : z[k];
-                c.v_[(size_t)k * r.L() + j] = (q && v < 0) ? v + q : v;
+                (*c.hp_)[(size_t)k * r.L() + j] = (q && v < 0) ? v + q : v;
             }
         return c;
     }
@@ -128,31 +174,62 @@ public:
         z[0] = s;
         return fromIntegers(r, z, Basis::Pow);
     }
+    // an element that exists on the device only (the result of a Tensor call in the resident modes)
+    static Cyc onDevice(const Ring& r, Basis b, std::shared_ptr<DevElem> d) {
+        Cyc c;
+        c.r_ = &r; c.basis_ = b; c.d_ = std::move(d);
+        return c;
+    }
     const Ring& ring() const { return *r_; }
     Basis basis() const { return basis_; }
-    std::vector<int64_t>& data() { return v_; }
-    const std::vector<int64_t>& data() const { return v_; }
-    int64_t at(uint32_t k, int j) const { return v_[(size_t)k * r_->L() + j]; }
+    bool onDeviceOnly() const { return !hp_; }
+    // host copy: downloaded on first use (pinned staging, one synchronisation)
+    const std::vector<int64_t>& data() const {
+        if (!hp_) {
+            hp_ = std::make_shared<std::vector<int64_t>>(r_->words(), 0);
+            check(alch_buf_download(d_->b, 0, 1, hp_->data()), "alch_buf_download");
+        }
+        return *hp_;
+    }
+    // writable host copy: private to this value, and the device copy (shared with other values) is dropped
+    std::vector<int64_t>& data() {
+        (void)static_cast<const Cyc*>(this)->data();
+        if (hp_.use_count() > 1) hp_ = std::make_shared<std::vector<int64_t>>(*hp_);
+        d_.reset();
+        return *hp_;
+    }
+    // device copy: uploaded on first use (no synchronisation)
+    alch_buf* dev() const {
+        if (!d_) {
+            d_ = DevElem::make(r_->handle());
+            check(alch_buf_upload(d_->b, 0, 1, hp_->data()), "alch_buf_upload");
+        }
+        return d_->b;
+    }
+    int64_t at(uint32_t k, int j) const { return data()[(size_t)k * r_->L() + j]; }
 
     Cyc toPow() const {
         if (basis_ == Basis::Pow) return *this;
-        Cyc o = *this;
-        if (basis_ == Basis::CRT) check(alch_crtinv(r_->handle(), o.v_.data()), "alch_crtinv");
-        else check(alch_l(r_->handle(), o.v_.data()), "alch_l");
+        if (resident()) return unary(basis_ == Basis::CRT ? ALCH_T_CRTINV : ALCH_T_L, Basis::Pow);
+        Cyc o = hostCopy();
+        if (basis_ == Basis::CRT) check(alch_crtinv(r_->handle(), o.hp_->data()), "alch_crtinv");
+        else check(alch_l(r_->handle(), o.hp_->data()), "alch_l");
         o.basis_ = Basis::Pow;
         return o;
     }
     Cyc toDec() const {
         if (basis_ == Basis::Dec) return *this;
         Cyc o = toPow();
-        check(alch_linv(r_->handle(), o.v_.data()), "alch_linv");
+        if (resident()) return o.unary(ALCH_T_LINV, Basis::Dec);
+        check(alch_linv(r_->handle(), o.hp_->data()), "alch_linv");
         o.basis_ = Basis::Dec;
         return o;
     }
     Cyc toCRT() const {
         if (basis_ == Basis::CRT) return *this;
         Cyc o = toPow();
-        check(alch_crt(r_->handle(), o.v_.data()), "alch_crt");
+        if (resident()) return o.unary(ALCH_T_CRT, Basis::CRT);
+        check(alch_crt(r_->handle(), o.hp_->data()), "alch_crt");
         o.basis_ = Basis::CRT;
         return o;
     }
@@ -160,50 +237,93 @@ public:
 
     friend Cyc operator*(const Cyc& a, const Cyc& b) {            // ring product: both to the CRT basis, zipWithT (*)
         Cyc x = a.toCRT(), y = b.toCRT();
-        check(alch_mul(x.r_->handle(), x.v_.data(), y.v_.data()), "alch_mul");
+        if (mode() == Mode::Resident) return x.binary(y, 0);
+        if (mode() == Mode::ResidentZipHost) return x.zipHost(y, 0);
+        x = x.hostCopy();
+        check(alch_mul(x.r_->handle(), x.hp_->data(), y.data().data()), "alch_mul");
         return x;
     }
     friend Cyc operator+(const Cyc& a, const Cyc& b) {
         Cyc x = a, y = b.to(a.basis_);
-        check(alch_add(x.r_->handle(), x.v_.data(), y.v_.data()), "alch_add");
+        if (mode() == Mode::Resident) return x.binary(y, 1);
+        if (mode() == Mode::ResidentZipHost) return x.zipHost(y, 1);
+        x = x.hostCopy();
+        check(alch_add(x.r_->handle(), x.hp_->data(), y.data().data()), "alch_add");
         return x;
     }
     friend Cyc operator-(const Cyc& a, const Cyc& b) {
         Cyc x = a, y = b.to(a.basis_);
-        check(alch_sub(x.r_->handle(), x.v_.data(), y.v_.data()), "alch_sub");
+        if (mode() == Mode::Resident) return x.binary(y, 2);
+        if (mode() == Mode::ResidentZipHost) return x.zipHost(y, 2);
+        x = x.hostCopy();
+        check(alch_sub(x.r_->handle(), x.hp_->data(), y.data().data()), "alch_sub");
         return x;
     }
     Cyc scale(const std::vector<uint64_t>& s) const {             // per-limb scalar (any basis)
-        Cyc o = *this;
-        check(alch_scale(r_->handle(), o.v_.data(), s.data()), "alch_scale");
+        if (mode() == Mode::Resident && r_->hasCRT()) {
+            auto d = DevElem::make(r_->handle());
+            check(alch_buf_scale(d->b, dev(), 1, s.data()), "alch_buf_scale");
+            return onDevice(*r_, basis_, d);
+        }
+        if (mode() == Mode::ResidentZipHost) {                      // Lol: fmapT (* s) with an opaque function -> host
+            Cyc o = hostCopy();
+            for (uint32_t k = 0; k < r_->n(); ++k)
+                for (int j = 0; j < r_->L(); ++j) {
+                    int64_t& w = (*o.hp_)[(size_t)k * r_->L() + j];
+                    w = (int64_t)mulmod((uint64_t)w, s[j] % r_->qs()[j], r_->qs()[j]);
+                }
+            return o;
+        }
+        Cyc o = hostCopy();
+        check(alch_scale(r_->handle(), o.hp_->data(), s.data()), "alch_scale");
         return o;
     }
     Cyc mulG() const {
-        Cyc o = *this;
-        check(basis_ == Basis::Pow ? alch_mulg_pow(r_->handle(), o.v_.data())
-              : basis_ == Basis::Dec ? alch_mulg_dec(r_->handle(), o.v_.data()) : alch_mulg_crt(r_->handle(), o.v_.data()), "alch_mulg");
+        if (resident()) return unary(basis_ == Basis::Pow ? ALCH_T_MULG_POW : basis_ == Basis::Dec ? ALCH_T_MULG_DEC : ALCH_T_MULG_CRT, basis_);
+        Cyc o = hostCopy();
+        check(basis_ == Basis::Pow ? alch_mulg_pow(r_->handle(), o.hp_->data())
+              : basis_ == Basis::Dec ? alch_mulg_dec(r_->handle(), o.hp_->data()) : alch_mulg_crt(r_->handle(), o.hp_->data()), "alch_mulg");
         return o;
     }
     // Lol's divG: false = Nothing
     bool divG(Cyc& out) const {
-        out = *this;
-        int rc = basis_ == Basis::Pow ? alch_divg_pow(r_->handle(), out.v_.data())
-                 : basis_ == Basis::Dec ? alch_divg_dec(r_->handle(), out.v_.data()) : alch_divg_crt(r_->handle(), out.v_.data());
+        if (resident()) {
+            auto d = DevElem::make(r_->handle());
+            const int op = basis_ == Basis::Pow ? ALCH_T_DIVG_POW : basis_ == Basis::Dec ? ALCH_T_DIVG_DEC : ALCH_T_DIVG_CRT;
+            const int rc = alch_buf_tensor_op(d->b, 0, dev(), 0, 1, op);
+            check(rc, "alch_buf_tensor_op (divG)");
+            out = onDevice(*r_, basis_, d);
+            return rc != ALCH_NOT_DIVISIBLE;
+        }
+        out = hostCopy();
+        int rc = basis_ == Basis::Pow ? alch_divg_pow(r_->handle(), out.hp_->data())
+                 : basis_ == Basis::Dec ? alch_divg_dec(r_->handle(), out.hp_->data()) : alch_divg_crt(r_->handle(), out.hp_->data());
         check(rc, "alch_divg");
         return rc != ALCH_NOT_DIVISIBLE;
     }
     // embed into a ring of a multiple index with the same moduli (Cyc embed: stays on this element's basis)
     Cyc embed(const Ring& big) const {
+        const int bs = basis_ == Basis::Pow ? ALCH_BASIS_POW : basis_ == Basis::Dec ? ALCH_BASIS_DEC : ALCH_BASIS_CRT;
+        if (resident()) {
+            auto d = DevElem::make(big.handle());
+            check(alch_buf_embed(d->b, dev(), 1, bs), "alch_buf_embed");
+            return onDevice(big, basis_, d);
+        }
         Cyc o(big, basis_);
         auto f = basis_ == Basis::Pow ? alch_embed_pow : basis_ == Basis::Dec ? alch_embed_dec : alch_embed_crt;
-        check(f(r_->handle(), big.handle(), v_.data(), o.v_.data()), "alch_embed");
+        check(f(r_->handle(), big.handle(), data().data(), o.hp_->data()), "alch_embed");
         return o;
     }
     // tweaked trace to a ring of a divisor index (Cyc twace)
     Cyc twace(const Ring& small) const {
+        if (resident()) {
+            auto d = DevElem::make(small.handle());
+            check(alch_buf_twace(d->b, dev(), 1, basis_ == Basis::CRT ? ALCH_BASIS_CRT : ALCH_BASIS_POW), "alch_buf_twace");
+            return onDevice(small, basis_, d);
+        }
         Cyc o(small, basis_);
         auto f = basis_ == Basis::CRT ? alch_twace_crt : alch_twace_pow_dec;
-        check(f(small.handle(), r_->handle(), v_.data(), o.v_.data()), "alch_twace");
+        check(f(small.handle(), r_->handle(), data().data(), o.hp_->data()), "alch_twace");
         return o;
     }
     // Cyc coeffsPow / coeffsDec: the d_rel coefficient vectors over the subring w.r.t. the relative powerful / decoding basis
@@ -211,12 +331,18 @@ public:
         Cyc src = to(b);
         if (b == Basis::CRT) throw std::runtime_error("coeffs: Pow or Dec");
         const uint32_t d = r_->n() / small.n();
-        std::vector<int64_t> all((size_t)d * small.words());
-        check(alch_coeffs(small.handle(), r_->handle(), src.v_.data(), all.data()), "alch_coeffs");
         std::vector<Cyc> out;
+        if (resident()) {
+            auto all = DevElem::make(small.handle(), d);
+            check(alch_buf_coeffs(all->b, src.dev(), 1), "alch_buf_coeffs");
+            for (uint32_t i = 0; i < d; ++i) out.push_back(onDevice(small, b, DevElem::view(all, i)));
+            return out;
+        }
+        std::vector<int64_t> all((size_t)d * small.words());
+        check(alch_coeffs(small.handle(), r_->handle(), src.data().data(), all.data()), "alch_coeffs");
         for (uint32_t i = 0; i < d; ++i) {
             Cyc c(small, b);
-            std::copy(all.begin() + (size_t)i * small.words(), all.begin() + (size_t)(i + 1) * small.words(), c.v_.begin());
+            std::copy(all.begin() + (size_t)i * small.words(), all.begin() + (size_t)(i + 1) * small.words(), c.hp_->begin());
             out.push_back(std::move(c));
         }
         return out;
@@ -224,12 +350,35 @@ public:
     // Lol `decompose` (TrivGad) then `reduce <$>` (Pow basis)
     std::vector<Cyc> decomposeTrivReduced() const {
         Cyc p = toPow();
-        std::vector<int64_t> all((size_t)r_->L() * r_->words());
-        check(alch_decompose_triv(r_->handle(), p.v_.data(), all.data()), "alch_decompose_triv");
         std::vector<Cyc> out;
+        if (mode() == Mode::Resident) {
+            auto all = DevElem::make(r_->handle(), (size_t)r_->L());
+            check(alch_buf_decompose_triv(p.dev(), 0, all->b, 0), "alch_buf_decompose_triv");
+            for (int i = 0; i < r_->L(); ++i) out.push_back(onDevice(*r_, Basis::Pow, DevElem::view(all, (size_t)i)));
+            return out;
+        }
+        if (mode() == Mode::ResidentZipHost) {                      // Lol: fmapT lift / reduce per coefficient -> host
+            const std::vector<int64_t>& v = p.data();
+            for (int i = 0; i < r_->L(); ++i) {
+                Cyc dgt(*r_, Basis::Pow);
+                const int64_t qi = (int64_t)r_->qs()[i];
+                for (uint32_t k = 0; k < r_->n(); ++k) {
+                    const int64_t c = centred(v[(size_t)k * r_->L() + i], qi);
+                    for (int j = 0; j < r_->L(); ++j) {
+                        const int64_t qj = (int64_t)r_->qs()[j];
+                        int64_t w = c % qj;
+                        (*dgt.hp_)[(size_t)k * r_->L() + j] = w < 0 ? w + qj : w;
+                    }
+                }
+                out.push_back(std::move(dgt));
+            }
+            return out;
+        }
+        std::vector<int64_t> all((size_t)r_->L() * r_->words());
+        check(alch_decompose_triv(r_->handle(), p.data().data(), all.data()), "alch_decompose_triv");
         for (int i = 0; i < r_->L(); ++i) {
             Cyc d(*r_, Basis::Pow);
-            std::copy(all.begin() + (size_t)i * r_->words(), all.begin() + (size_t)(i + 1) * r_->words(), d.v_.begin());
+            std::copy(all.begin() + (size_t)i * r_->words(), all.begin() + (size_t)(i + 1) * r_->words(), d.hp_->begin());
             out.push_back(std::move(d));
         }
         return out;
@@ -301,9 +450,43 @@ public:
     }
 
 private:
+    // a value whose host vector may be modified in place (HostBuffers mode: the host-buffer entry points work in place)
+    Cyc hostCopy() const {
+        Cyc o;
+        o.r_ = r_; o.basis_ = basis_; o.hp_ = std::make_shared<std::vector<int64_t>>(data());
+        return o;
+    }
+    Cyc unary(int op, Basis nb) const {
+        auto d = DevElem::make(r_->handle());
+        check(alch_buf_tensor_op(d->b, 0, dev(), 0, 1, op), "alch_buf_tensor_op");
+        return onDevice(*r_, nb, d);
+    }
+    Cyc binary(const Cyc& y, int op) const {                        // 0 mul, 1 add, 2 sub on the device
+        auto d = DevElem::make(r_->handle());
+        check((op == 0 ? alch_buf_mul : op == 1 ? alch_buf_add : alch_buf_sub)(d->b, dev(), y.dev(), 1), "alch_buf_mul/add/sub");
+        return onDevice(*r_, basis_, d);
+    }
+    // zipWithT f a b with an opaque f: both operands come to the host and lol-cpp computes (plain C++ stands in for it here)
+    Cyc zipHost(const Cyc& y, int op) const {
+        Cyc o = hostCopy();
+        const std::vector<int64_t>& w = y.data();
+        const int L = r_->L();
+        for (uint32_t k = 0; k < r_->n(); ++k)
+            for (int j = 0; j < L; ++j) {
+                const uint64_t q = r_->qs()[j];
+                int64_t& x = (*o.hp_)[(size_t)k * L + j];
+                const int64_t z = w[(size_t)k * L + j];
+                if (op == 0) x = q ? (int64_t)mulmod((uint64_t)x, (uint64_t)z, q) : x * z;
+                else if (op == 1) { x += z; if (q && (uint64_t)x >= q) x -= (int64_t)q; }
+                else { x -= z; if (q && x < 0) x += (int64_t)q; }
+            }
+        return o;
+    }
+
     const Ring* r_;
     Basis basis_;
-    std::vector<int64_t> v_;
+    mutable std::shared_ptr<std::vector<int64_t>> hp_;      // host copy, shared between copies of the value (copy on write); null = none
+    mutable std::shared_ptr<DevElem> d_;                    // device copy; null = none
 };
 
 // ---- the tweaked Gaussian on the decoding basis (Lol Tensor tGaussianDec; SymmSHE genSK / errorRounded / errorCoset) ----

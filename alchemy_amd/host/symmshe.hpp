@@ -18,6 +18,8 @@
 //
 // Everything numeric goes through the C ABI (device kernels); this file only sequences calls and keeps the
 // (enc, k, l) metadata.  Errors surface as std::runtime_error carrying alch_last_error().
+// REPLAY AND TEST CODE, NOT A KEY GENERATOR: keys, errors and hints are drawn from a caller-supplied std::mt19937_64 with `rng() % q`
+// for uniform residues (reproducible, not a CSPRNG, modulo-biased); a production host keeps Lol's sampling.
 #pragma once
 #include <cmath>
 #include <cstdint>

@@ -7,6 +7,10 @@
 //   toLSD / toMSD, (*), addPublic, mulPublic, modSwitchPT, modSwitch, keySwitchQuadCirc, tunnel   (Eval.hs:65-67,129-134)
 //   ksQuadCircHint, tunnelHint               (KeysHints.hs:101-129)
 //
+// REPLAY AND TEST CODE, NOT A KEY GENERATOR: randomness comes from a caller-supplied std::mt19937_64 (reproducible runs) and uniform
+// residues are drawn as `rng() % q` -- not a CSPRNG, with the 2^-33 modulo bias of a 31-bit q in a 64-bit draw.  A production host
+// keeps Lol's own sampling (`getRandom`, Crypto/Alchemy/Interpreter/KeysHints.hs:86-129) and only the ring arithmetic comes here.
+//
 // Two forms of every ciphertext operation: the per-element form on host `CT` values (one Tensor call per step, as `eval` over
 // `Tensor GT` would issue them), and -- for the ops PT2CT emits in bulk -- the batched device entry points on `DevBatch`
 // (alch_ct_tunnel, alch_ct_mul_full, alch_ct_mod_switch, alch_buf_*), which carry the same (enc, k, l, p) metadata on the host.
@@ -329,7 +333,11 @@ struct DevBatch {
 
     void upload(size_t b, const CT& ct) {
         if (ct.c.size() != 2) throw std::runtime_error("DevBatch: linear ciphertexts");
-        for (int c = 0; c < 2; ++c) check(alch_buf_upload(buf, 2 * b + c, 1, ct.c[c].to(basis).data().data()), "alch_buf_upload");
+        for (int c = 0; c < 2; ++c) {
+            const Cyc x = ct.c[c].to(basis);
+            if (x.onDeviceOnly()) check(alch_buf_copy(buf, 2 * b + c, x.dev(), 0, 1), "alch_buf_copy");      // already in HBM
+            else check(alch_buf_upload(buf, 2 * b + c, 1, x.data().data()), "alch_buf_upload");
+        }
     }
     CT download(size_t b) const {
         CT ct{enc, k, l, p, m, {Cyc(*ring, basis), Cyc(*ring, basis)}};
@@ -475,9 +483,18 @@ inline DevBatch tunnelBatch(const DevTunnel& tun, DevBatch& x, const Ring& rout,
 inline CT modSwitch(const CT& ct_, const Ring& dst) {
     const CT ct = toMSD(ct_);
     if (&ct.c[0].ring() == &dst) return ct;
+    if (mode() == Mode::Resident) {
+        // the two components side by side in one pooled buffer, the result handed on as two aliases: nothing leaves HBM
+        auto in = DevElem::make(ct.c[0].ring().handle(), 2), out = DevElem::make(dst.handle(), 2);
+        for (int c = 0; c < 2; ++c) check(alch_buf_copy(in->b, (size_t)c, ct.c[c].toCRT().dev(), 0, 1), "alch_buf_copy");
+        check(alch_ct_mod_switch(in->b, out->b, 1, 0), "alch_ct_mod_switch");
+        return CT{Encoding::MSD, ct.k, ct.l, ct.p, ct.m,
+                  {Cyc::onDevice(dst, Basis::CRT, DevElem::view(out, 0)), Cyc::onDevice(dst, Basis::CRT, DevElem::view(out, 1))}};
+    }
+    // HostBuffers, and ResidentZipHost (Lol's rescale is fmapT-class work: the components cross to the host and back)
     DevBatch in(ct.c[0].ring(), 1), out(dst, 1);
     in.basis = Basis::CRT;
-    in.upload(0, ct);
+    for (int c = 0; c < 2; ++c) check(alch_buf_upload(in.buf, (size_t)c, 1, ct.c[c].toCRT().data().data()), "alch_buf_upload");
     check(alch_ct_mod_switch(in.buf, out.buf, 1, 0), "alch_ct_mod_switch");
     out.enc = Encoding::MSD; out.k = ct.k; out.l = ct.l; out.p = ct.p; out.m = ct.m; out.basis = Basis::CRT;
     return out.download(0);

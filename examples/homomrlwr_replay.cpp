@@ -12,10 +12,19 @@
 // stage ciphertext 0 is decrypted with the stage's key and compared with the plaintext computation, and its error rate
 // max |c(s)| / q -- what the ERW interpreter logs (Crypto/Alchemy/Interpreter/ErrorRateWriter.hs:70-75, Eval.hs:151-160) -- is printed.
 //
-//   homomrlwr_replay [batch] [--seed N] [--dump DIR] [--per-element]
+//   homomrlwr_replay [batch] [--seed N] [--dump DIR] [--per-element] [--per-element-resident] [--per-element-zip-host]
+//                    [--host-mode buffers|resident] [--var-scale F] [--quiet-stages]
 // --dump writes the final ciphertexts, the H5' key and the expected plaintexts for an independent decryption by the oracle
-// (tests/test_gpu_homomrlwr_full.py); --per-element also runs the first hop through the per-Tensor-call path and compares.
+// (tests/test_gpu_homomrlwr_full.py).  The --per-element* flags also run the first hop (modSwitch . tunnel hint . modSwitch) through
+// the per-Tensor-call path -- what `eval` over `instance Tensor GT` issues, one C-ABI call per Tensor method -- in the three
+// representations of a ring element (alchemy_amd/host/cycgen.hpp): host buffers staged through the GPU per call, device-resident
+// elements, device-resident with the pointwise operations on the host (unchanged Lol's zipWithT), and compare each with the batched
+// result bit for bit.  --host-mode picks the representation the setup (keys, hints), the plaintext side and the decryptions use
+// (default resident).  --var-scale multiplies the Gaussian parameter r = 5.0 of examples/HomomRLWR.hs:56 (svar = r / sqrt(phi(m'))):
+// the noise-margin experiment of DESIGN.md section 5.
+#include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,13 +55,22 @@ int main(int argc, char** argv) {
     size_t B = 4;
     uint64_t seed = 2026;
     std::string dump;
-    bool per_element = false;
+    bool per_element = false, per_resident = false, per_ziphost = false, quiet = false;
+    double var_scale = 1.0;
+    Mode host_mode = Mode::Resident;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--seed") && i + 1 < argc) seed = strtoull(argv[++i], nullptr, 10);
         else if (!strcmp(argv[i], "--dump") && i + 1 < argc) dump = argv[++i];
         else if (!strcmp(argv[i], "--per-element")) per_element = true;
+        else if (!strcmp(argv[i], "--per-element-resident")) per_resident = true;
+        else if (!strcmp(argv[i], "--per-element-zip-host")) per_ziphost = true;
+        else if (!strcmp(argv[i], "--quiet-stages")) quiet = true;
+        else if (!strcmp(argv[i], "--var-scale") && i + 1 < argc) var_scale = atof(argv[++i]);
+        else if (!strcmp(argv[i], "--host-mode") && i + 1 < argc) host_mode = !strcmp(argv[++i], "buffers") ? Mode::HostBuffers : Mode::Resident;
         else B = (size_t)atoi(argv[i]);
     }
+    const double R_GAUSS = 5.0 * var_scale;                       // examples/HomomRLWR.hs:56
+    mode() = host_mode;
     try {
         std::mt19937_64 rng(seed);
         RingCache rc;
@@ -71,7 +89,7 @@ int main(int argc, char** argv) {
         // ---- "Generating function": keys, linear functions, hints (examples/HomomRLWR.hs:52-59,64)
         double t0 = now();
         std::vector<SK> sk;
-        for (int k = 0; k < 6; ++k) sk.push_back(genSK(rc, HP[k], 5.0, rng));
+        for (int k = 0; k < 6; ++k) sk.push_back(genSK(rc, HP[k], R_GAUSS, rng));
         std::vector<Linear> lin;
         for (int k = 0; k < 5; ++k) lin.push_back(decToCRT(ops, H[k], H[k + 1], 2, K_EXP));
         std::vector<DevTunnel> dtun;
@@ -128,7 +146,7 @@ int main(int argc, char** argv) {
             double er = 0;
             bool ok = decrypt(rc, ops, sk[key], ct, got, &er);
             bool match = ok && want && got.v == ops.to(*want, Basis::Pow).v && got.p == want->p;
-            printf("  %-26s q has %d limbs, p = %2lld, k = %2d   error rate %.3e   decrypts to the plaintext stage: %s\n", what, x.ring->L(),
+            if (!quiet || (want && !match)) printf("  %-26s q has %d limbs, p = %2lld, k = %2d   error rate %.3e   decrypts to the plaintext stage: %s\n", what, x.ring->L(),
                    (long long)x.p, x.k, er, want ? (match ? "yes" : "NO") : "-");
             return !want || match;
         };
@@ -149,22 +167,42 @@ int main(int argc, char** argv) {
         }
         stages_ok &= rate("mulPublic a (H0')", cur, 0, &stage_pt[0][0]);
         CT first_in;
-        if (per_element) first_in = cur.download(0);
+        if (per_element || per_resident || per_ziphost) first_in = cur.download(0);
         for (int k = 0; k < 5; ++k) {
             DevBatch nxt = tunnelBatch(dtun[k], cur, rc.get(HP[k + 1], moduli(tuns[k].lout)), H[k + 1]);
-            if (per_element && k == 0) {
+            if ((per_element || per_resident || per_ziphost) && k == 0) {
                 // the same hop through the per-Tensor-call path (what `eval` over `instance Tensor GT` issues: one C-ABI call per
                 // Tensor method): modSwitch up, tunnel, modSwitch down on ciphertext 0 -- must equal the batched result bit for bit
-                const double tp = now();
-                const std::vector<uint64_t> qh = moduli(tuns[0].lh);
-                CT pe = modSwitch(tunnel(rc, thints[0], modSwitch(first_in, rc.get(HP[0], qh)), H[1]), rc.get(HP[1], moduli(tuns[0].lout)));
-                const double secs = now() - tp;
                 check(alch_sync(nxt.ring->handle()), "alch_sync");
                 const CT dev = nxt.download(0);
-                const bool same = pe.c[0].toCRT().data() == dev.c[0].data() && pe.c[1].toCRT().data() == dev.c[1].data() && pe.l == dev.l;
-                printf("  per-Tensor-call path of switch1 on one ciphertext: %.3f s (%.1f tunnels/s); equal to the batched result: %s\n", secs,
-                       1.0 / secs, same ? "yes" : "NO");
-                stages_ok &= same;
+                const std::vector<uint64_t> qh = moduli(tuns[0].lh);
+                struct Run { const char* name; Mode m; bool on; int reps; };
+                const Run runs[3] = {{"host buffers (GTHost + host-buffer entry points)", Mode::HostBuffers, per_element, 2},
+                                     {"device-resident elements (GTDev)", Mode::Resident, per_resident, 40},
+                                     {"device-resident, pointwise ops on the host (unchanged Lol's zipWithT)", Mode::ResidentZipHost, per_ziphost, 4}};
+                const Mode saved = mode();
+                for (const Run& run : runs) {
+                    if (!run.on) continue;
+                    mode() = run.m;
+                    // operands as a host would hold them in this representation; hint elements likewise (converted once, untimed)
+                    CT in0 = first_in;
+                    if (run.m != Mode::HostBuffers) { for (Cyc& x : in0.c) (void)x.dev(); for (auto& h : thints[0].ks) for (auto& pr : h.h) { (void)pr.first.dev(); (void)pr.second.dev(); } for (auto& y : thints[0].lin) (void)y.dev(); }
+                    CT pe;
+                    double best = 1e30, total = 0;
+                    for (int rep = 0; rep < run.reps; ++rep) {
+                        const double tp = now();
+                        pe = modSwitch(tunnel(rc, thints[0], modSwitch(in0, rc.get(HP[0], qh)), H[1]), rc.get(HP[1], moduli(tuns[0].lout)));
+                        check(alch_sync(pe.c[0].ring().handle()), "alch_sync");        // the hop has run, not just been queued
+                        const double secs = now() - tp;
+                        if (rep) { best = std::min(best, secs); total += secs; }
+                    }
+                    const double mean = total / (run.reps - 1);
+                    const bool same = pe.c[0].toCRT().data() == dev.c[0].data() && pe.c[1].toCRT().data() == dev.c[1].data() && pe.l == dev.l;
+                    printf("  per-Tensor-call path of switch1, %s: %.3f ms per hop (%.1f tunnels/s; best %.3f ms); equal to the batched result: %s\n",
+                           run.name, mean * 1e3, 1.0 / mean, best * 1e3, same ? "yes" : "NO");
+                    stages_ok &= same;
+                }
+                mode() = saved;
             }
             cur = std::move(nxt);
             char name[64];
@@ -217,15 +255,22 @@ int main(int argc, char** argv) {
         // ---- decrypt and compare (examples/HomomRLWR.hs:70-71)
         size_t good = 0;
         double worst = 0, mean = 0;
+        std::vector<double> rates;
         for (size_t b = 0; b < B; ++b) {
             PtCyc got;
             double er = 0;
             if (decrypt(rc, ops, sk[5], res.download(b), got, &er) && got.p == expect[b].p && got.v == ops.to(expect[b], Basis::Pow).v) ++good;
             worst = std::max(worst, er);
             mean += er / (double)B;
+            rates.push_back(er);
         }
+        std::sort(rates.begin(), rates.end());
+        const double p999 = rates[std::min(rates.size() - 1, (size_t)std::ceil(0.999 * (double)rates.size()) - 1)];
+        const double med = rates[rates.size() / 2];
         printf("decrypted results equal to the plaintext results: %zu of %zu   (final error rate: mean %.3f, worst %.3f; decryption needs < 0.5)\n",
                good, B, mean, worst);
+        printf("STATS batch %zu var_scale %.3f equal %zu mean %.4f median %.4f p99.9 %.4f max %.4f over_half %zu\n", B, var_scale, good, mean, med, p999, worst,
+               (size_t)(rates.end() - std::lower_bound(rates.begin(), rates.end(), 0.5)));
         if (!dump.empty()) {
             std::vector<int64_t> meta = {(int64_t)B, (int64_t)res.ring->n(), (int64_t)res.ring->L(), res.enc == Encoding::MSD ? 1 : 0, res.k, res.l, res.p,
                                          (int64_t)res.ring->qs()[0]};

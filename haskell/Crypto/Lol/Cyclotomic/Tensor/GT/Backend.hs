@@ -36,6 +36,7 @@ foreign import ccall unsafe "alch_modulus_units"       c_modulusUnits    :: Word
 foreign import ccall unsafe "alch_host_root"           c_hostRoot        :: Word32 -> Word64 -> Ptr Word64 -> Ptr Word64 -> IO CInt
 foreign import ccall unsafe "alch_ring_n"              c_ringN           :: Ptr AlchRing -> Ptr Word32 -> Ptr CInt -> Ptr CInt -> IO CInt
 foreign import ccall unsafe "alch_ring_set_stream"     c_ringSetStream   :: Ptr AlchRing -> Ptr () -> IO CInt
+foreign import ccall safe   "alch_ring_share_stream"   c_ringShareStream :: Ptr AlchRing -> Ptr AlchRing -> IO CInt
 foreign import ccall unsafe "alch_ring_set_option"     c_ringSetOption   :: Ptr AlchRing -> CString -> CLong -> IO CInt
 foreign import ccall safe   "alch_sync"                c_sync            :: Ptr AlchRing -> IO CInt
 foreign import ccall unsafe "alch_timer_start"         c_timerStart      :: Ptr AlchRing -> IO CInt
@@ -77,6 +78,11 @@ foreign import ccall safe   "alch_decompose_base2"     c_decomposeBase2  :: Ptr 
 -- device-resident batches
 foreign import ccall safe   "alch_buf_alloc"           c_bufAlloc        :: Ptr AlchRing -> CSize -> Ptr (Ptr AlchBuf) -> IO CInt
 foreign import ccall safe   "alch_buf_free"            c_bufFree         :: Ptr AlchBuf -> IO CInt
+-- device-resident Tensor values (GT's constructor GTDev): pooled single-element buffers, aliases, copies, the unary Tensor methods
+-- out of place.  The launches return at once (asynchronous on the ring's stream): `unsafe` imports, a few microseconds each.
+foreign import ccall unsafe "alch_buf_view"            c_bufView         :: Ptr AlchBuf -> CSize -> CSize -> Ptr (Ptr AlchBuf) -> IO CInt
+foreign import ccall unsafe "alch_buf_copy"            c_bufCopy         :: Ptr AlchBuf -> CSize -> Ptr AlchBuf -> CSize -> CSize -> IO CInt
+foreign import ccall safe   "alch_buf_tensor_op"       c_bufTensorOp     :: Ptr AlchBuf -> CSize -> Ptr AlchBuf -> CSize -> CSize -> CInt -> IO CInt
 foreign import ccall unsafe "alch_buf_elems"           c_bufElems        :: Ptr AlchBuf -> Ptr CSize -> IO CInt
 foreign import ccall unsafe "alch_buf_device_ptr"      c_bufDevicePtr    :: Ptr AlchBuf -> Ptr (Ptr ()) -> Ptr CSize -> IO CInt
 foreign import ccall safe   "alch_buf_upload"          c_bufUpload       :: Ptr AlchBuf -> CSize -> CSize -> Ptr Int64 -> IO CInt

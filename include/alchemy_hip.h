@@ -49,9 +49,10 @@ extern "C" {
 
 #define ALCH_OK 0
 #define ALCH_E_INVALID (-1)        /* bad argument (null, size, basis) */
-#define ALCH_E_NOT_PRIME (-2)      /* a modulus is not prime */
-#define ALCH_E_NO_CRT (-3)         /* q != 1 mod m: Lol's crtFuncs returns Nothing */
-#define ALCH_E_UNSUPPORTED (-4)    /* index with a prime factor > 13, ring too large for LDS, q too large */
+#define ALCH_E_NOT_PRIME (-2)      /* alch_host_root only: q is not an odd prime */
+#define ALCH_E_NO_CRT (-3)         /* no CRT basis over Z_q: q composite, q = 2, or q != 1 mod m -- Lol's crtFuncs returns Nothing */
+#define ALCH_E_UNSUPPORTED (-4)    /* a CRT basis exists but this backend does not serve the ring: index with a prime factor > 13,
+                                      limb-polynomial larger than the LDS, q >= 2^62 */
 #define ALCH_E_NO_DEVICE (-5)      /* no gfx950 device / HIP runtime error at init */
 #define ALCH_E_HIP (-6)            /* HIP runtime error (message in alch_last_error) */
 #define ALCH_E_NOMEM (-7)
@@ -82,8 +83,18 @@ uint32_t alch_version(void);
 /* ---- ring context ------------------------------------------------------------------------------
  * Replaces the per-call twiddle/modulus arguments lol-cpp receives from Haskell; built once per
  * (index, modulus-list) type, i.e. once per `Cyc t m' zq` instance (PT2CT.hs:251-254).
- * m = cyclotomic index (2n).  Validates q prime and q == 1 mod m (else ALCH_E_NO_CRT, the CRTrans
- * failure of Lol's crtFuncs), builds device-resident twiddle tables with the root rule above.
+ * m = cyclotomic index (2n).  Builds device-resident twiddle tables with the root rule above.
+ * STATUS ORDER (part of the ABI; haskell/.../GT.hs `ringFor` dispatches on it, tests/test_host_logic.py and
+ * tests/test_gpu_example_rings.py pin it):
+ *   ALCH_E_INVALID      malformed arguments (null, L out of 1..8, a modulus < 2, repeated moduli)
+ *   ALCH_E_NO_CRT       some modulus is composite, 2, or a prime that is not 1 mod m -- exactly the cases in which Lol's
+ *                       `crtFuncs` is Nothing for ZqBasic (CRTrans Maybe needs a prime q with m | q - 1; a pair needs both
+ *                       components).  Decided BEFORE the index is looked at: it is a property of (m, q), not of this backend.
+ *                       The plaintext rings of the reference land here (Z_{2^e}, examples/Common.hs:32; Zq 7 over F4,
+ *                       examples/Arithmetic.hs:23); the caller then creates the ring with alch_ring_create_nocrt.
+ *   ALCH_E_UNSUPPORTED  a CRT basis exists but the backend does not serve (m, q): a Lol host keeps that (index, element type)
+ *                       on lol-cpp as a whole (every basis-order-dependent method).
+ *   ALCH_E_NO_DEVICE / ALCH_E_HIP / ALCH_E_NOMEM   run-time failures, checked last.
  * Two-power m: 32 <= m <= 2^17 (n <= 2^16) when every q < 2^31, m <= 2^16 (n <= 2^15) otherwise.  The largest size
  * of each word runs its transforms as two LDS-resident halves and the key switch unfused; the fused
  * kernels of alch_ct_mul_relin / alch_ct_mul_full cover n <= 2^15 (32-bit) / 2^14 (64-bit); at the largest size both
@@ -178,6 +189,10 @@ int alch_decompose_base2(alch_ring *ring, const int64_t *c_pow, int64_t *digits,
  * transpose (and the 64 -> 32 bit narrowing when the ring uses 32-bit words). */
 int alch_buf_alloc(alch_ring *ring, size_t n_elems, alch_buf **out);
 int alch_buf_free(alch_buf *buf);
+/* A non-owning alias of elements [first, first + count) of `parent` (same ring): lets the d_rel results of `coeffs` or the L digits
+ * of `decompose` be handed on as single-element Tensor values without copies.  alch_buf_free of a view releases only the handle;
+ * the parent must outlive its views (the Haskell side keeps the parent's ForeignPtr alive from the view's finalizer). */
+int alch_buf_view(const alch_buf *parent, size_t first, size_t count, alch_buf **out);
 int alch_buf_elems(const alch_buf *buf, size_t *n_elems);
 /* Device address and size of the buffer (limb-major words, see above) for zero-copy hand-off to other device
  * code on the same GPU -- RCCL collectives that gather result batches, a caller's own kernels.
@@ -219,6 +234,34 @@ int alch_buf_decompose_triv(const alch_buf *src, size_t src_index, alch_buf *dst
 /* 64-bit order-independent checksum of elements [first, first+count): sum over words of
  * splitmix64(position ^ value<<20) -- used by the full-size parity tests. */
 int alch_buf_checksum(const alch_buf *buf, size_t first, size_t count, uint64_t *sum);
+
+/* ---- device-resident Tensor values -------------------------------------------------
+ * E issues one Lol call per op (Crypto/Alchemy/Interpreter/Eval.hs:120-134) and Lol one Tensor call per basis change, so through
+ * `instance Tensor GT` a ciphertext operation arrives as a chain of single-element calls.  A `GT` value may therefore hold an
+ * alch_buf of ONE ring element instead of a host vector (haskell/.../GT.hs: constructor GTDev); these entry points are what its
+ * methods call.  alch_buf_alloc / alch_buf_free of small buffers are served from a per-ring free list (no hipMalloc / hipFree, no
+ * synchronisation; reuse is ordered on the ring's stream), and uploads / downloads of a few elements go through pinned staging
+ * (no synchronisation on upload, one on download).
+ *   alch_ring_share_stream   `ring` queues its work on the stream of `with` from now on: operations between the two rings
+ *                            (embed / twace / coeffs, modSwitch, tunnel) then need no events.  A host that issues one Tensor call
+ *                            at a time shares one stream between all its rings.
+ *   alch_buf_copy            dst[dst_first + i] = src[src_first + i]
+ *   alch_buf_tensor_op       dst[dst_first + i] = op(src[src_first + i]) for the unary Tensor methods, out of place (the ranges
+ *                            may coincide: in place): crt / crtInv read src and write dst in one kernel, l / lInv / mulG / divG on
+ *                            Pow and Dec likewise.  ALCH_T_DIVG_* return ALCH_NOT_DIVISIBLE for Lol's Nothing (dst unspecified). */
+#define ALCH_T_CRT 0
+#define ALCH_T_CRTINV 1
+#define ALCH_T_L 2
+#define ALCH_T_LINV 3
+#define ALCH_T_MULG_POW 4
+#define ALCH_T_MULG_DEC 5
+#define ALCH_T_MULG_CRT 6
+#define ALCH_T_DIVG_POW 7
+#define ALCH_T_DIVG_DEC 8
+#define ALCH_T_DIVG_CRT 9
+int alch_ring_share_stream(alch_ring *ring, alch_ring *with);
+int alch_buf_copy(alch_buf *dst, size_t dst_first, const alch_buf *src, size_t src_first, size_t count);
+int alch_buf_tensor_op(alch_buf *dst, size_t dst_first, const alch_buf *src, size_t src_first, size_t count, int op);
 
 /* ---- Tensor methods between two indices m | m'  ----------------------------------------------------
  * Lol's embedPow / embedDec / twacePowDec / coeffs and crtExtFuncs = (twaceCRT, embedCRT): what Cyc `embed`, `twace` and `coeffsCyc`

@@ -63,7 +63,7 @@ def test_host_root_rejects_bad_arguments():
     assert e.value.code == capi.ALCH_E_NO_CRT
     with pytest.raises(A.AlchemyError) as e:
         capi.host_root(512, 268440579)                # not prime
-    assert e.value.code == capi.ALCH_E_INVALID
+    assert e.value.code == capi.ALCH_E_NOT_PRIME
 
 
 def _no_gpu():
@@ -80,10 +80,21 @@ def test_ring_create_fails_loudly_without_gpu():
 
 
 def test_ring_argument_validation_precedes_device_probe():
-    for args, code in [((512, [268440579]), capi.ALCH_E_NOT_PRIME),          # composite
+    """The status ORDER is part of the ABI (include/alchemy_hip.h, alch_ring_create): malformed -> INVALID; no CRT basis over the
+    base ring (composite q, q = 2, prime q != 1 mod m: Lol's crtFuncs = Nothing) -> NO_CRT whatever the index; only then
+    UNSUPPORTED.  haskell/.../GT.hs `ringFor` maps NO_CRT to the no-CRT ring and UNSUPPORTED to lol-cpp."""
+    for args, code in [((512, [268440579]), capi.ALCH_E_NO_CRT),             # composite: Lol's crtInfo needs a prime
+                       ((11648, [32]), capi.ALCH_E_NO_CRT),                   # Z_{2^5} over H0': the plaintext ring of HomomRLWR
+                       ((128, [2]), capi.ALCH_E_NO_CRT),                      # Z_2 (Z2E 1, examples/Common.hs:32)
+                       ((4, [7]), capi.ALCH_E_NO_CRT),                        # Arithmetic's PT = Cyc F4 (Zq 7): 7 != 1 mod 4
+                       ((4 * 17, [32]), capi.ALCH_E_NO_CRT),                  # no CRT basis beats "unsupported index"
+                       ((4 * 17, [ARITH_QS[1]]), capi.ALCH_E_NO_CRT),         # 8392193 != 1 mod 17
+                       ((512, [ARITH_QS[0], 16]), capi.ALCH_E_NO_CRT),        # one bad limb of a pair is enough (CRTrans of a pair needs both)
+                       ((512, [0]), capi.ALCH_E_INVALID),                     # the integers are alch_ring_create_nocrt's
+                       ((512, [1]), capi.ALCH_E_INVALID),
                        ((1 << 16, [ARITH_QS[1]]), capi.ALCH_E_NO_CRT),        # q != 1 mod m
                        ((48, [ARITH_QS[1]]), capi.ALCH_E_NO_CRT),             # composite index, q != 1 mod 3
-                       ((4 * 17, [ARITH_QS[0]]), capi.ALCH_E_UNSUPPORTED),    # odd prime factor above 13
+                       ((4 * 17, [268435577]), capi.ALCH_E_UNSUPPORTED),         # a CRT basis exists (268435577 = 1 mod 68) but 17 > 13: not served
                        ((3 * 5 * 7 * 11 * 13 * 64, [960961]), capi.ALCH_E_UNSUPPORTED),  # phi = 184320: a limb-polynomial exceeds the LDS
                        ((1 << 17, [CFG3_QS[3]]), capi.ALCH_E_NO_CRT),         # 2145976321 is 1 mod 2^16 only
                        ((1 << 18, [2146959361]), capi.ALCH_E_UNSUPPORTED),    # n = 2^17: beyond the split transform (32-bit words)
