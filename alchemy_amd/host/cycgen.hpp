@@ -211,9 +211,9 @@ public:
     Cyc toPow() const {
         if (basis_ == Basis::Pow) return *this;
         if (resident()) return unary(basis_ == Basis::CRT ? ALCH_T_CRTINV : ALCH_T_L, Basis::Pow);
-        Cyc o = hostCopy();
-        if (basis_ == Basis::CRT) check(alch_crtinv(r_->handle(), o.hp_->data()), "alch_crtinv");
-        else check(alch_l(r_->handle(), o.hp_->data()), "alch_l");
+        Cyc o = *this;                                              // the writable data() below is private to o (copy on write)
+        if (basis_ == Basis::CRT) check(alch_crtinv(r_->handle(), o.data().data()), "alch_crtinv");
+        else check(alch_l(r_->handle(), o.data().data()), "alch_l");
         o.basis_ = Basis::Pow;
         return o;
     }
@@ -221,7 +221,7 @@ public:
         if (basis_ == Basis::Dec) return *this;
         Cyc o = toPow();
         if (resident()) return o.unary(ALCH_T_LINV, Basis::Dec);
-        check(alch_linv(r_->handle(), o.hp_->data()), "alch_linv");
+        check(alch_linv(r_->handle(), o.data().data()), "alch_linv");
         o.basis_ = Basis::Dec;
         return o;
     }
@@ -229,7 +229,7 @@ public:
         if (basis_ == Basis::CRT) return *this;
         Cyc o = toPow();
         if (resident()) return o.unary(ALCH_T_CRT, Basis::CRT);
-        check(alch_crt(r_->handle(), o.hp_->data()), "alch_crt");
+        check(alch_crt(r_->handle(), o.data().data()), "alch_crt");
         o.basis_ = Basis::CRT;
         return o;
     }
@@ -240,7 +240,7 @@ public:
         if (mode() == Mode::Resident) return x.binary(y, 0);
         if (mode() == Mode::ResidentZipHost) return x.zipHost(y, 0);
         x = x.hostCopy();
-        check(alch_mul(x.r_->handle(), x.hp_->data(), y.data().data()), "alch_mul");
+        check(alch_mul(x.r_->handle(), x.data().data(), y.data().data()), "alch_mul");
         return x;
     }
     friend Cyc operator+(const Cyc& a, const Cyc& b) {
@@ -248,7 +248,7 @@ public:
         if (mode() == Mode::Resident) return x.binary(y, 1);
         if (mode() == Mode::ResidentZipHost) return x.zipHost(y, 1);
         x = x.hostCopy();
-        check(alch_add(x.r_->handle(), x.hp_->data(), y.data().data()), "alch_add");
+        check(alch_add(x.r_->handle(), x.data().data(), y.data().data()), "alch_add");
         return x;
     }
     friend Cyc operator-(const Cyc& a, const Cyc& b) {
@@ -256,7 +256,7 @@ public:
         if (mode() == Mode::Resident) return x.binary(y, 2);
         if (mode() == Mode::ResidentZipHost) return x.zipHost(y, 2);
         x = x.hostCopy();
-        check(alch_sub(x.r_->handle(), x.hp_->data(), y.data().data()), "alch_sub");
+        check(alch_sub(x.r_->handle(), x.data().data(), y.data().data()), "alch_sub");
         return x;
     }
     Cyc scale(const std::vector<uint64_t>& s) const {             // per-limb scalar (any basis)
@@ -275,14 +275,14 @@ public:
             return o;
         }
         Cyc o = hostCopy();
-        check(alch_scale(r_->handle(), o.hp_->data(), s.data()), "alch_scale");
+        check(alch_scale(r_->handle(), o.data().data(), s.data()), "alch_scale");
         return o;
     }
     Cyc mulG() const {
         if (resident()) return unary(basis_ == Basis::Pow ? ALCH_T_MULG_POW : basis_ == Basis::Dec ? ALCH_T_MULG_DEC : ALCH_T_MULG_CRT, basis_);
         Cyc o = hostCopy();
-        check(basis_ == Basis::Pow ? alch_mulg_pow(r_->handle(), o.hp_->data())
-              : basis_ == Basis::Dec ? alch_mulg_dec(r_->handle(), o.hp_->data()) : alch_mulg_crt(r_->handle(), o.hp_->data()), "alch_mulg");
+        check(basis_ == Basis::Pow ? alch_mulg_pow(r_->handle(), o.data().data())
+              : basis_ == Basis::Dec ? alch_mulg_dec(r_->handle(), o.data().data()) : alch_mulg_crt(r_->handle(), o.data().data()), "alch_mulg");
         return o;
     }
     // Lol's divG: false = Nothing
@@ -296,8 +296,8 @@ public:
             return rc != ALCH_NOT_DIVISIBLE;
         }
         out = hostCopy();
-        int rc = basis_ == Basis::Pow ? alch_divg_pow(r_->handle(), out.hp_->data())
-                 : basis_ == Basis::Dec ? alch_divg_dec(r_->handle(), out.hp_->data()) : alch_divg_crt(r_->handle(), out.hp_->data());
+        int rc = basis_ == Basis::Pow ? alch_divg_pow(r_->handle(), out.data().data())
+                 : basis_ == Basis::Dec ? alch_divg_dec(r_->handle(), out.data().data()) : alch_divg_crt(r_->handle(), out.data().data());
         check(rc, "alch_divg");
         return rc != ALCH_NOT_DIVISIBLE;
     }
@@ -311,7 +311,7 @@ public:
         }
         Cyc o(big, basis_);
         auto f = basis_ == Basis::Pow ? alch_embed_pow : basis_ == Basis::Dec ? alch_embed_dec : alch_embed_crt;
-        check(f(r_->handle(), big.handle(), data().data(), o.hp_->data()), "alch_embed");
+        check(f(r_->handle(), big.handle(), data().data(), o.data().data()), "alch_embed");
         return o;
     }
     // tweaked trace to a ring of a divisor index (Cyc twace)
@@ -323,7 +323,7 @@ public:
         }
         Cyc o(small, basis_);
         auto f = basis_ == Basis::CRT ? alch_twace_crt : alch_twace_pow_dec;
-        check(f(small.handle(), r_->handle(), data().data(), o.hp_->data()), "alch_twace");
+        check(f(small.handle(), r_->handle(), data().data(), o.data().data()), "alch_twace");
         return o;
     }
     // Cyc coeffsPow / coeffsDec: the d_rel coefficient vectors over the subring w.r.t. the relative powerful / decoding basis

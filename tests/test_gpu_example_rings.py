@@ -69,7 +69,12 @@ class Shim:
         return self.cache[key]
 
     def pow_ring(self, m, qs):
-        """GT.hs `powRing`: the CRT ring when there is one, else the no-CRT ring; None = the whole (m, r) stays on lol-cpp."""
+        """GT.hs `powRing`: the CRT ring when there is one, else the no-CRT ring; None = the whole (m, r) stays on lol-cpp.
+        The integers (modulus 0) are not a GTDispatch type in GT.hs (`Int64` stays on lol-cpp); the compiled C++ host serves them
+        from alch_ring_create_nocrt directly (alchemy_amd/host/cycgen.hpp decToPowZ), which is what is replayed for them."""
+        if list(qs) == [0]:
+            b = self.ring_for(True, m, qs)
+            return (b[1], False) if b[0] == "dev" else (None, False)
         a = self.ring_for(False, m, qs)
         if a[0] == "dev":
             return a[1], True
