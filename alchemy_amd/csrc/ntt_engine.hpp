@@ -82,7 +82,11 @@ template <> struct Vec4<u64> { typedef u64 type __attribute__((ext_vector_type(2
 // lost element 12 of lanes 12-15 / 28-31 / 44-47 / 60-63 of one wave in ~0.5 % of its polynomials until its store data
 // were kept live across one s_nop (found by the whole-batch checksum of tests/test_gpu_bench_shape.py).  Every 16-byte
 // buffer store in this library is followed by this guard; it costs one issue slot.
+#ifndef ALCH_NO_STORE_GUARD
 #define ALCH_STORE_GUARD(v) asm volatile("s_nop 0" ::"v"(v))
+#else
+#define ALCH_STORE_GUARD(v) ((void)0)   // lint self-test only (tests/test_store_hazard_lint.py): never in a product build
+#endif
 
 // Workgroup barrier for LDS hand-offs only.  __syncthreads() is also a fence for global memory, so hipcc puts
 // `s_waitcnt vmcnt(0)` in front of it whenever vector-memory operations are outstanding -- which drains every

@@ -102,14 +102,22 @@ def totient(m: int) -> int:
     return r - r // t if t > 1 else r
 
 
+_GOLDEN = None
+
+
 def golden_checksums():
     """tests/golden/batch_checksums.json: what the C restatement computed offline for the seeded batches timed here
     (tests/golden/make_batch_checksums.py).  Every driver-timed line asserts its results against it: a wrong word in any chunk
-    of any timed line ends the run."""
-    try:
-        return json.load(open(os.path.join(ROOT, "tests", "golden", "batch_checksums.json")))
-    except (OSError, ValueError):
-        return {}
+    of any timed line ends the run.  The fixture is committed: a missing or unreadable file is a broken checkout and ends the run
+    too, instead of silently turning every check off."""
+    global _GOLDEN
+    if _GOLDEN is None:
+        path = os.path.join(ROOT, "tests", "golden", "batch_checksums.json")
+        try:
+            _GOLDEN = json.load(open(path))
+        except (OSError, ValueError) as e:
+            raise SystemExit(f"[bench] {path} is missing or unreadable ({e}): the timed lines cannot be checked against the oracle")
+    return _GOLDEN
 
 
 def assert_checksum(what, got, expected, detail):
@@ -117,6 +125,35 @@ def assert_checksum(what, got, expected, detail):
     if not rec["ok"]:
         raise SystemExit(f"[bench] {what}: result batch differs from the oracle's: {rec}")
     return rec
+
+
+def check_batch(what, ref, batch, checksum_fn, key="checksum"):
+    """Assert a timed line's result batch against its fixture entry, or say WHY it was not checked (a non-default --batch, an entry the
+    fixture does not hold) -- never a silent null."""
+    if ref is None:
+        return {"skipped": f"tests/golden/batch_checksums.json holds no entry for {what}"}
+    if ref.get("batch") != batch:
+        return {"skipped": f"the fixture's {what} batch is {ref.get('batch')}, this run's is {batch} (non-default --batch)"}
+    return assert_checksum(what, checksum_fn(), ref[key], {"batch": batch})
+
+
+def hbm_copy_GBs(ring_cls):
+    """Measured streaming bandwidth of this box next to the 8 TB/s specification ("confirm on the box with a
+    device-to-device copy benchmark, and report both"): alch_buf_copy of 1 GiB (hipMemcpyAsync D2D on the library's stream),
+    read + write bytes over the HIP-event time, best of five."""
+    ring = ring_cls(2 << LOGN, CFG3_QS)
+    elems = 2048                                            # 2048 elements of 512 KiB = 1 GiB
+    src, dst = ring.alloc(elems), ring.alloc(elems)
+    src.fill_uniform(1)
+    dst.copy_from(src, elems)
+    ring.sync()
+    best = 1e9
+    for _ in range(5):
+        ring.timer_start()
+        dst.copy_from(src, elems)
+        best = min(best, ring.timer_stop())
+    nbytes = elems * ring.n * ring.L * ring.word_bytes
+    return {"GBs": 2 * nbytes / (best * 1e-3) / 1e9, "bytes_copied": nbytes, "method": "hipMemcpyAsync device-to-device, read + write bytes, best of 5"}
 
 
 def apply_opts(*rings):
@@ -151,10 +188,7 @@ def general_index_line():
     for _ in range(3):
         tr.crt()
     crt_s = 3 * tr.n_elems * ring.L / (ring.timer_stop() * 1e-3)
-    ref = golden_checksums().get("general_index", {}).get("bench")
-    check = None
-    if ref is not None and ref["batch"] == Bg:
-        check = assert_checksum("general_index", out.checksum(), ref["checksum"], {"batch": Bg})
+    check = check_batch("general_index", golden_checksums().get("general_index", {}).get("bench"), Bg, out.checksum)
     return {"workload": "keySwitchQuadCirc(hint, a*b), index m'=20475 (phi=8640), L=4 HomomRLWR moduli, TrivGad, CRT in/out",
             "ops_per_s": ops, "batch": Bg, "batch_checksum": check, "algorithmic_bytes_per_op": algo, "achieved_GBs": ops * algo / 1e9,
             "frac_of_hbm_peak": ops * algo / 1e9 / HBM_PEAK_GBS, "frac_at_device_word": ops * algo / 2 / 1e9 / HBM_PEAK_GBS,
@@ -184,10 +218,8 @@ def q30_line(B):
         for _ in range(5):
             ring.ct_mul_relin(hint, a, b, out, B)
         rates[q30] = 5 * B / (ring.timer_stop() * 1e-3)
-        ref = golden_checksums().get("q30", {}).get("bench_mul_relin")
-        if ref is not None and ref["batch"] == B:
-            rec = assert_checksum(f"moduli below 2^30 (q30 = {q30})", out.checksum(), ref["checksum"], {"batch": B})
-            check = rec if q30 else check
+        rec = check_batch(f"moduli below 2^30 (q30 = {q30})", golden_checksums().get("q30", {}).get("bench_mul_relin"), B, out.checksum)
+        check = rec if q30 else check
         del a, b, out, hs, hint, ring
     # PT2CT's whole mul_ (4 -> 5 -> 3 limbs) on the same moduli: the UP instantiation of the Harvey key-switch kernel
     full, fref = None, golden_checksums().get("q30", {}).get("full_mul")
@@ -234,10 +266,7 @@ def n16_line():
     for _ in range(3):
         ring.ct_mul_relin(hint, a, b, out, B)
     ops = 3 * B / (ring.timer_stop() * 1e-3)
-    ref = golden_checksums().get("n16", {}).get("bench_mul_relin")
-    check = None
-    if ref is not None and ref["batch"] == B:
-        check = assert_checksum("n = 2^16, six limbs", out.checksum(), ref["checksum"], {"batch": B})
+    check = check_batch("n = 2^16, six limbs", golden_checksums().get("n16", {}).get("bench_mul_relin"), B, out.checksum)
     algo = 6 * len(qs) * n * 8
     return {"workload": "keySwitchQuadCirc(hint, a*b), n=2^16, 6 limbs (31-bit primes = 1 mod 2^17), TrivGad, CRT in/out, split transforms",
             "ops_per_s": ops, "batch": B, "batch_checksum": check, "algorithmic_bytes_per_op": algo, "achieved_GBs": ops * algo / 1e9,
@@ -256,7 +285,7 @@ def tunnel_hs_line():
     for k in range(5):
         hop = Hop(k, TUNNEL_HS_BATCH, RING_OPTS)
         rate, res = hop.measure(reps=3)
-        check = None
+        check = {"skipped": f"the fixture holds no hop {k}"}
         if k in ref:                                        # per-ciphertext checksums are position dependent, so any prefix adds up
             cnt = min(hop.B, ref[k]["batch"])
             want = sum(int(x, 16) for x in ref[k]["per_ciphertext"][:cnt]) & MASK64
@@ -299,7 +328,7 @@ def config2_line():
             raise SystemExit(f"[bench] config2 {label}: crtInv^4(crt^4(x)) != x")
         a.crt()
         t_m = best(lambda: c.mul(a, b, polys))
-        check = None
+        check = {"skipped": f"the fixture holds no config2 entry for {label}"}
         pre = ref.get("prefix")
         if label in ref and pre and pre <= polys:
             check = {"crt": assert_checksum(f"config2 {label} crt", a.checksum(0, pre), ref[label]["crt"], {"polynomials": pre}),
@@ -422,12 +451,7 @@ def main():
     # (tests/golden/batch_checksums.json, generated by tests/golden/make_batch_checksums.py)
     batch_check = None
     if rank == 0:
-        ref = golden_checksums().get("bench_mul_relin")
-        if ref is not None and ref.get("batch") == B:
-            got = out.checksum()
-            batch_check = {"batch": B, "expected": ref["checksum"], "got": f"{got:016x}", "ok": f"{got:016x}" == ref["checksum"]}
-            if not batch_check["ok"]:
-                raise SystemExit(f"[bench] result batch differs from the oracle's: {batch_check}")
+        batch_check = check_batch("the headline batch", golden_checksums().get("bench_mul_relin"), B, out.checksum)
 
     # The batch gather (north star: "RCCL over xGMI for the batch gather only"): after timing, every rank
     # contributes a slice of its result batch to an all-gather, zero-copy from the library's buffer.  Reported next
@@ -466,7 +490,7 @@ def main():
                   "backend": "rccl" if red_dev is not None else "gloo"}
         del everyone
 
-    pow_ops = None
+    pow_ops = pow_check = None
     if args.pow and rank == 0:
         from alchemy_amd.capi import ALCH_POW_IN, ALCH_POW_OUT
         Bp = min(B, 2048)
@@ -476,6 +500,7 @@ def main():
         for _ in range(3):
             ring.ct_mul_relin(hint, a, b, out, Bp, flags=ALCH_POW_IN | ALCH_POW_OUT)
         pow_ops = 3 * Bp / (ring.timer_stop() * 1e-3)
+        pow_check = check_batch("Pow-basis in/out", golden_checksums().get("bench_extra", {}).get("pow_in_out"), Bp, lambda: out.checksum(0, 2 * Bp))
 
     full = None
     if args.full and rank == 0:
@@ -502,7 +527,9 @@ def main():
                 "keySwitchQuadCirc, modSwitch to 3 limbs; CRT-basis in/out", "moduli_hint": qs_h, "batch": Bf,
                 "algorithmic_bytes_per_op": algo, "achieved_GBs": ops * algo / 1e9,
                 "frac_of_hbm_peak": ops * algo / 1e9 / HBM_PEAK_GBS,
-                "frac_at_device_word": ops * (algo // 2) / 1e9 / HBM_PEAK_GBS, "out_checksum": f"{fout.checksum(0, 2):016x}"}
+                "frac_at_device_word": ops * (algo // 2) / 1e9 / HBM_PEAK_GBS,
+                "batch_checksum": check_batch("full_mul", golden_checksums().get("bench_extra", {}).get("full_mul"), Bf, fout.checksum),
+                "out_checksum": f"{fout.checksum(0, 2):016x}"}
         del fout, hint_h, hsrc
 
     general = None
@@ -544,7 +571,7 @@ def main():
             # whole-batch check of the timed pass: rank 0's shard starts at ciphertext 0, so the committed per-ciphertext checksums
             # of the C restatement's replay (tests/ringround_oracle.py) apply to its first min(Bp, fixture batch) results
             ref = golden_checksums().get("homomrlwr")
-            pipe_check = None
+            pipe_check = {"skipped": "the fixture holds no homomrlwr entry"}
             if ref is not None:
                 cnt = min(Bp, ref["batch"])
                 want = sum(int(x, 16) for x in ref["per_ciphertext"][:cnt]) & MASK64
@@ -573,6 +600,7 @@ def main():
         del rr
 
     if rank == 0:
+        copy_bw = hbm_copy_GBs(Ring)
         total_ops = B * world * args.steps
         value = total_ops / wall_max
         # per-GPU achieved algorithmic bandwidth from the HIP-event time of the K launches on the stream
@@ -608,14 +636,17 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "sharding": f"dp{world} by ciphertext, no collective in the timed region", "hint": hint_dist,
                        "moduli": CFG3_QS, "device_word_bytes": ring.word_bytes},
             "roofline": {"bound": "hbm", "limiter": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
+                         "frac": achieved / HBM_PEAK_GBS, "hbm_copy_GBs": copy_bw["GBs"], "hbm_copy": copy_bw,
+                         "frac_of_measured_copy": achieved / copy_bw["GBs"],
                          "frac_at_device_word": per_gpu_ops_s * (DEVICE_WORD_BYTES_PER_OP + HINT_BYTES / 2 / B) / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_bytes_per_op": traffic_per_op, "traffic_source": traffic_src,
                          "note": "frac prices an op at SURVEY 8d's 6,291,456 B (six ciphertext components at the reference's "
                                  "8-byte Int64 word); frac_at_device_word prices the same components at the 4-byte word the "
                                  "device actually moves (3,145,728 B) -- the honest fraction of the 8 TB/s peak for this "
                                  "build.  bound names the roofline SURVEY 8d prescribes; limiter says what the kernels are "
-                                 "actually bound by (integer VALU issue, DESIGN.md 4).  traffic = physical GB/s = PMC "
+                                 "actually bound by (integer VALU issue, DESIGN.md 4).  hbm_copy_GBs = what a plain device-to-device "
+                                 "copy reaches on this very box in this very run (SURVEY 8d asks for it next to the 8 TB/s "
+                                 "specification); frac_of_measured_copy = achieved / that.  traffic = physical GB/s = PMC "
                                  "(FETCH_SIZE x2 + WRITE_SIZE) bytes per op x this run's ops/s, null when the committed PMC "
                                  "summary was taken on other kernel sources"},
             "hip_event_ms_per_step": ev_ms_max / args.steps,
@@ -625,6 +656,7 @@ def main():
         }
         if pow_ops is not None:
             line["pow_basis_in_out_ops_per_s"] = pow_ops
+            line["pow_basis_in_out"] = {"ops_per_s": pow_ops, "batch": min(B, 2048), "batch_checksum": pow_check}
         if full is not None:
             line["full_mul"] = full
         if general is not None:

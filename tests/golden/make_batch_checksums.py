@@ -15,10 +15,12 @@
    * n16: the headline op at n = 2^16 on six limbs (split transforms), B = 2048 for bench.py's extra line and a ragged test batch;
    * q30: the headline op on four moduli below 2^30 (Harvey-butterfly kernels), B = 8192 for bench.py's extra line and the ragged
      test batch;
+   * bench_extra: bench.py's `full_mul` line (PT2CT's whole mul_, 4 -> 5 -> 3 limbs, B = 4096) and its `pow_basis_in_out` line (the headline
+     op with Pow-basis operands and result, B = 2048) -- the two driver-timed lines that only printed a checksum until round 4;
    Per-ciphertext lists let any prefix (a ragged test batch) be checked: sums are position-dependent, so they add.
 A result error confined to any chunk, stream or persistent-workgroup slot changes the sum.
 
-    python tests/golden/make_batch_checksums.py [two_power] [q30] [n16] [general] [homomrlwr] [tunnel_hs]     (default: all; sections not
+    python tests/golden/make_batch_checksums.py [two_power] [bench_extra] [q30] [n16] [general] [homomrlwr] [tunnel_hs]     (default: all; sections not
     regenerated are kept from the existing file)"""
 import json
 import os
@@ -91,6 +93,18 @@ def full_range(first, count, qs_h=None):
         b0, b1 = o_in.fill_uniform(SEED_B, 2 * ct), o_in.fill_uniform(SEED_B, 2 * ct + 1)
         w0, w1 = oracle_full_mul(cref, N, qs_h, 4, 3, hint, a0, a1, b0, b1)
         s += elem_checksum(w0, 2 * ct, 3) + elem_checksum(w1, 2 * ct + 1, 3)
+    return s & MASK
+
+
+def pow_range(first, count):
+    """keySwitchQuadCirc(hint, a*b) with Pow-basis operands and result (ALCH_POW_IN | ALCH_POW_OUT; the hint stays CRT-basis data)."""
+    o = cref.Ring(N, CFG3_QS)
+    hint = [o.fill_uniform(SEED_H, i) for i in range(2 * len(CFG3_QS))]
+    s = 0
+    for ct in range(first, first + count):
+        w0, w1 = o.ct_mul_relin(hint, o.fill_uniform(SEED_A, 2 * ct), o.fill_uniform(SEED_A, 2 * ct + 1),
+                                o.fill_uniform(SEED_B, 2 * ct), o.fill_uniform(SEED_B, 2 * ct + 1), pow_basis=True)
+        s += elem_checksum(w0, 2 * ct, 4) + elem_checksum(w1, 2 * ct + 1, 4)
     return s & MASK
 
 
@@ -174,7 +188,7 @@ if __name__ == "__main__":
     cref.build()
     path = os.path.join(HERE, "batch_checksums.json")
     out = json.load(open(path)) if os.path.exists(path) else {}
-    want = set(sys.argv[1:]) or {"two_power", "q30", "n16", "general", "homomrlwr", "tunnel_hs", "config2"}
+    want = set(sys.argv[1:]) or {"two_power", "bench_extra", "q30", "n16", "general", "homomrlwr", "tunnel_hs", "config2"}
     if "q30" in want:
         B_TEST, B_BENCH = 2 * 1024 + 37, 8192
         head = run_ranges(lambda f, c: relin_range(f, c, Q30_QS), B_TEST)
@@ -197,6 +211,14 @@ if __name__ == "__main__":
                     "test_mul_relin": {"batch": B_TEST, "checksum": f"{head:016x}"},
                     "bench_mul_relin": {"batch": B_BENCH, "checksum": f"{(head + tail) & MASK:016x}"},
                     "test_mul_full": {"batch": B_TEST, "limbs": "4 -> 5 -> 3", "checksum": f"{full:016x}"}})
+    if "bench_extra" in want:
+        B_TEST, B_FULL, B_POW = out["test_mul_full"]["batch"], 4096, 2048          # sums are position dependent: the test batch is a prefix
+        tail = run_ranges(lambda f, c: full_range(B_TEST + f, c), B_FULL - B_TEST)
+        powc = run_ranges(pow_range, B_POW)
+        out["bench_extra"] = {"what": "bench.py's full_mul line (same seeds as the headline, operands on the four config-3 moduli, hint on five, "
+                                      "result on three) and its Pow-basis in/out line",
+                              "full_mul": {"batch": B_FULL, "limbs": "4 -> 5 -> 3", "checksum": f"{(int(out['test_mul_full']['checksum'], 16) + tail) & MASK:016x}"},
+                              "pow_in_out": {"batch": B_POW, "checksum": f"{powc:016x}", "first_2": f"{pow_range(0, 2):016x}"}}
     if "n16" in want:
         B_TEST, B_BENCH = 1024 + 37, 2048
         head = run_ranges(lambda f, c: relin_range(f, c, SIX_QS_17, 1 << 16), B_TEST)

@@ -52,3 +52,31 @@ def test_two_power_fixtures_are_current(gen):
     assert f"{gen.relin_range(0, 2, gen.Q30_QS):016x}" == ref["q30"]["first_2"]
     assert ref["n16"]["moduli"] == gen.SIX_QS_17 and ref["n16"]["n"] == 1 << 16
     assert f"{gen.relin_range(0, 2, gen.SIX_QS_17, 1 << 16):016x}" == ref["n16"]["first_2"]
+
+
+def test_bench_extra_fixtures_are_current(gen):
+    """bench.py's full_mul (B = 4096) and Pow-basis in/out (B = 2048) lines, asserted since round 4."""
+    ref = load_golden("batch_checksums.json")
+    ex = ref["bench_extra"]
+    assert ex["full_mul"]["batch"] == 4096 and ex["pow_in_out"]["batch"] == 2048
+    assert f"{gen.pow_range(0, 2):016x}" == ex["pow_in_out"]["first_2"]
+    # the full_mul batch extends the test batch: its checksum is the test batch's plus a tail, so one recomputed ciphertext of the tail pins it
+    head = int(ref["test_mul_full"]["checksum"], 16)
+    assert ex["full_mul"]["checksum"] != f"{head:016x}" and ref["test_mul_full"]["batch"] < ex["full_mul"]["batch"]
+
+
+def test_bench_reports_why_a_line_was_not_checked():
+    """a stale fixture or a non-default --batch must show up in the line, and a wrong batch must end the run."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert "holds no entry" in bench.check_batch("x", None, 8, lambda: 0)["skipped"]
+    assert "non-default --batch" in bench.check_batch("x", {"batch": 16, "checksum": "0" * 16}, 8, lambda: 0)["skipped"]
+    assert bench.check_batch("x", {"batch": 8, "checksum": f"{5:016x}"}, 8, lambda: 5)["ok"] is True
+    import pytest
+    with pytest.raises(SystemExit):
+        bench.check_batch("x", {"batch": 8, "checksum": f"{5:016x}"}, 8, lambda: 6)
+    assert bench.golden_checksums()["bench_mul_relin"]["batch"] == 8192
