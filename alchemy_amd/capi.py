@@ -35,7 +35,7 @@ SYMBOLS = [
     "alch_tunnel_info", "alch_tunnel_create", "alch_tunnel_free", "alch_ct_tunnel", "alch_ct_mod_switch",
     "alch_buf_embed", "alch_buf_twace", "alch_buf_coeffs", "alch_embed_pow", "alch_embed_dec", "alch_embed_crt",
     "alch_twace_pow_dec", "alch_twace_crt", "alch_coeffs", "alch_ext_table", "alch_crt_set_dec", "alch_ct_add_public",
-    "alch_ring_share_stream", "alch_buf_copy", "alch_buf_tensor_op", "alch_buf_view",
+    "alch_ring_share_stream", "alch_buf_copy", "alch_buf_tensor_op", "alch_buf_view", "alch_buf_ring", "alch_ring_device",
 ]
 
 
@@ -110,6 +110,8 @@ def load_library():
         "alch_ring_n": [VP, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "alch_ring_set_stream": [VP, VP],
         "alch_ring_share_stream": [VP, VP],
+        "alch_buf_ring": [VP, C.POINTER(VP)],
+        "alch_ring_device": [VP, C.POINTER(C.c_int), C.POINTER(VP)],
         "alch_buf_copy": [VP, C.c_size_t, VP, C.c_size_t, C.c_size_t],
         "alch_buf_tensor_op": [VP, C.c_size_t, VP, C.c_size_t, C.c_size_t, C.c_int],
         "alch_buf_view": [VP, C.c_size_t, C.c_size_t, C.POINTER(VP)],

@@ -1325,6 +1325,19 @@ extern "C" int alch_buf_device_ptr(const alch_buf* b, void** ptr, size_t* bytes)
     return ALCH_OK;
 }
 
+extern "C" int alch_buf_ring(const alch_buf* b, alch_ring** ring) {
+    if (!b || !ring) return fail(ALCH_E_INVALID, "null argument");
+    *ring = b->ring;
+    return ALCH_OK;
+}
+
+extern "C" int alch_ring_device(const alch_ring* r, int* device, void** hip_stream) {
+    if (!r) return fail(ALCH_E_INVALID, "null ring");
+    if (device) *device = r->device;
+    if (hip_stream) *hip_stream = (void*)r->stream;
+    return ALCH_OK;
+}
+
 template <typename W>
 static int do_transfer(alch_ring* r, void* dev, size_t count, int64_t* host, bool to_device) {
     const size_t bytes = count * elem_words(r) * sizeof(int64_t);

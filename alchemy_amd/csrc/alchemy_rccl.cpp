@@ -1,0 +1,135 @@
+// libalchemy_rccl.so -- RCCL collectives on the library's device buffers (include/alchemy_rccl.h).
+// Uses only the public C ABI of libalchemy_hip.so (alch_buf_device_ptr, alch_buf_ring, alch_ring_device, alch_ring_n,
+// alch_buf_elems), the HIP runtime and RCCL.  One process, rank r = device r, group calls from the calling thread.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/alchemy_rccl.h"
+
+struct alch_comm {
+    int n = 0;
+    std::vector<ncclComm_t> comms;
+};
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+extern "C" const char* alch_rccl_last_error(void) { return g_err.c_str(); }
+
+#define NCCL_TRY(expr)                                                                                   \
+    do {                                                                                                 \
+        ncclResult_t _r = (expr);                                                                        \
+        if (_r != ncclSuccess) return fail(ALCH_E_HIP, std::string(#expr) + ": " + ncclGetErrorString(_r)); \
+    } while (0)
+
+extern "C" int alch_comm_init_all(int n_dev, alch_comm** out) {
+    if (!out) return fail(ALCH_E_INVALID, "alch_comm_init_all: null out");
+    *out = nullptr;
+    if (n_dev < 1) return fail(ALCH_E_INVALID, "alch_comm_init_all: n_dev must be >= 1");
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1) return fail(ALCH_E_NO_DEVICE, "no HIP device");
+    if (n_dev > visible)
+        return fail(ALCH_E_NO_DEVICE, "alch_comm_init_all: " + std::to_string(n_dev) + " ranks but only " + std::to_string(visible) + " devices visible (one rank per GPU)");
+    alch_comm* c = new alch_comm();
+    c->n = n_dev;
+    c->comms.resize((size_t)n_dev);
+    std::vector<int> devs((size_t)n_dev);
+    for (int r = 0; r < n_dev; ++r) devs[(size_t)r] = r;
+    ncclResult_t rc = ncclCommInitAll(c->comms.data(), n_dev, devs.data());
+    if (rc != ncclSuccess) { delete c; return fail(ALCH_E_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(rc)); }
+    *out = c;
+    return ALCH_OK;
+}
+
+extern "C" int alch_comm_destroy(alch_comm* c) {
+    if (!c) return ALCH_OK;
+    for (ncclComm_t k : c->comms) (void)ncclCommDestroy(k);
+    delete c;
+    return ALCH_OK;
+}
+
+extern "C" int alch_comm_size(const alch_comm* c, int* n_dev) {
+    if (!c || !n_dev) return fail(ALCH_E_INVALID, "null argument");
+    *n_dev = c->n;
+    return ALCH_OK;
+}
+
+namespace {
+struct RankBuf {
+    char* ptr = nullptr;
+    size_t elems = 0, elem_bytes = 0;
+    int device = -1;
+    hipStream_t stream = nullptr;
+};
+
+// Resolves one buffer per rank and checks that rank r's buffer lives on device r and that all rings have one element size.
+int resolve(const alch_comm* c, alch_buf* const* bufs, const char* what, std::vector<RankBuf>& out) {
+    if (!c || !bufs) return fail(ALCH_E_INVALID, std::string(what) + ": null argument");
+    out.resize((size_t)c->n);
+    for (int r = 0; r < c->n; ++r) {
+        if (!bufs[r]) return fail(ALCH_E_INVALID, std::string(what) + ": null buffer for rank " + std::to_string(r));
+        alch_ring* ring = nullptr;
+        void* p = nullptr;
+        size_t bytes = 0, elems = 0;
+        uint32_t n = 0;
+        int L = 0, word = 0;
+        void* stream = nullptr;
+        RankBuf& b = out[(size_t)r];
+        if (alch_buf_ring(bufs[r], &ring) != ALCH_OK || alch_buf_device_ptr(bufs[r], &p, &bytes) != ALCH_OK ||
+            alch_buf_elems(bufs[r], &elems) != ALCH_OK || alch_ring_n(ring, &n, &L, &word) != ALCH_OK ||
+            alch_ring_device(ring, &b.device, &stream) != ALCH_OK)
+            return fail(ALCH_E_INVALID, std::string(what) + ": bad buffer handle for rank " + std::to_string(r));
+        b.ptr = static_cast<char*>(p);
+        b.elems = elems;
+        b.elem_bytes = (size_t)n * (size_t)L * (size_t)word;
+        b.stream = static_cast<hipStream_t>(stream);
+        if (b.device != r)
+            return fail(ALCH_E_INVALID, std::string(what) + ": the buffer of rank " + std::to_string(r) + " lives on device " + std::to_string(b.device) +
+                                            " (rank r = device r: create that rank's rings with device r current)");
+        if (b.elem_bytes != out[0].elem_bytes) return fail(ALCH_E_INVALID, std::string(what) + ": the ranks' rings differ in dimension, limbs or word size");
+    }
+    return ALCH_OK;
+}
+}  // namespace
+
+extern "C" int alch_hint_broadcast(alch_comm* c, int root, alch_buf* const* bufs, size_t first, size_t count) {
+    std::vector<RankBuf> b;
+    int rc = resolve(c, bufs, "alch_hint_broadcast", b);
+    if (rc != ALCH_OK) return rc;
+    if (root < 0 || root >= c->n) return fail(ALCH_E_INVALID, "alch_hint_broadcast: root out of range");
+    for (auto& x : b) if (first + count > x.elems) return fail(ALCH_E_INVALID, "alch_hint_broadcast: element range out of bounds");
+    if (count == 0) return ALCH_OK;
+    const size_t bytes = count * b[0].elem_bytes, off = first * b[0].elem_bytes;
+    NCCL_TRY(ncclGroupStart());
+    for (int r = 0; r < c->n; ++r) {
+        ncclResult_t e = ncclBroadcast(b[(size_t)root].ptr + off, b[(size_t)r].ptr + off, bytes, ncclChar, root, c->comms[(size_t)r], b[(size_t)r].stream);
+        if (e != ncclSuccess) { (void)ncclGroupEnd(); return fail(ALCH_E_HIP, std::string("ncclBroadcast: ") + ncclGetErrorString(e)); }
+    }
+    NCCL_TRY(ncclGroupEnd());
+    return ALCH_OK;
+}
+
+extern "C" int alch_buf_all_gather(alch_comm* c, alch_buf* const* src, size_t first, size_t count, alch_buf* const* dst) {
+    std::vector<RankBuf> s, d;
+    int rc = resolve(c, src, "alch_buf_all_gather (src)", s);
+    if (rc != ALCH_OK) return rc;
+    if ((rc = resolve(c, dst, "alch_buf_all_gather (dst)", d)) != ALCH_OK) return rc;
+    if (s[0].elem_bytes != d[0].elem_bytes) return fail(ALCH_E_INVALID, "alch_buf_all_gather: source and destination rings differ");
+    for (int r = 0; r < c->n; ++r) {
+        if (first + count > s[(size_t)r].elems) return fail(ALCH_E_INVALID, "alch_buf_all_gather: source range out of bounds");
+        if ((size_t)c->n * count > d[(size_t)r].elems) return fail(ALCH_E_INVALID, "alch_buf_all_gather: dst must hold n_dev * count elements");
+        if (s[(size_t)r].stream != d[(size_t)r].stream)
+            return fail(ALCH_E_INVALID, "alch_buf_all_gather: a rank's source and destination rings must share a stream (the same ring, or alch_ring_share_stream)");
+    }
+    if (count == 0) return ALCH_OK;
+    const size_t bytes = count * s[0].elem_bytes, off = first * s[0].elem_bytes;
+    NCCL_TRY(ncclGroupStart());
+    for (int r = 0; r < c->n; ++r) {
+        ncclResult_t e = ncclAllGather(s[(size_t)r].ptr + off, d[(size_t)r].ptr, bytes, ncclChar, c->comms[(size_t)r], s[(size_t)r].stream);
+        if (e != ncclSuccess) { (void)ncclGroupEnd(); return fail(ALCH_E_HIP, std::string("ncclAllGather: ") + ncclGetErrorString(e)); }
+    }
+    NCCL_TRY(ncclGroupEnd());
+    return ALCH_OK;
+}

@@ -1,0 +1,203 @@
+// BASELINE config 4 ("examples/HomomRLWR.hs pipeline, 8192-ciphertext batch sharded over 8 x MI355X") from a native host: no Python,
+// no torch -- one process, one host thread per GPU, RCCL through include/alchemy_rccl.h.
+//
+//   ringround_multi [--gpus N] [--batch B] [--passes K] [--gather G] [--fixture PATH]
+//
+//   1. every rank r (thread r, device r) builds the pipeline of alchemy_amd/host/ringround.hpp for its shard of B ciphertexts
+//      (default 1024: 8 ranks x 1024 = 8192);
+//   2. the hint sources (five tunnels' linear functions and key-switch hints, four quadratic hints -- generated once per circuit,
+//      Crypto/Alchemy/Interpreter/KeysHints.hs:101-129) are generated on rank 0 ONLY and broadcast with alch_hint_broadcast; the
+//      other ranks' sources start zeroed, so a broadcast that did not deliver cannot go unnoticed;
+//   3. every rank runs K timed passes of the op sequence on its shard between two barriers -- no collective inside;
+//   4. every shard's result is checked against the C restatement's per-ciphertext checksums (tests/golden/batch_checksums.json,
+//      "homomrlwr"): the shards carry the same seeded inputs, so the fixture applies to each of them;
+//   5. the first G result ciphertexts of every rank are all-gathered (alch_buf_all_gather) and every rank checks every slice.
+// Prints one JSON line: aggregate ringRound evaluations per second (N * B / slowest rank's time), per-rank times, check results.
+// Exit status 0 only when every check passed.
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <sstream>
+#include <thread>
+
+#include <hip/hip_runtime_api.h>
+
+#include "../alchemy_amd/host/ringround.hpp"
+#include "../include/alchemy_rccl.h"
+
+using alchemy::ringround::RingRound;
+
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// the "per_ciphertext" list of the "homomrlwr" section of tests/golden/batch_checksums.json
+static std::vector<uint64_t> load_fixture(const std::string& path) {
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    const std::string s = ss.str();
+    size_t a = s.find("\"homomrlwr\"");
+    if (a == std::string::npos) throw std::runtime_error("no homomrlwr section in " + path);
+    a = s.find("\"per_ciphertext\"", a);
+    a = s.find('[', a);
+    const size_t b = s.find(']', a);
+    std::vector<uint64_t> out;
+    for (size_t i = a; i < b;) {
+        const size_t q0 = s.find('"', i);
+        if (q0 == std::string::npos || q0 > b) break;
+        const size_t q1 = s.find('"', q0 + 1);
+        out.push_back(strtoull(s.substr(q0 + 1, q1 - q0 - 1).c_str(), nullptr, 16));
+        i = q1 + 1;
+    }
+    return out;
+}
+
+struct Barrier {
+    explicit Barrier(int n) : n_(n) {}
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu_);
+        const int gen = gen_;
+        if (++count_ == n_) { count_ = 0; ++gen_; cv_.notify_all(); }
+        else cv_.wait(lk, [&] { return gen != gen_; });
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    int n_, count_ = 0, gen_ = 0;
+};
+
+int main(int argc, char** argv) {
+    int N = 1, passes = 2;
+    size_t B = 1024, G = 16;
+    std::string fixture = "tests/golden/batch_checksums.json";
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--gpus") && i + 1 < argc) N = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--batch") && i + 1 < argc) B = (size_t)atol(argv[++i]);
+        else if (!strcmp(argv[i], "--passes") && i + 1 < argc) passes = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--gather") && i + 1 < argc) G = (size_t)atol(argv[++i]);
+        else if (!strcmp(argv[i], "--fixture") && i + 1 < argc) fixture = argv[++i];
+        else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
+    }
+    try {
+        if (N < 1 || passes < 1 || B < 1) throw std::runtime_error("--gpus, --passes and --batch must be positive");
+        G = std::min(G, B);
+        const std::vector<uint64_t> fix = load_fixture(fixture);
+        alch_comm* comm = nullptr;
+        if (alch_comm_init_all(N, &comm) != ALCH_OK) throw std::runtime_error(std::string("alch_comm_init_all: ") + alch_rccl_last_error());
+
+        std::vector<std::unique_ptr<RingRound>> rr((size_t)N);
+        std::vector<std::string> errors((size_t)N);
+        std::vector<double> secs((size_t)N, 0.0);
+        std::vector<int> shard_ok((size_t)N, 0), gather_ok((size_t)N, 0);
+        std::vector<alch_buf*> results((size_t)N, nullptr), gathered((size_t)N, nullptr);
+        Barrier bar(N);
+        std::atomic<bool> failed(false);
+        double t_bcast = 0;
+
+        auto guarded = [&](int r, const std::function<void()>& fn) {
+            if (failed) return;
+            try { fn(); } catch (const std::exception& e) { errors[(size_t)r] = e.what(); failed = true; }
+        };
+        auto worker = [&](int r) {
+            guarded(r, [&] {
+                if (hipSetDevice(r) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
+                rr[(size_t)r].reset(new RingRound(B));
+                if (r == 0) rr[0]->fillSources();                         // generated once, on one rank
+                else {
+                    for (auto& s : rr[(size_t)r]->sources) {               // zeros until the broadcast arrives
+                        void* p = nullptr;
+                        size_t bytes = 0;
+                        alchemy::ringround::check(alch_buf_device_ptr(s.first, &p, &bytes), "alch_buf_device_ptr");
+                        if (hipMemset(p, 0, bytes) != hipSuccess) throw std::runtime_error("hipMemset failed");
+                    }
+                    if (hipDeviceSynchronize() != hipSuccess) throw std::runtime_error("hipDeviceSynchronize failed");
+                }
+                rr[(size_t)r]->sync();
+            });
+            bar.wait();
+            if (r == 0) guarded(0, [&] {                                  // the one collective of the path, before anything is timed
+                const double t0 = now();
+                const size_t ns = rr[0]->sources.size();
+                for (size_t i = 0; i < ns; ++i) {
+                    std::vector<alch_buf*> bufs;
+                    size_t elems = 0;
+                    for (int k = 0; k < N; ++k) bufs.push_back(rr[(size_t)k]->sources[i].first);
+                    alchemy::ringround::check(alch_buf_elems(bufs[0], &elems), "alch_buf_elems");
+                    if (alch_hint_broadcast(comm, 0, bufs.data(), 0, elems) != ALCH_OK) throw std::runtime_error(std::string("alch_hint_broadcast: ") + alch_rccl_last_error());
+                }
+                for (int k = 0; k < N; ++k) rr[(size_t)k]->sync();
+                t_bcast = now() - t0;
+            });
+            bar.wait();
+            guarded(r, [&] {
+                (void)hipSetDevice(r);
+                rr[(size_t)r]->buildHints();
+                rr[(size_t)r]->run();                                     // allocations, first touch
+                rr[(size_t)r]->sync();
+            });
+            bar.wait();
+            guarded(r, [&] {
+                const double t0 = now();
+                alch_buf* res = nullptr;
+                for (int p = 0; p < passes; ++p) res = rr[(size_t)r]->run();
+                rr[(size_t)r]->sync();
+                secs[(size_t)r] = (now() - t0) / passes;
+                results[(size_t)r] = res;
+                // the shard against the oracle: per-ciphertext checksums are position dependent, so any prefix adds up
+                const size_t cnt = std::min(B, fix.size());
+                uint64_t want = 0, got = 0;
+                for (size_t i = 0; i < cnt; ++i) want += fix[i];
+                alchemy::ringround::check(alch_buf_checksum(res, 0, 2 * cnt, &got), "alch_buf_checksum");
+                shard_ok[(size_t)r] = got == want;
+                alch_ring* ring = nullptr;
+                alchemy::ringround::check(alch_buf_ring(res, &ring), "alch_buf_ring");
+                alchemy::ringround::check(alch_buf_alloc(ring, (size_t)N * 2 * G, &gathered[(size_t)r]), "alch_buf_alloc");
+            });
+            bar.wait();
+            if (r == 0) guarded(0, [&] {                                  // the batch gather, after timing
+                if (alch_buf_all_gather(comm, results.data(), 0, 2 * G, gathered.data()) != ALCH_OK)
+                    throw std::runtime_error(std::string("alch_buf_all_gather: ") + alch_rccl_last_error());
+            });
+            bar.wait();
+            guarded(r, [&] {
+                // every slice equals this rank's own first G ciphertexts (the shards carry the same data) -- bit for bit
+                uint64_t own = 0;
+                alchemy::ringround::check(alch_buf_checksum(results[(size_t)r], 0, 2 * G, &own), "alch_buf_checksum");
+                bool ok = true;
+                for (int k = 0; k < N; ++k) {
+                    uint64_t got = 0;
+                    alchemy::ringround::check(alch_buf_checksum(gathered[(size_t)r], (size_t)k * 2 * G, 2 * G, &got), "alch_buf_checksum");
+                    ok = ok && got == own;
+                }
+                gather_ok[(size_t)r] = ok;
+            });
+        };
+        std::vector<std::thread> threads;
+        for (int r = 0; r < N; ++r) threads.emplace_back(worker, r);
+        for (auto& t : threads) t.join();
+        for (alch_buf* g : gathered) if (g) alch_buf_free(g);
+        rr.clear();
+        alch_comm_destroy(comm);
+        bool ok = !failed;
+        double slow = 0;
+        for (int r = 0; r < N; ++r) { ok = ok && shard_ok[(size_t)r] && gather_ok[(size_t)r]; slow = std::max(slow, secs[(size_t)r]); }
+        printf("{\"workload\": \"HomomRLWR ringRound pipeline, %zu ciphertexts per GPU, native host (C++ threads + RCCL, no torch)\", \"n_gpus\": %d, "
+               "\"pipelines_per_s\": %.1f, \"ms_per_pass_slowest_rank\": %.3f, \"hint_broadcast_ms\": %.3f, \"shard_checksums_ok\": [", B, N,
+               slow > 0 ? (double)N * (double)B / slow : 0.0, slow * 1e3, t_bcast * 1e3);
+        for (int r = 0; r < N; ++r) printf("%s%s", r ? ", " : "", shard_ok[(size_t)r] ? "true" : "false");
+        printf("], \"all_gather_slices_ok\": [");
+        for (int r = 0; r < N; ++r) printf("%s%s", r ? ", " : "", gather_ok[(size_t)r] ? "true" : "false");
+        printf("], \"gathered_ciphertexts_per_rank\": %zu, \"ciphertexts_checked_per_shard\": %zu}\n", G, std::min(B, fix.size()));
+        for (int r = 0; r < N; ++r) if (!errors[(size_t)r].empty()) fprintf(stderr, "rank %d: %s\n", r, errors[(size_t)r].c_str());
+        return ok ? 0 : 1;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 2;
+    }
+}

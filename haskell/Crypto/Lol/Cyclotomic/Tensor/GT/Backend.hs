@@ -36,6 +36,8 @@ foreign import ccall unsafe "alch_modulus_units"       c_modulusUnits    :: Word
 foreign import ccall unsafe "alch_host_root"           c_hostRoot        :: Word32 -> Word64 -> Ptr Word64 -> Ptr Word64 -> IO CInt
 foreign import ccall unsafe "alch_ring_n"              c_ringN           :: Ptr AlchRing -> Ptr Word32 -> Ptr CInt -> Ptr CInt -> IO CInt
 foreign import ccall unsafe "alch_ring_set_stream"     c_ringSetStream   :: Ptr AlchRing -> Ptr () -> IO CInt
+foreign import ccall unsafe "alch_buf_ring"            c_bufRing         :: Ptr AlchBuf -> Ptr (Ptr AlchRing) -> IO CInt
+foreign import ccall unsafe "alch_ring_device"         c_ringDevice      :: Ptr AlchRing -> Ptr CInt -> Ptr (Ptr ()) -> IO CInt
 foreign import ccall safe   "alch_ring_share_stream"   c_ringShareStream :: Ptr AlchRing -> Ptr AlchRing -> IO CInt
 foreign import ccall unsafe "alch_ring_set_option"     c_ringSetOption   :: Ptr AlchRing -> CString -> CLong -> IO CInt
 foreign import ccall safe   "alch_sync"                c_sync            :: Ptr AlchRing -> IO CInt

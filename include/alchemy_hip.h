@@ -198,6 +198,10 @@ int alch_buf_elems(const alch_buf *buf, size_t *n_elems);
  * code on the same GPU -- RCCL collectives that gather result batches, a caller's own kernels.
  * Work queued on the ring's stream must be ordered against the consumer by the caller (alch_sync or events). */
 int alch_buf_device_ptr(const alch_buf *buf, void **ptr, size_t *bytes);
+/* The ring a buffer belongs to, and the HIP device / stream a ring queues its work on: what other device code on the same GPU
+ * needs to order itself against the library (include/alchemy_rccl.h queues its collectives on that stream). */
+int alch_buf_ring(const alch_buf *buf, alch_ring **ring);
+int alch_ring_device(const alch_ring *ring, int *device, void **hip_stream);
 int alch_buf_upload(alch_buf *buf, size_t first, size_t count, const int64_t *host);
 int alch_buf_download(const alch_buf *buf, size_t first, size_t count, int64_t *host);
 /* Synthetic residues: word (e,j,k) = splitmix64(seed + ((e*L + j)*n + k)) mod q_j  (oracle:
