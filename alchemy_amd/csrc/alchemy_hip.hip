@@ -561,6 +561,128 @@ __global__ void k_hint_mac_e(DevRing<W> R, W* out, const W* digits, const W* hin
     }
 }
 
+// Round 4: the tunnel's hint inner product with lazy 64-bit accumulation, and evalLin's constant term as its starting value.
+//
+// k_hint_mac_e spends 7 VALU instructions per (slot, digit, hint row): a Montgomery product (3), its conditional subtraction, the
+// addition and the sum's conditional subtraction.  On the hops whose digits were transformed in E' (every S' slot re-reads an E'
+// entry but multiplies it by its OWN hint word) that made the kernel VALU-bound: 5.7 10^11 slot-piece-digits/s x 56 lane
+// instructions is 82 % of the chip's integer issue rate on Tunnel.hs's first hop, while the digits arrive at 2.3 TB/s, half of
+// what a copy moves (profiles/r04_tunnel_hs_kernel_stats_before.csv).  Here a group of K products is summed in 64 bits and reduced
+// once: with t the running sum in [0, 2q), acc = t * (R mod q) + sum_{K} x h stays below q 2^32 as long as (K + 2) q < 2^32, and one
+// Montgomery reduction of acc is again the running sum in [0, 2q).  K = floor((2^32 - 1) / q) - 2: 5 for Tunnel.hs's moduli
+// (examples/Tunnel.hs:34-39, ~2^29), 3 for HomomRLWR's three rounding moduli, 0 for its 30.5-bit ones -- those limbs keep the
+// product-at-a-time form.  Per (slot, digit, row): (K + 1 + 3) / K instructions = 1.8 at K = 5.  Same residues: the sum is the
+// same element of Z_q, reduced to [0, q) at the end.
+// lin != null: c0' starts from sum_i crt(x0_i) y_i (evalLin on the constant term, what k_tunnel_lin computed into `out` in a pass
+// of its own) and c1' from zero -- one kernel launch, one write and one read of the output ciphertexts less per tunnel.
+template <int TILE>
+__global__ void __launch_bounds__(256) k_tunnel_mac_e(DevRing<u32> R, u32* out, const u32* digits, const u32* hint, size_t nct, u32 D, u32 grp, u32 hskip,
+                                                      const u32* slot_e, u32 n_d, const u32* x0crt, const u32* lin, u32 d_rel, u32 Lx, u32 xoff) {
+    typedef u32 W;
+    typedef typename Vec4<W>::type V;
+    constexpr int VL = 4;
+    const size_t n = (size_t)R.n;
+    const size_t Ln = (size_t)R.L * n;
+    const size_t ntile = (nct + TILE - 1) / TILE;
+    const size_t nv = n / VL;
+    ALCH_WALK_INIT(nv, R.L);
+    ALCH_WALK(w, ntile * (size_t)R.L * nv, wk) {
+        const size_t ct0 = wk.outer * TILE, rem = (size_t)wk.mid * n + (size_t)wk.k * VL;
+        const u32 limb = wk.mid;
+        const W q = R.mod[limb].q, qni = R.mod[limb].qni;
+        const u32 se = slot_e[(size_t)wk.k * VL];
+        const u32 kmax = 0xFFFFFFFFu / q;                       // (K + 2) q < 2^32
+        const u32 K = kmax >= 4 ? (kmax - 2 > 8 ? 8u : kmax - 2) : 0u;
+        const bool lazy = K >= 2;
+        const W r1 = lazy ? R.mod[limb].r1 : (W)1;            // not lazy: the accumulators hold the running sum itself, in [0, q)
+        u64 a0[TILE][VL], a1[TILE][VL];
+        const W* dv[TILE];
+        // starting values, as acc = value * (R mod q) < q^2
+#pragma unroll
+        for (int c = 0; c < TILE; ++c) {
+            const size_t ct = ct0 + c < nct ? ct0 + c : ct0;   // a dead lane of the tile recomputes ciphertext ct0 and stores nothing
+            dv[c] = digits + (ct * (size_t)D * R.L + limb) * (size_t)n_d + se;
+            if (lin) {
+#pragma unroll
+                for (int e = 0; e < VL; ++e) { a0[c][e] = 0; a1[c][e] = 0; }
+                if (limb >= xoff) {
+                    for (u32 i = 0; i < d_rel; ++i) {
+                        const V x = *reinterpret_cast<const V*>(x0crt + ((ct * d_rel + i) * (size_t)Lx + (limb - xoff)) * (size_t)n_d + se);
+                        const V y = *reinterpret_cast<const V*>(lin + (size_t)i * Ln + rem);
+#pragma unroll
+                        for (int e = 0; e < VL; ++e) {
+                            const W t = csub(mont_mul_lazy(x[e], y[e], q, qni), q);
+                            a0[c][e] = (u64)csub((W)((W)a0[c][e] + t), q);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < VL; ++e) a0[c][e] = a0[c][e] * r1;
+                }
+            } else {
+                const V o0 = *reinterpret_cast<const V*>(out + 2 * ct * Ln + rem);
+                const V o1 = *reinterpret_cast<const V*>(out + (2 * ct + 1) * Ln + rem);
+#pragma unroll
+                for (int e = 0; e < VL; ++e) { a0[c][e] = (u64)o0[e] * r1; a1[c][e] = (u64)o1[e] * r1; }
+            }
+        }
+        const size_t dstep = (size_t)R.L * n_d;
+        auto redc = [&](u64 t) -> W { const W m = (W)t * qni; return (W)((t + (u64)m * q) >> 32); };     // t < q 2^32 -> [0, 2q)
+        if (lazy) {
+            for (u32 d0 = 0; d0 < D; d0 += K) {
+                const u32 dend = d0 + K < D ? d0 + K : D;
+                for (u32 d = d0; d < dend; ++d) {
+                    const u32 hd = hskip ? d + (d / grp + 1) * hskip : d;
+                    const V h0 = *reinterpret_cast<const V*>(hint + (size_t)(2 * hd) * Ln + rem);
+                    const V h1 = *reinterpret_cast<const V*>(hint + (size_t)(2 * hd + 1) * Ln + rem);
+#pragma unroll
+                    for (int c = 0; c < TILE; ++c) {
+                        const V x = *reinterpret_cast<const V*>(dv[c] + (size_t)d * dstep);
+#pragma unroll
+                        for (int e = 0; e < VL; ++e) {
+                            a0[c][e] += (u64)x[e] * h0[e];
+                            a1[c][e] += (u64)x[e] * h1[e];
+                        }
+                    }
+                }
+                if (dend < D) {                                 // carry the running sum into the next group: t (R mod q) < 2 q^2
+#pragma unroll
+                    for (int c = 0; c < TILE; ++c)
+#pragma unroll
+                        for (int e = 0; e < VL; ++e) { a0[c][e] = (u64)redc(a0[c][e]) * r1; a1[c][e] = (u64)redc(a1[c][e]) * r1; }
+                }
+            }
+        } else {
+            // moduli too close to 2^31 for a lazy group: one reduction per product, running sum as acc = t (R mod q)
+            for (u32 d = 0; d < D; ++d) {
+                const u32 hd = hskip ? d + (d / grp + 1) * hskip : d;
+                const V h0 = *reinterpret_cast<const V*>(hint + (size_t)(2 * hd) * Ln + rem);
+                const V h1 = *reinterpret_cast<const V*>(hint + (size_t)(2 * hd + 1) * Ln + rem);
+#pragma unroll
+                for (int c = 0; c < TILE; ++c) {
+                    const V x = *reinterpret_cast<const V*>(dv[c] + (size_t)d * dstep);
+#pragma unroll
+                    for (int e = 0; e < VL; ++e) {
+                        a0[c][e] = (u64)csub((W)((W)a0[c][e] + csub(mont_mul_lazy(x[e], h0[e], q, qni), q)), q);
+                        a1[c][e] = (u64)csub((W)((W)a1[c][e] + csub(mont_mul_lazy(x[e], h1[e], q, qni), q)), q);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < TILE; ++c) {
+            if (ct0 + c >= nct) continue;
+            V r0, r1v;
+#pragma unroll
+            for (int e = 0; e < VL; ++e) {
+                r0[e] = lazy ? csub(redc(a0[c][e]), q) : (W)a0[c][e];
+                r1v[e] = lazy ? csub(redc(a1[c][e]), q) : (W)a1[c][e];
+            }
+            *reinterpret_cast<V*>(out + 2 * (ct0 + c) * Ln + rem) = r0;
+            *reinterpret_cast<V*>(out + (2 * (ct0 + c) + 1) * Ln + rem) = r1v;
+        }
+    }
+}
+
 // Rescale (a,b) -> b: dst limb j-1 = q_0^-1 (src_j - reduce(lift src_0)).  q0inv_m[j] = q_0^-1 mod q_j (Montgomery).
 template <typename W>
 __global__ void k_rescale_drop0(DevRing<W> R, const W* src, W* dst, size_t elems, Scal<W> q0inv_m) {
@@ -1126,6 +1248,7 @@ extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) 
     else if (k == "rs_half") r->opts.rs_half = value != 0;
     else if (k == "tunnel_ep") r->opts.tunnel_ep = value != 0;
     else if (k == "gen_fused") r->opts.gen_fused = value != 0;
+    else if (k == "tunnel_mac") r->opts.tunnel_mac = value != 0;
     else if (k == "tunnel_fused") { if (value < 0 || (value != 0 && value != 2 && value != 4)) return fail(ALCH_E_INVALID, "tunnel_fused: 0 (composed), 2 or 4 (digits side by side)"); r->opts.tunnel_fused = (int)value; }
     else if (k == "gen_nt") {
         if (value != 0 && value != 128 && value != 256 && value != 512) return fail(ALCH_E_INVALID, "gen_nt must be 0 (by ring size), 128, 256 or 512");
@@ -2911,9 +3034,13 @@ static int do_tunnel(const alch_tunnel* t, alch_ring* rin, const void* in, void*
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("tunnel crt launch: ") + hipGetErrorString(e));
         } else if ((rc = do_crt<W>(rx, x0, 0, now * D, false, nullptr, rs->stream)) != ALCH_OK) return rc;
         W* po = reinterpret_cast<W*>(reinterpret_cast<char*>(out) + done * 2 * ebs);
-        ALCH_LAUNCH_VW(k_tunnel_lin, rs, now * elem_words(rs), rs->stream, dev_ring<W>(rs), po, (const W*)x0,
+        // k_tunnel_mac_e starts its accumulators from evalLin's constant term itself: no pass for it then
+        const bool mac_e = sizeof(W) == 4 && !fused && slot_e && t->pieces_ok && rs->n % 4 == 0 && rs->opts.tunnel_mac;
+        if (!mac_e) {
+            ALCH_LAUNCH_VW(k_tunnel_lin, rs, now * elem_words(rs), rs->stream, dev_ring<W>(rs), po, (const W*)x0,
                            (const W*)t->lin, D, now, Lx, xoff, slot_e, rx->n);
-        HIP_TRY(hipGetLastError());
+            HIP_TRY(hipGetLastError());
+        }
         // linear term: decompose + reduce + crt of every embedded coefficient, inner product with the hints
         if (fused) {                                  // one kernel, no digits in HBM (k_gen_tunnel_ks)
             if constexpr (sizeof(W) == 4) {
@@ -2941,8 +3068,16 @@ static int do_tunnel(const alch_tunnel* t, alch_ring* rin, const void* in, void*
             hipError_t e = gen_dispatch(g);
             if (e != hipSuccess) return fail(ALCH_E_HIP, std::string("tunnel crt_digits launch: ") + hipGetErrorString(e));
         }
-        launch_hint_mac<W>(rs, rs->stream, po, (const W*)dig, (const W*)t->ks, now, D * GD, (const W*)nullptr, Lx, compact ? (u32)dup : 0u,
-                           slot_e, rx->n, t->pieces_ok);
+        if (mac_e) {
+            if constexpr (sizeof(W) == 4) {
+                const size_t pieces = (now + 3) / 4 * (size_t)rs->L * (rs->n / 4);
+                hipLaunchKernelGGL((k_tunnel_mac_e<4>), dim3(ew_grid(pieces)), dim3(256), 0, rs->stream, rs->d32, (u32*)po, (const u32*)dig, (const u32*)t->ks,
+                                   now, D * GD, Lx, compact ? (u32)dup : 0u, slot_e, rx->n, (const u32*)x0, (const u32*)t->lin, D, Lx, xoff);
+            }
+        } else {
+            launch_hint_mac<W>(rs, rs->stream, po, (const W*)dig, (const W*)t->ks, now, D * GD, (const W*)nullptr, Lx, compact ? (u32)dup : 0u,
+                               slot_e, rx->n, t->pieces_ok);
+        }
         HIP_TRY(hipGetLastError());
     }
     return ALCH_OK;

@@ -89,6 +89,7 @@ struct LaunchOpts {
     int gen_fused = 1;       // general index: 1 = fused tensor + key switch kernels (kernel_gen.hpp).  Round 2 measured 0.69-0.82x the composed
                              // path (48 accumulators + the CRT_13 pass matrices in VGPRs spilled); with the pass matrices in SGPRs (round 3) the
                              // kernel needs 127 VGPRs, no scratch: 1.13x on H5', 1.24x on H3', 1.08x on H1', 0.99x on H0'  (key switch, L = 4)
+    bool tunnel_mac = true;  // alch_ct_tunnel, E'-level digits: hint inner product with lazy 64-bit accumulation, evalLin's constant term as its start (k_tunnel_mac_e); 0 = k_tunnel_lin + k_hint_mac_e
     int tunnel_fused = 0;    // alch_ct_tunnel (TrivGad, E'-level transforms): 2 or 4 = digit transforms + hint products in one kernel with that many
                              // digits side by side per workgroup (k_gen_tunnel_ks); 0 = k_gen_crt_digits + k_hint_mac_v through HBM.  Measured on the
                              // HomomRLWR pipeline (round 3): 41.7 k ringRounds/s composed, 41.2 k fused (hop 1: 2.17 -> 2.36 ms, hop 3: 3.75 -> 4.1 ms,

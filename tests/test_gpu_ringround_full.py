@@ -35,7 +35,7 @@ def test_ringround_pipeline_at_the_reference_parameters(oracle_lib):
         assert np.array_equal(got[2 * ct], want[0]) and np.array_equal(got[2 * ct + 1], want[1]), ct
 
 
-@pytest.mark.parametrize("B,opts", [(70, ()), (33, (("scratch_mib", 64),))])
+@pytest.mark.parametrize("B,opts", [(70, ()), (33, (("scratch_mib", 64),)), (41, (("tunnel_mac", 0),))])
 def test_ringround_pipeline_ragged_batch_checksum(B, opts):
     ref = load_golden("batch_checksums.json")["homomrlwr"]
     assert ref["batch"] >= B

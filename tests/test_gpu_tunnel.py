@@ -54,14 +54,17 @@ def test_tunnel_hop_matches_the_oracle(oracle_lib, rp, sp, L, batch):
     # tunnel_ep = 1 (default): the embedded E'-coefficients are transformed at dimension phi(e') and read through the embedCRT slot
     # table; 0: embedded into S' first and transformed there
     # tunnel_fused: digit transforms + hint products in one kernel (2 or 4 digits side by side), or through HBM (0)
-    for ep_level, fused in ((1, 2), (1, 4), (1, 0), (0, 2)):
+    # tunnel_mac (round 4): the hint inner product with lazy 64-bit groups starting from evalLin's constant term (1, default), or
+    # k_tunnel_lin + one Montgomery product at a time (0)
+    for ep_level, fused, mac in ((1, 2, 1), (1, 4, 1), (1, 0, 1), (1, 0, 0), (0, 2, 1)):
         gs.set_option("tunnel_ep", ep_level)
         gs.set_option("tunnel_fused", fused)
+        gs.set_option("tunnel_mac", mac)
         tun = A.Tunnel(gr, gs, gs.upload(lin), gs.upload(ks))
         tun.apply(gin, gout, batch, s_pre=s_pre)
         got = gout.download()
         for ct in range(batch):
-            assert np.array_equal(got[2 * ct], want[ct][0]) and np.array_equal(got[2 * ct + 1], want[ct][1]), (ct, ep_level, fused)
+            assert np.array_equal(got[2 * ct], want[ct][0]) and np.array_equal(got[2 * ct + 1], want[ct][1]), (ct, ep_level, fused, mac)
 
 
 @pytest.mark.parametrize("rp,sp,L,dup,gadget", [(40, 60, 3, 1, "triv"), (63, 105, 4, 2, "triv"), (11648, 29120, 6, 1, "triv"),
@@ -107,9 +110,13 @@ def test_tunnel_hs_hop_with_base2_hints_at_full_size(oracle_lib, k):
     from helpers import load_golden
     from tunnelhops_oracle import HopOracle
     B = 37
+    old = Hop(k, B, (("tunnel_mac", 0),))                 # the round-3 kernels (k_tunnel_lin + k_hint_mac_e): same words
+    old_sum = old.run().checksum(0, 2 * B)
+    del old
     hop = Hop(k, B)
     res = hop.run()
     hop.rs.sync()
+    assert res.checksum(0, 2 * B) == old_sum
     orc = HopOracle(oracle_lib, k)
     assert (orc.lin, orc.lh, orc.lout, orc.d_rel, orc.D) == (hop.lin, hop.lh, hop.lout, hop.d_rel, hop.D)
     got = res.download(0, 4)

@@ -1,16 +1,17 @@
 #!/usr/bin/env python3
 """BASELINE config 4 at the reference's real parameters: the HomomRLWR ringRound op sequence (alchemy_amd/ringround.py) on a
 batch of ciphertexts resident in HBM.  One JSON line: pipelines per second and the time per stage.
-Usage: tools/bench_homomrlwr.py [batch]"""
+Usage: tools/bench_homomrlwr.py [batch] [name=value ...]      (launch options, e.g. tunnel_mac=0)"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from alchemy_amd.ringround import RingRound
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+B = int(sys.argv[1]) if len(sys.argv) > 1 and "=" not in sys.argv[1] else 1024
 import os
 NT = int(os.environ.get('GEN_NT', '0'))
 TF = os.environ.get('TUNNEL_FUSED')
 opts = ((('gen_nt', NT),) if NT else ()) + ((('tunnel_fused', int(TF)),) if TF is not None else ())
+opts += tuple((a.split("=")[0], int(a.split("=")[1])) for a in sys.argv[1:] if "=" in a)
 rr = RingRound(B, opts)
 secs, out = rr.measure(passes=2)
 rr.stages.clear()

@@ -10,12 +10,15 @@ from alchemy_amd import capi
 
 QS = [537264001, 539884801, 555609601, 560851201, 566092801]          # examples/Tunnel.hs:34-39, Zqs order
 HP = [11648, 29120, 43680, 54600, 27300, 20475]
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+B = int(sys.argv[1]) if len(sys.argv) > 1 and "=" not in sys.argv[1] else 2048
+OPTS = [(a.split("=")[0], int(a.split("=")[1])) for a in sys.argv[1:] if "=" in a]        # launch options, e.g. tunnel_mac=0
 
 _rings = {}
 def ring(m, L):
     if (m, L) not in _rings:
         _rings[(m, L)] = A.Ring(m, list(reversed(QS[:L])))
+        for k_, v_ in OPTS:
+            _rings[(m, L)].set_option(k_, v_)
     return _rings[(m, L)]
 
 p, tuns = 0, []
