@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(256) k_tunnel_mac_e(DevRing<u32> R, u32* out, 
         const size_t ct0 = wk.outer * TILE, rem = (size_t)wk.mid * n + (size_t)wk.k * VL;
         const u32 limb = wk.mid;
         const W q = R.mod[limb].q, qni = R.mod[limb].qni;
-        const u32 se = slot_e[(size_t)wk.k * VL];
+        const u32 se = slot_e ? slot_e[(size_t)wk.k * VL] : wk.k * (u32)VL;      // no slot table: the digits were transformed in S' itself
         const u32 kmax = 0xFFFFFFFFu / q;                       // (K + 2) q < 2^32
         const u32 K = kmax >= 4 ? (kmax - 2 > 8 ? 8u : kmax - 2) : 0u;
         const bool lazy = K >= 2;
@@ -3035,7 +3035,7 @@ static int do_tunnel(const alch_tunnel* t, alch_ring* rin, const void* in, void*
         } else if ((rc = do_crt<W>(rx, x0, 0, now * D, false, nullptr, rs->stream)) != ALCH_OK) return rc;
         W* po = reinterpret_cast<W*>(reinterpret_cast<char*>(out) + done * 2 * ebs);
         // k_tunnel_mac_e starts its accumulators from evalLin's constant term itself: no pass for it then
-        const bool mac_e = sizeof(W) == 4 && !fused && slot_e && t->pieces_ok && rs->n % 4 == 0 && rs->opts.tunnel_mac;
+        const bool mac_e = sizeof(W) == 4 && !fused && (slot_e ? t->pieces_ok : true) && rs->n % 4 == 0 && rx->n % 4 == 0 && rs->opts.tunnel_mac;
         if (!mac_e) {
             ALCH_LAUNCH_VW(k_tunnel_lin, rs, now * elem_words(rs), rs->stream, dev_ring<W>(rs), po, (const W*)x0,
                            (const W*)t->lin, D, now, Lx, xoff, slot_e, rx->n);

@@ -23,7 +23,7 @@ out = {"collected": time.strftime("%Y-%m-%d"), "kernel_src_sha16": kernel_src_sh
        "commands": open(os.path.join(d, "commands.txt")).read().splitlines() if os.path.exists(os.path.join(d, "commands.txt")) else [],
        "note": "counter totals over all dispatches of the kernel in the pass; durations from the kernel trace of the same pass (counter "
                "collection serialises dispatches and slows them: use the ratios, not the rates); clock assumed 2.4 GHz", "workloads": {}}
-for wl in ("headline", "general", "homomrlwr"):
+for wl in ("headline", "full_mul", "general", "homomrlwr", "tunnel_hs"):
     ctr = defaultdict(lambda: defaultdict(float))
     disp = defaultdict(int)
     for path in glob.glob(os.path.join(d, "**", f"{wl}_counter_collection.csv"), recursive=True):
