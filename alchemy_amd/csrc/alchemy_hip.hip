@@ -2270,6 +2270,7 @@ static int do_mul_relin(alch_ring* r, const alch_hint* hint, const void* a, cons
     c.balanced = r->balanced;
     c.opts = r->opts;
     c.q30 = r->q30 && r->opts.q30;
+    c.partials = true;                              // read by ALCH_A_PARTIALS builds only (kernel_tensor_split.hpp)
     scal_to_mont<W>(r, s_pre, 2, c.spre_r2);
     const size_t ct_words = 2 * elem_words(r);
     const bool two = batch > chunk && !r->one_stream;

@@ -29,6 +29,9 @@
 #ifndef ALCH_KS_HINT_DEPTH
 #define ALCH_KS_HINT_DEPTH 5
 #endif
+#ifndef ALCH_A_PARTIALS
+#define ALCH_A_PARTIALS 0
+#endif
 // Ablation switches (ALCH_EXP_FLAGS; wrong results, timing only) exist in -DALCH_ABLATE builds alone: in the product
 // kernel they cost real instructions (the compiler hoists e.g. the "skip the tensor part" zero-fill in front of the branch).
 #ifdef ALCH_ABLATE
@@ -247,6 +250,31 @@ k_ks_accum_half(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict
     const u32 hstride = (u32)L * ROW;
 
     KS_STAMP_INIT();
+#if ALCH_A_PARTIALS
+    if constexpr (!UP && !Q30) {
+        // experiment (kernel_tensor_split.hpp, ALCH_A_PARTIALS): the starting values were formed by the tensor kernel and wait in the
+        // result rows -- two loads per slice instead of six, no products
+        const u32 o0 = ((2 * cti) * (u32)L + (u32)j) * ROW + slot0, o1 = ((2 * cti + 1) * (u32)L + (u32)j) * ROW + slot0;
+        V st[2][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const u32 so = SLICE * (u32)((s + rot) & (EPT / 4 - 1));
+            st[s][0] = buf_ld16(ro, lane16, o0 + so); st[s][1] = buf_ld16(ro, lane16, o1 + so);
+        }
+        flush_stores();                       // previous item's results: behind this item's first loads
+#pragma unroll
+        for (int s = 2; s < EPT / 4; ++s) {
+            const u32 so = SLICE * (u32)((s + rot) & (EPT / 4 - 1));
+            const V v0 = buf_ld16(ro, lane16, o0 + so), v1 = buf_ld16(ro, lane16, o1 + so);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc0[s * 4 + e] = v0[e]; acc1[s * 4 + e] = v1[e]; }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc0[s * 4 + e] = st[s][0][e]; acc1[s * 4 + e] = st[s][1][e]; }
+    } else
+#endif
     {   // c0, c1 and the diagonal digit (i == j): d_j = c2_j (mod q_j), no transform needed.
         // Eight 4-coefficient slices, software-pipelined: the six 16-byte loads of slice s+1 are in flight
         // while slice s is multiplied out (issuing them one slice at a time exposed the HBM latency eight

@@ -21,13 +21,25 @@
 #define ALCH_TI_NT_IN 0
 #endif
 
+// experiment (tools/build_variant.sh partials -DALCH_A_PARTIALS=1): this kernel also forms the key-switch
+// kernel's starting values c0 = a0 b0 s + c2 h0_i, c1 = (a0 b1 + a1 b0) s + c2 h1_i for its limb (it holds a1, b1 and c2 anyway) and
+// writes them to the result rows, so that the key-switch kernel reads two finished polynomials instead of four cold operands and
+// two hint rows at the head of every item.  Measured, see DESIGN.md "dead ends"; off in the product.
+#ifndef ALCH_A_PARTIALS
+#define ALCH_A_PARTIALS 0
+#endif
+
 namespace alch {
 
 // Q30: every modulus below 2^30 -- 8-instruction inverse butterflies (bfly_inv4); values stay in [0,2q) as otherwise
 template <int LOGN, bool Q30 = false>
 __global__ void __launch_bounds__(1 << (LOGN - 6), 4)
 k_tensor_intt_split(DevRing<u32> R, const u32* __restrict__ a, const u32* __restrict__ b, int32_t* __restrict__ digits,
-                    unsigned nitems, Scal<u32> spre) {
+                    unsigned nitems, Scal<u32> spre
+#if ALCH_A_PARTIALS
+                    , const u32* __restrict__ hint, u32* __restrict__ out
+#endif
+                    ) {
     typedef u32 W;
     constexpr int LOGM = LOGN - 1, M = 1 << LOGM, LT = LOGN - 6, T = 1 << LT;
     typedef Geo<LOGM, LT> G;
@@ -44,6 +56,10 @@ k_tensor_intt_split(DevRing<u32> R, const u32* __restrict__ a, const u32* __rest
     const auto rd = __builtin_amdgcn_make_buffer_rsrc(digits, 0, (u32)((size_t)nct * L * (2 * M) * 4), 0x00020000);
     const u32 lane16 = threadIdx.x * 16u;
     constexpr u32 ROW = (u32)(2 * M) * 4u, SLICE = (u32)T * 16u, HALF = (u32)M * 4u;
+#if ALCH_A_PARTIALS
+    const auto rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<W*>(hint), 0, (u32)((size_t)2 * L * L * (2 * M) * 4), 0x00020000);
+    const auto ro = __builtin_amdgcn_make_buffer_rsrc(out, 0, (u32)((size_t)nct * 2 * L * (2 * M) * 4), 0x00020000);
+#endif
 
     for (unsigned item = blockIdx.x; item < nitems; item += gridDim.x) {
         const u32 ct = item / (unsigned)L, i = item % (unsigned)L;
@@ -65,6 +81,36 @@ k_tensor_intt_split(DevRing<u32> R, const u32* __restrict__ a, const u32* __rest
                 const u32 so = row + (u32)half * HALF + SLICE * (u32)((r + rot) & (NV - 1));
                 const V va = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(ra, lane16, so, ALCH_TI_NT_IN));
                 const V vb = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rb, lane16, so, ALCH_TI_NT_IN));
+#if ALCH_A_PARTIALS
+                if (out) {   // the key-switch kernel's tensor part for this limb, with its very formulas (kernel_ks_half.hpp)
+                    const u32 so0 = so - (u32)L * ROW;                                  // a0 / b0: the element in front of a1 / b1
+                    const u32 piece = (u32)half * HALF + SLICE * (u32)((r + rot) & (NV - 1));
+                    const u32 hrow = ((2 * i) * (u32)L + i) * ROW + piece;               // hint row (digit i, component 0, limb i)
+                    const V a0v = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(ra, lane16, so0, ALCH_TI_NT_IN));
+                    const V b0v = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rb, lane16, so0, ALCH_TI_NT_IN));
+                    const V h0v = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rh, lane16, hrow, 0));
+                    const V h1v = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rh, lane16, hrow + (u32)L * ROW, 0));
+                    const W sr2 = spre.v[i];
+                    V o0v, o1v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const W x0 = csub(mont_mul_lazy(a0v[e], sr2, q, qni), q);
+                        const W x1 = csub(mont_mul_lazy(va[e], sr2, q, qni), q);
+                        const W c2 = csub(mont_mul_lazy(vb[e], x1, q, qni), q);
+                        const u64 p0 = (u64)x0 * b0v[e] + (u64)c2 * h0v[e];
+                        const u32 m0 = (u32)p0 * qni;
+                        o0v[e] = csub((u32)((p0 + (u64)m0 * q) >> 32), q);
+                        const u64 p1 = (u64)x0 * vb[e] + (u64)x1 * b0v[e] + (u64)c2 * h1v[e];
+                        const u64 p1r = ((u64)csub((W)(p1 >> 32), q) << 32) | (u32)p1;
+                        const u32 m1 = (u32)p1r * qni;
+                        o1v[e] = csub((u32)((p1r + (u64)m1 * q) >> 32), q);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(ro, 0, 0, 0)), o0v), ro, lane16, so0, 0);
+                    ALCH_STORE_GUARD(o0v);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(decltype(__builtin_amdgcn_raw_buffer_load_b128(ro, 0, 0, 0)), o1v), ro, lane16, so, 0);
+                    ALCH_STORE_GUARD(o1v);
+                }
+#endif
                 V v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = mont_mul_lazy(va[e], vb[e], q, qni);

@@ -117,6 +117,7 @@ struct NttCall {
     // OP_CRT / OP_CRTINV
     W* data;
     const W* src;          // null: in place
+    bool partials = false; // ALCH_A_PARTIALS builds: the tensor kernel also writes the key-switch kernel's starting values into `out`
     size_t first_poly, npoly;
     // fused kernels
     const W* a;
@@ -565,8 +566,13 @@ inline hipError_t run_call(const NttCall<W>& c) {
                 if ((e = set_lds(k, half_lds)) != hipSuccess) return e;
                 const unsigned nitems = (unsigned)(c.nct * (size_t)R.L);
                 const unsigned grid = split > 1 && (unsigned)split < nitems ? (unsigned)split : nitems;
+#if ALCH_A_PARTIALS
+                hipLaunchKernelGGL(k, dim3(grid), dim3(1 << (LOGN - 6)), half_lds, c.stream, R, c.a, c.b, (int32_t*)c.digits, nitems,
+                                   c.spre_r2, c.hint, c.partials ? c.out : nullptr);   // only alch_ct_mul_relin's launch pair asks for them
+#else
                 hipLaunchKernelGGL(k, dim3(grid), dim3(1 << (LOGN - 6)), half_lds, c.stream, R, c.a, c.b, (int32_t*)c.digits, nitems,
                                    c.spre_r2);
+#endif
                 break;
             }
         }

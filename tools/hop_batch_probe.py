@@ -1,5 +1,5 @@
 import sys, json
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 from alchemy_amd.tunnelhops import Hop
 for B in (256, 1024, 2048):
     rates = []

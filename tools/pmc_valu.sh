@@ -8,7 +8,7 @@
 #   general    tools/bench_general.py 20475                        (k_gen_crt, k_gen_crt_digits, k_hint_mac_v, k_tensor_ew, ...)
 #   homomrlwr  tools/bench_homomrlwr.py 1024                       (the whole ringRound pipeline)
 # tools/pmc_valu_summary.py turns the CSVs into profiles/${tag}_pmc_valu.json.
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/pmc_$tag
 mkdir -p "$out"

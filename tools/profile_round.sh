@@ -9,7 +9,7 @@
 #   6. the HomomRLWR pipeline (config 4) under --kernel-trace --stats                             -> ${tag}_homomrlwr_kernel_stats.csv
 #   7. the measurement tools themselves (no profiler): general indices, pipeline, Tunnel.hs hops, config 2, other paths -> ${tag}_*.jsonl
 # Counters run in their own passes, never together with --stats or an API trace.  The program after `--` is python3 itself.
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
