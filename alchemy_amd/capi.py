@@ -27,7 +27,7 @@ SYMBOLS = [
     "alch_mul", "alch_add", "alch_sub", "alch_scale", "alch_mulg_pow", "alch_mulg_dec", "alch_mulg_crt",
     "alch_divg_pow", "alch_divg_dec", "alch_divg_crt", "alch_decompose_triv", "alch_buf_alloc", "alch_buf_free",
     "alch_buf_elems", "alch_buf_upload", "alch_buf_download", "alch_buf_fill_uniform", "alch_buf_crt",
-    "alch_buf_crtinv", "alch_buf_mul", "alch_buf_add", "alch_buf_checksum", "alch_hint_load", "alch_hint_from_buf",
+    "alch_buf_crtinv", "alch_buf_mul", "alch_buf_add", "alch_buf_checksum", "alch_buf_checksum_at", "alch_hint_load", "alch_hint_from_buf",
     "alch_hint_free", "alch_ct_mul_relin", "alch_buf_rescale_drop0", "alch_buf_sub", "alch_buf_scale",
     "alch_buf_decompose_triv", "alch_buf_rescale_add0", "alch_decompose_base2", "alch_ct_mul_full", "alch_buf_device_ptr",
     "alch_ring_set_option", "alch_ring_create_nocrt", "alch_l", "alch_linv", "alch_buf_l", "alch_buf_linv", "alch_buf_mulg",
@@ -137,6 +137,7 @@ def load_library():
         "alch_buf_mul": [VP, VP, VP, C.c_size_t],
         "alch_buf_add": [VP, VP, VP, C.c_size_t],
         "alch_buf_checksum": [VP, C.c_size_t, C.c_size_t, PU64],
+        "alch_buf_checksum_at": [VP, C.c_size_t, C.c_size_t, C.c_uint64, PU64],
         "alch_hint_load": [VP, C.c_int, P64, C.POINTER(VP)],
         "alch_hint_from_buf": [VP, C.c_int, VP, C.POINTER(VP)],
         "alch_hint_free": [VP],
@@ -531,9 +532,10 @@ class Buf:
     def coeffs_from(self, src_big: "Buf", count: int):
         _check(self.ring._l.alch_buf_coeffs(self._h, src_big._h, count))
 
-    def checksum(self, first: int = 0, count: int | None = None) -> int:
+    def checksum(self, first: int = 0, count: int | None = None, position: int = 0) -> int:
+        """position: element index of `first` in the whole batch this buffer is a part of (alch_buf_checksum_at)."""
         s = C.c_uint64()
-        _check(self.ring._l.alch_buf_checksum(self._h, first, self.n_elems - first if count is None else count, C.byref(s)))
+        _check(self.ring._l.alch_buf_checksum_at(self._h, first, self.n_elems - first if count is None else count, position, C.byref(s)))
         return int(s.value)
 
     def rescale_drop0_into(self, dst: "Buf", count: int):

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -32,6 +33,15 @@ struct ExtTab {
     int32_t* fibres = nullptr;         // [n_small][fibre]: CRT slots of the big ring above a slot of the small ring (twaceCRT)
 };
 
+struct StreamOwner {
+    hipStream_t s;
+    int device;
+    StreamOwner(hipStream_t s_, int d) : s(s_), device(d) {}
+    ~StreamOwner() { if (s) { (void)hipSetDevice(device); (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } }
+    StreamOwner(const StreamOwner&) = delete;
+    StreamOwner& operator=(const StreamOwner&) = delete;
+};
+
 struct alch_ring {
     u32 m = 0, n = 0;
     int logn = 0, L = 0, word = 0;            // word = 4 or 8 bytes per residue on the device
@@ -39,7 +49,10 @@ struct alch_ring {
     bool balanced = false;
     bool q30 = false;                          // 32-bit words and every modulus below 2^30 (4q fits a word)
     hipStream_t stream = nullptr;
-    bool own_stream = false;
+    // Owner of `stream` when the library created it: shared by every ring that borrowed the stream through alch_ring_share_stream, so
+    // the stream outlives the ring that created it for as long as another ring still queues on it (rings are destroyed in any order --
+    // a garbage-collected host gives none).  Null when the stream is the caller's (alch_ring_set_stream).
+    std::shared_ptr<StreamOwner> stream_owner;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void* tables = nullptr;                    // all twiddle tables, one allocation
     void* tables_p = nullptr;                  // Plantard forward constants (32-bit rings) / Shoup pairs (64-bit rings)
@@ -156,7 +169,7 @@ static int fail(int code, const std::string& msg) {
     } while (0)
 
 extern "C" const char* alch_last_error(void) { return g_err.c_str(); }
-extern "C" uint32_t alch_version(void) { return (1u << 16) | 5u; }   // 1.5: device-resident Tensor values (alch_buf_tensor_op, alch_buf_copy, alch_ring_share_stream, pooled small buffers, pinned staging), status order of alch_ring_create; 1.4: general cyclotomic indices, l / lInv, real mulG / divG, mulPublic / addPublic, alch_ring_set_option; 1.3: + alch_decompose_base2, BaseBGad hints, alch_ct_mul_full, alch_buf_device_ptr, n = 2^16
+extern "C" uint32_t alch_version(void) { return (1u << 16) | 6u; }   // 1.6: alch_buf_checksum_at, shared streams owned by their last user; 1.5: device-resident Tensor values (alch_buf_tensor_op, alch_buf_copy, alch_ring_share_stream, pooled small buffers, pinned staging), status order of alch_ring_create; 1.4: general cyclotomic indices, l / lInv, real mulG / divG, mulPublic / addPublic, alch_ring_set_option; 1.3: + alch_decompose_base2, BaseBGad hints, alch_ct_mul_full, alch_buf_device_ptr, n = 2^16
 
 // ------------------------------------------------------------------------------------------------------
 // element-wise kernels (HBM-bound; 16 B per lane, grid-stride, ~2048 workgroups)
@@ -847,10 +860,10 @@ __global__ void k_rescale_up(DevRing<W> Rd, const W* src, W* dst, size_t elems, 
 }
 
 template <typename W>
-__global__ void k_checksum(const W* data, size_t words, u64* sum) {
+__global__ void k_checksum(const W* data, size_t words, u64* sum, u64 w0) {
     u64 acc = 0;
     for (size_t w = blockIdx.x * (size_t)blockDim.x + threadIdx.x; w < words; w += (size_t)gridDim.x * blockDim.x)
-        acc += splitmix64((u64)w ^ ((u64)data[w] << 20));
+        acc += splitmix64(((u64)w + w0) ^ ((u64)data[w] << 20));
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long*)sum, (unsigned long long)acc);
 }
@@ -1156,7 +1169,7 @@ static int ring_create_impl(uint32_t m, int L, const uint64_t* q, bool nocrt, al
     r->device = dev;
     hipError_t e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete r; return fail(ALCH_E_HIP, "hipStreamCreate failed"); }
-    r->own_stream = true;
+    r->stream_owner = std::make_shared<StreamOwner>(r->stream, dev);
     if (hipEventCreate(&r->ev0) != hipSuccess || hipEventCreate(&r->ev1) != hipSuccess) { delete r; return fail(ALCH_E_HIP, "hipEventCreate failed"); }
     if (hipStreamCreateWithFlags(&r->aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -1207,7 +1220,7 @@ extern "C" int alch_ring_destroy(alch_ring* r) {
         if (r->xs[e]) { (void)hipStreamSynchronize(r->xs[e]); (void)hipStreamDestroy(r->xs[e]); }
         if (r->ev_xs[e]) (void)hipEventDestroy(r->ev_xs[e]);
     }
-    if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
+    r->stream_owner.reset();                       // destroys the stream with its last user
     delete r;
     return ALCH_OK;
 }
@@ -1224,9 +1237,8 @@ extern "C" int alch_ring_set_stream(alch_ring* r, void* s) {
     if (!r) return fail(ALCH_E_INVALID, "null ring");
     BIND(r);
     HIP_TRY(hipStreamSynchronize(r->stream));
-    if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
+    r->stream_owner.reset();
     r->stream = (hipStream_t)s;
-    r->own_stream = false;
     return ALCH_OK;
 }
 
@@ -1591,7 +1603,7 @@ extern "C" int alch_buf_mul(alch_buf* d, const alch_buf* a, const alch_buf* b, s
 extern "C" int alch_buf_add(alch_buf* d, const alch_buf* a, const alch_buf* b, size_t count) { return buf_pointwise(d, a, b, count, PW_ADD); }
 extern "C" int alch_buf_sub(alch_buf* d, const alch_buf* a, const alch_buf* b, size_t count) { return buf_pointwise(d, a, b, count, PW_SUB); }
 
-extern "C" int alch_buf_checksum(const alch_buf* b, size_t first, size_t count, uint64_t* sum) {
+static int buf_checksum(const alch_buf* b, size_t first, size_t count, uint64_t position, uint64_t* sum) {
     if (!b || !sum) return fail(ALCH_E_INVALID, "null argument");
     if (first + count > b->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
     alch_ring* r = b->ring;
@@ -1599,13 +1611,16 @@ extern "C" int alch_buf_checksum(const alch_buf* b, size_t first, size_t count, 
     const size_t words = count * elem_words(r);
     const char* base = reinterpret_cast<const char*>(b->dptr) + first * elem_bytes(r);
     HIP_TRY(hipMemsetAsync(r->ws_sum, 0, sizeof(u64), r->stream));
-    if (r->word == 4) hipLaunchKernelGGL((k_checksum<u32>), dim3(ew_grid(words)), dim3(256), 0, r->stream, (const u32*)base, words, r->ws_sum);
-    else hipLaunchKernelGGL((k_checksum<u64>), dim3(ew_grid(words)), dim3(256), 0, r->stream, (const u64*)base, words, r->ws_sum);
+    if (r->word == 4) hipLaunchKernelGGL((k_checksum<u32>), dim3(ew_grid(words)), dim3(256), 0, r->stream, (const u32*)base, words, r->ws_sum, (u64)position * elem_words(r));
+    else hipLaunchKernelGGL((k_checksum<u64>), dim3(ew_grid(words)), dim3(256), 0, r->stream, (const u64*)base, words, r->ws_sum, (u64)position * elem_words(r));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(sum, r->ws_sum, sizeof(u64), hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     return ALCH_OK;
 }
+
+extern "C" int alch_buf_checksum(const alch_buf* b, size_t first, size_t count, uint64_t* sum) { return buf_checksum(b, first, count, 0, sum); }
+extern "C" int alch_buf_checksum_at(const alch_buf* b, size_t first, size_t count, uint64_t position, uint64_t* sum) { return buf_checksum(b, first, count, position, sum); }
 
 // ------------------------------------------------------------------------------------------------------
 // host-buffer Tensor methods: stage one element through a scratch device buffer
@@ -1972,9 +1987,8 @@ extern "C" int alch_ring_share_stream(alch_ring* r, alch_ring* with) {
     if (r == with || r->stream == with->stream) return ALCH_OK;
     BIND(r);
     HIP_TRY(hipStreamSynchronize(r->stream));
-    if (r->own_stream && r->stream) (void)hipStreamDestroy(r->stream);
+    r->stream_owner = with->stream_owner;          // releases r's own stream (destroyed with its last user), keeps with's alive
     r->stream = with->stream;
-    r->own_stream = false;
     return ALCH_OK;
 }
 

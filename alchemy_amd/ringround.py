@@ -24,9 +24,13 @@ def moduli(L):
 
 
 class RingRound:
-    def __init__(self, batch, ring_opts=(), pow_handoff=True):
+    def __init__(self, batch, ring_opts=(), pow_handoff=True, one_stream=True, first=0):
         self.B = batch
+        self.first = first                 # index of this batch's first ciphertext in the whole (seeded) batch: RingRoundLanes
         self.pow_handoff = pow_handoff
+        # one_stream: every ring of the pipeline queues on the first ring's HIP stream (alch_ring_share_stream) -- the op sequence is one
+        # dependency chain, so per-ring streams only add an event record + wait at each of its ~100 ring-to-ring hand-offs
+        self.one_stream = one_stream
         self.rings, self.pool, self.cursor, self.pubs, self.stages = {}, [], 0, {}, {}
         self.ring_opts = tuple(ring_opts)
         # PT2CT's limb counts, resolved backwards from the output pNoise 0
@@ -59,6 +63,8 @@ class RingRound:
             r = Ring(m, moduli(L))
             for k, v in self.ring_opts:
                 r.set_option(k, v)
+            if self.one_stream and self.rings:
+                r.share_stream(next(iter(self.rings.values())))
             self.rings[(m, L)] = r
         return self.rings[(m, L)]
 
@@ -108,7 +114,9 @@ class RingRound:
         r0 = ring(HP[0], L_0)
         self.cursor = 0
         if "x" not in self.pubs:
-            self.pubs["x"] = self.seeded(r0, 2 * B, 1)
+            # word (e, j, k) of the whole batch is splitmix64(1 + ((e L + j) n + k)) mod q_j (alch_buf_fill_uniform): a lane that starts
+            # at ciphertext `first` = element 2 first shifts the seed by the words in front of it
+            self.pubs["x"] = self.seeded(r0, 2 * B, 1 + 2 * self.first * L_0 * r0.n)
         if "pub_msd" not in self.pubs:
             ps = r0.alloc(1)
             ps.scale(public(r0, 2), 1, [pow(P, -1, q) for q in moduli(L_0)])
@@ -178,3 +186,48 @@ class RingRound:
             out = self.run()
         self.sync()
         return (time.perf_counter() - t0) / passes, out
+
+
+class RingRoundLanes:
+    """The same batch as `lanes` contiguous sub-batches, each a RingRound of its own on its own HIP stream (its own rings, hints and
+    scratch; same seeds, so the union of the results is word for word RingRound(batch)'s).  The op sequence of one sub-batch is a
+    single dependency chain of ~130 kernels, half of them memory-bound passes or the thin last wave of a transform grid; a second
+    chain fills those with its own VALU-bound transforms.  Measured on MI355X at 1024 ciphertexts (tools/bench_homomrlwr_dual.py):
+    1 lane 46.6 k pipelines/s, 2 lanes 51.8 k, 4 lanes 48.9 k, 8 lanes 48.2 k -- two is the default, as for the headline's two chunk pipelines."""
+
+    def __init__(self, batch, lanes=2, ring_opts=(), pow_handoff=True):
+        lanes = max(1, min(lanes, batch))
+        sizes = [batch // lanes + (1 if i < batch % lanes else 0) for i in range(lanes)]
+        firsts = [sum(sizes[:i]) for i in range(lanes)]
+        self.B, self.sizes, self.firsts = batch, sizes, firsts
+        self.lanes = [RingRound(b, ring_opts, pow_handoff, True, f) for b, f in zip(sizes, firsts)]
+        self.tuns, self.muls = self.lanes[0].tuns, self.lanes[0].muls
+
+    def run(self):
+        """One pass over the whole batch; the result buffers of the lanes in batch order (lane i holds ciphertexts firsts[i] ...)."""
+        return [rr.run() for rr in self.lanes]
+
+    def sync(self):
+        for rr in self.lanes:
+            rr.sync()
+
+    def checksum(self, outs, count=None):
+        """Checksum of the first `count` result ciphertexts (all by default), additive over ciphertexts like Buf.checksum."""
+        count, total = (self.B if count is None else count), 0
+        for o, b, f in zip(outs, self.sizes, self.firsts):
+            take = max(0, min(b, count - f))
+            if take:
+                total = (total + o.checksum(0, 2 * take, 2 * f)) & ((1 << 64) - 1)
+        return total
+
+    def download(self, outs):
+        import numpy as np
+        return np.concatenate([o.download(0, 2 * b) for o, b in zip(outs, self.sizes)])
+
+    def measure(self, passes=1):
+        self.run(); self.sync()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            outs = self.run()
+        self.sync()
+        return (time.perf_counter() - t0) / passes, outs

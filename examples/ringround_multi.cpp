@@ -1,10 +1,11 @@
 // BASELINE config 4 ("examples/HomomRLWR.hs pipeline, 8192-ciphertext batch sharded over 8 x MI355X") from a native host: no Python,
 // no torch -- one process, one host thread per GPU, RCCL through include/alchemy_rccl.h.
 //
-//   ringround_multi [--gpus N] [--batch B] [--passes K] [--gather G] [--fixture PATH]
+//   ringround_multi [--gpus N] [--batch B] [--lanes S] [--passes K] [--gather G] [--fixture PATH]
 //
 //   1. every rank r (thread r, device r) builds the pipeline of alchemy_amd/host/ringround.hpp for its shard of B ciphertexts
-//      (default 1024: 8 ranks x 1024 = 8192);
+//      (default 1024: 8 ranks x 1024 = 8192), as S sub-batches on S streams (default 2: two dependency chains fill each other's
+//      memory-bound passes);
 //   2. the hint sources (five tunnels' linear functions and key-switch hints, four quadratic hints -- generated once per circuit,
 //      Crypto/Alchemy/Interpreter/KeysHints.hs:101-129) are generated on rank 0 ONLY and broadcast with alch_hint_broadcast; the
 //      other ranks' sources start zeroed, so a broadcast that did not deliver cannot go unnoticed;
@@ -32,7 +33,7 @@
 #include "../alchemy_amd/host/ringround.hpp"
 #include "../include/alchemy_rccl.h"
 
-using alchemy::ringround::RingRound;
+using alchemy::ringround::Lanes;
 
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -73,25 +74,27 @@ struct Barrier {
 };
 
 int main(int argc, char** argv) {
-    int N = 1, passes = 2;
+    int N = 1, passes = 2, S = 2;
     size_t B = 1024, G = 16;
     std::string fixture = "tests/golden/batch_checksums.json";
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--gpus") && i + 1 < argc) N = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--batch") && i + 1 < argc) B = (size_t)atol(argv[++i]);
         else if (!strcmp(argv[i], "--passes") && i + 1 < argc) passes = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--lanes") && i + 1 < argc) S = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--gather") && i + 1 < argc) G = (size_t)atol(argv[++i]);
         else if (!strcmp(argv[i], "--fixture") && i + 1 < argc) fixture = argv[++i];
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
     try {
-        if (N < 1 || passes < 1 || B < 1) throw std::runtime_error("--gpus, --passes and --batch must be positive");
-        G = std::min(G, B);
+        if (N < 1 || passes < 1 || B < 1 || S < 1) throw std::runtime_error("--gpus, --passes, --lanes and --batch must be positive");
+        S = (int)std::min((size_t)S, B);
+        G = std::min(G, B / (size_t)S);                                   // the gathered ciphertexts come from the first sub-batch
         const std::vector<uint64_t> fix = load_fixture(fixture);
         alch_comm* comm = nullptr;
         if (alch_comm_init_all(N, &comm) != ALCH_OK) throw std::runtime_error(std::string("alch_comm_init_all: ") + alch_rccl_last_error());
 
-        std::vector<std::unique_ptr<RingRound>> rr((size_t)N);
+        std::vector<std::unique_ptr<Lanes>> rr((size_t)N);
         std::vector<std::string> errors((size_t)N);
         std::vector<double> secs((size_t)N, 0.0);
         std::vector<int> shard_ok((size_t)N, 0), gather_ok((size_t)N, 0);
@@ -107,10 +110,10 @@ int main(int argc, char** argv) {
         auto worker = [&](int r) {
             guarded(r, [&] {
                 if (hipSetDevice(r) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
-                rr[(size_t)r].reset(new RingRound(B));
+                rr[(size_t)r].reset(new Lanes(B, S));
                 if (r == 0) rr[0]->fillSources();                         // generated once, on one rank
                 else {
-                    for (auto& s : rr[(size_t)r]->sources) {               // zeros until the broadcast arrives
+                    for (auto& ln : rr[(size_t)r]->lane) for (auto& s : ln->sources) {   // zeros until the broadcast arrives
                         void* p = nullptr;
                         size_t bytes = 0;
                         alchemy::ringround::check(alch_buf_device_ptr(s.first, &p, &bytes), "alch_buf_device_ptr");
@@ -123,11 +126,11 @@ int main(int argc, char** argv) {
             bar.wait();
             if (r == 0) guarded(0, [&] {                                  // the one collective of the path, before anything is timed
                 const double t0 = now();
-                const size_t ns = rr[0]->sources.size();
-                for (size_t i = 0; i < ns; ++i) {
+                const size_t ns = rr[0]->lane[0]->sources.size();
+                for (size_t l = 0; l < rr[0]->lane.size(); ++l) for (size_t i = 0; i < ns; ++i) {
                     std::vector<alch_buf*> bufs;
                     size_t elems = 0;
-                    for (int k = 0; k < N; ++k) bufs.push_back(rr[(size_t)k]->sources[i].first);
+                    for (int k = 0; k < N; ++k) bufs.push_back(rr[(size_t)k]->lane[l]->sources[i].first);
                     alchemy::ringround::check(alch_buf_elems(bufs[0], &elems), "alch_buf_elems");
                     if (alch_hint_broadcast(comm, 0, bufs.data(), 0, elems) != ALCH_OK) throw std::runtime_error(std::string("alch_hint_broadcast: ") + alch_rccl_last_error());
                 }
@@ -144,16 +147,17 @@ int main(int argc, char** argv) {
             bar.wait();
             guarded(r, [&] {
                 const double t0 = now();
-                alch_buf* res = nullptr;
-                for (int p = 0; p < passes; ++p) res = rr[(size_t)r]->run();
+                std::vector<alch_buf*> outs;
+                for (int p = 0; p < passes; ++p) outs = rr[(size_t)r]->run();
                 rr[(size_t)r]->sync();
                 secs[(size_t)r] = (now() - t0) / passes;
+                alch_buf* res = outs[0];
                 results[(size_t)r] = res;
                 // the shard against the oracle: per-ciphertext checksums are position dependent, so any prefix adds up
                 const size_t cnt = std::min(B, fix.size());
                 uint64_t want = 0, got = 0;
                 for (size_t i = 0; i < cnt; ++i) want += fix[i];
-                alchemy::ringround::check(alch_buf_checksum(res, 0, 2 * cnt, &got), "alch_buf_checksum");
+                got = rr[(size_t)r]->checksum(outs, cnt);
                 shard_ok[(size_t)r] = got == want;
                 alch_ring* ring = nullptr;
                 alchemy::ringround::check(alch_buf_ring(res, &ring), "alch_buf_ring");
@@ -187,8 +191,8 @@ int main(int argc, char** argv) {
         bool ok = !failed;
         double slow = 0;
         for (int r = 0; r < N; ++r) { ok = ok && shard_ok[(size_t)r] && gather_ok[(size_t)r]; slow = std::max(slow, secs[(size_t)r]); }
-        printf("{\"workload\": \"HomomRLWR ringRound pipeline, %zu ciphertexts per GPU, native host (C++ threads + RCCL, no torch)\", \"n_gpus\": %d, "
-               "\"pipelines_per_s\": %.1f, \"ms_per_pass_slowest_rank\": %.3f, \"hint_broadcast_ms\": %.3f, \"shard_checksums_ok\": [", B, N,
+        printf("{\"workload\": \"HomomRLWR ringRound pipeline, %zu ciphertexts per GPU as %d sub-batches, native host (C++ threads + RCCL, no torch)\", \"n_gpus\": %d, "
+               "\"pipelines_per_s\": %.1f, \"ms_per_pass_slowest_rank\": %.3f, \"hint_broadcast_ms\": %.3f, \"shard_checksums_ok\": [", B, S, N,
                slow > 0 ? (double)N * (double)B / slow : 0.0, slow * 1e3, t_bcast * 1e3);
         for (int r = 0; r < N; ++r) printf("%s%s", r ? ", " : "", shard_ok[(size_t)r] ? "true" : "false");
         printf("], \"all_gather_slices_ok\": [");

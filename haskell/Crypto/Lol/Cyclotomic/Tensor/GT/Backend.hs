@@ -108,6 +108,7 @@ foreign import ccall safe   "alch_buf_twace"           c_bufTwace        :: Ptr 
 foreign import ccall safe   "alch_buf_coeffs"          c_bufCoeffs       :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> IO CInt
 foreign import ccall safe   "alch_ct_add_public"       c_ctAddPublic     :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> Ptr Word64 -> Ptr AlchBuf -> CSize -> IO CInt
 foreign import ccall safe   "alch_buf_checksum"        c_bufChecksum     :: Ptr AlchBuf -> CSize -> CSize -> Ptr Word64 -> IO CInt
+foreign import ccall safe   "alch_buf_checksum_at"     c_bufChecksumAt   :: Ptr AlchBuf -> CSize -> CSize -> Word64 -> Ptr Word64 -> IO CInt
 foreign import ccall safe   "alch_buf_rescale_drop0"   c_bufRescaleDrop0 :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> IO CInt
 foreign import ccall safe   "alch_buf_rescale_add0"    c_bufRescaleAdd0  :: Ptr AlchBuf -> Ptr AlchBuf -> CSize -> IO CInt
 

@@ -238,6 +238,10 @@ int alch_buf_decompose_triv(const alch_buf *src, size_t src_index, alch_buf *dst
 /* 64-bit order-independent checksum of elements [first, first+count): sum over words of
  * splitmix64(position ^ value<<20) -- used by the full-size parity tests. */
 int alch_buf_checksum(const alch_buf *buf, size_t first, size_t count, uint64_t *sum);
+/* The same sum with the words counted from element `position` of a larger array: the checksum of a batch that lives in several
+ * buffers (sub-batches on their own streams, shards on their own GPUs) is the sum of its parts' checksums, each taken at the
+ * position of the part's first element in the whole batch. */
+int alch_buf_checksum_at(const alch_buf *buf, size_t first, size_t count, uint64_t position, uint64_t *sum);
 
 /* ---- device-resident Tensor values -------------------------------------------------
  * E issues one Lol call per op (Crypto/Alchemy/Interpreter/Eval.hs:120-134) and Lol one Tensor call per basis change, so through

@@ -146,6 +146,29 @@ def test_shared_stream_between_rings(oracle_lib):
     rs.share_stream(rb)                                          # idempotent
 
 
+def test_shared_stream_outlives_the_ring_that_created_it():
+    """A ring that borrowed another ring's stream keeps working -- and is destroyed cleanly -- after the lender is destroyed (a
+    garbage-collected host destroys rings in any order; the stream belongs to its last user)."""
+    qs = RLWR_QS[:3][::-1]
+    lender, user, third = A.Ring(128 * 7, qs), A.Ring(11648, qs), A.Ring(128 * 7, qs)
+    user.share_stream(lender)
+    third.share_stream(user)                                     # a borrowed stream can be lent on
+    rng = np.random.default_rng(6)
+    x = rand_elems(rng, 2, user.n, qs)
+    b = user.upload(x)
+    lender.close()                                               # the creator goes first
+    b.crt(); b.crtinv()
+    assert np.array_equal(b.download(), x)
+    b.free()
+    user.close()
+    y = rand_elems(rng, 1, third.n, qs)
+    c = third.upload(y)
+    c.crt(); c.crtinv()
+    assert np.array_equal(c.download(), y)
+    c.free()
+    third.close()
+
+
 def test_transfers_small_and_large_round_trip():
     r = A.Ring(1 << 16, CFG3_QS)                                 # one element = 1 MiB of int64
     rng = np.random.default_rng(5)

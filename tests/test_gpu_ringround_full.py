@@ -11,7 +11,7 @@ pipeline computes what the oracle's composition of the reference's ops computes:
 import numpy as np
 import pytest
 
-from alchemy_amd.ringround import RingRound
+from alchemy_amd.ringround import RingRound, RingRoundLanes
 from helpers import load_golden
 from ringround_oracle import RingRoundOracle
 
@@ -47,3 +47,26 @@ def test_ringround_pipeline_ragged_batch_checksum(B, opts):
     out2 = rr.run()                       # the second pass replays the buffer pool: same results
     rr.sync()
     assert out2.checksum(0, 2 * B) == want
+
+
+@pytest.mark.parametrize("B,lanes", [(70, 3), (9, 2), (5, 8)])
+def test_ringround_lanes_equal_the_single_chain(B, lanes):
+    """The batch as sub-batches on their own streams (what bench.py times): every word equals the one-chain pipeline's, and the
+    checksum assembled from the parts at their positions (alch_buf_checksum_at) equals the oracle's for the whole batch."""
+    ref = load_golden("batch_checksums.json")["homomrlwr"]
+    rl = RingRoundLanes(B, lanes)
+    assert sum(rl.sizes) == B and len(rl.lanes) == min(lanes, B) and max(rl.sizes) - min(rl.sizes) <= 1
+    outs = rl.run()
+    rl.sync()
+    want = sum(int(x, 16) for x in ref["per_ciphertext"][:B]) & MASK
+    assert f"{rl.checksum(outs):016x}" == f"{want:016x}"
+    cut = B - 2                                                         # a prefix that ends inside the last lane
+    assert rl.checksum(outs, cut) == sum(int(x, 16) for x in ref["per_ciphertext"][:cut]) & MASK
+    if B <= 9:
+        one = RingRound(B)
+        o = one.run()
+        one.sync()
+        assert np.array_equal(rl.download(outs), o.download(0, 2 * B))
+    outs2 = rl.run()                                                    # second pass: the lanes replay their buffer pools
+    rl.sync()
+    assert rl.checksum(outs2) == want
