@@ -92,6 +92,13 @@ class RingRound:
     def run(self, stage_times=False):
         """One pass over the batch; returns the result buffer (ciphertexts over H5' on one limb).  stage_times: synchronise
         around every stage and accumulate seconds per stage in self.stages."""
+        for _ in self.steps(stage_times):
+            pass
+        return self.result
+
+    def steps(self, stage_times=False):
+        """run() as a generator that yields after every stage (14 of them): RingRoundLanes issues the stages of its sub-batches in
+        turn, so that the chains start and end together on the device whatever the host's launch rate.  The result is self.result."""
         B, muls, tuns = self.B, self.muls, self.tuns
         ring, scratch, public = self.ring, self.scratch, self.public
 
@@ -123,6 +130,7 @@ class RingRound:
             self.pubs["pub_msd"] = ps
         x, x1 = self.pubs["x"], scratch(r0, 2 * B)
         timed("mulPublic", r0, lambda: x1.mul_public(x, self.pubs["pub_msd"], 0, 2 * B))
+        yield
         cur = x1
         for k in range(5):
             lin_, lh_, lout_ = tuns[k]
@@ -142,6 +150,7 @@ class RingRound:
                     self.tunnels[k].apply(cur, mid, B, flags=pow_in | pow_out)
                 return mid
             cur = timed(f"tunnel{k + 1}", rs, hop)
+            yield
         # rescale tree on H5'
         m5 = HP[5]
 
@@ -164,19 +173,23 @@ class RingRound:
         def level0():                                   # x_lsd = P x stays pending on x itself
             return product(0, cur, [P % q for q in moduli(L0)], plus_public(cur, one0, L0, 50), one0)
         y = timed("x(1+x)", ring(m5, muls[0][1]), level0)
+        yield
         L1 = muls[1][0]
         one1 = [1] * L1
         t = timed("leaves(addPublic,div2)", ring(m5, L1), lambda: [plus_public(y, one1, L1, 60 + i) for i in range(8)])
-
-        def tree(t=t):
-            pend = one1
-            for level in (1, 2, 3):
-                t = [product(level, t[2 * i], pend, t[2 * i + 1], pend) for i in range(len(t) // 2)]
-                pend = [pow(2, -1, q) for q in moduli(muls[level][2])]          # div2_: toMSD scalar, plaintext modulus halves (metadata)
-            res = t[0]
-            res.scale(res, 2 * B, pend)                 # the last div2's scalar: nothing follows that could absorb it
-            return res
-        return timed("tree(4+2+1 mul_, div2)", ring(m5, muls[3][1]), tree)
+        yield
+        pend = one1
+        for level in (1, 2, 3):
+            def tree_level(t=t, level=level, pend=pend):
+                return [product(level, t[2 * i], pend, t[2 * i + 1], pend) for i in range(len(t) // 2)]
+            t = timed(f"tree level {level} ({8 >> level} mul_, div2)", ring(m5, muls[level][1]), tree_level)
+            pend = [pow(2, -1, q) for q in moduli(muls[level][2])]              # div2_: toMSD scalar, plaintext modulus halves (metadata)
+            if level < 3:
+                yield
+        res = t[0]
+        res.scale(res, 2 * B, pend)                     # the last div2's scalar: nothing follows that could absorb it
+        self.result = res
+        yield
 
     def measure(self, passes=1):
         """Warm-up pass (allocations), then `passes` timed passes; wall-clock seconds per pass."""
@@ -204,8 +217,16 @@ class RingRoundLanes:
         self.tuns, self.muls = self.lanes[0].tuns, self.lanes[0].muls
 
     def run(self):
-        """One pass over the whole batch; the result buffers of the lanes in batch order (lane i holds ciphertexts firsts[i] ...)."""
-        return [rr.run() for rr in self.lanes]
+        """One pass over the whole batch; the result buffers of the lanes in batch order (lane i holds ciphertexts firsts[i] ...).
+        The lanes' stages are issued in turn (RingRound.steps): both chains are on the device from the first stage to the last."""
+        gens = [rr.steps() for rr in self.lanes]
+        live = True
+        while live:
+            live = False
+            for g in gens:
+                if next(g, StopIteration) is not StopIteration:
+                    live = True
+        return [rr.result for rr in self.lanes]
 
     def sync(self):
         for rr in self.lanes:
