@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 ALCH_OK = 0
 ALCH_E_INVALID, ALCH_E_NOT_PRIME, ALCH_E_NO_CRT, ALCH_E_UNSUPPORTED = -1, -2, -3, -4
-ALCH_E_NO_DEVICE, ALCH_E_HIP, ALCH_E_NOMEM = -5, -6, -7
+ALCH_E_NO_DEVICE, ALCH_E_HIP, ALCH_E_NOMEM, ALCH_E_INTERNAL = -5, -6, -7, -8
 ALCH_POW_IN, ALCH_POW_OUT = 1, 2
 ALCH_GAD_TRIV, ALCH_GAD_BASE2 = 0, 1
 ALCH_NOT_DIVISIBLE = 1

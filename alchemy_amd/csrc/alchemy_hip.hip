@@ -11,6 +11,8 @@
 #include <deque>
 #include <memory>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -153,6 +155,33 @@ static int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+// No C++ exception leaves the library (include/alchemy_hip.h: "no exceptions across the ABI" -- the callers are C, Haskell's FFI and
+// ctypes, where an escaping exception is std::terminate at best): every `extern "C" int` entry point is a function-try-block that
+// ends in this handler.  What can throw inside them is host-side allocation (std::vector / std::string / new: std::bad_alloc,
+// std::length_error) -- reported as ALCH_E_NOMEM / ALCH_E_INTERNAL with the message in alch_last_error(), never as an abort.
+// tests/test_abi_guard.py checks the mechanism through the real ABI (alch_debug_throw) and, lexically, that no entry point lacks it.
+static int abi_catch() noexcept {
+    int code = ALCH_E_INTERNAL;
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        code = ALCH_E_NOMEM;
+        try { g_err = "out of host memory (std::bad_alloc)"; } catch (...) {}
+    } catch (const std::exception& e) {
+        try { g_err = std::string("internal error: ") + e.what(); } catch (...) {}
+    } catch (...) {
+        try { g_err = "internal error: unknown exception"; } catch (...) {}
+    }
+    return code;
+}
+// test hook (not part of the Tensor surface): throws the chosen exception inside a guarded entry point
+extern "C" int alch_debug_throw(int kind) try {
+    if (kind == 1) throw std::bad_alloc();
+    if (kind == 2) throw std::length_error("alch_debug_throw");
+    if (kind == 3) throw 42;
+    return ALCH_OK;
+} catch (...) { return abi_catch(); }
+
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t _e = (expr);                                                                         \
@@ -1086,13 +1115,13 @@ static int validate_ring_args(uint32_t m, int L, const uint64_t* q, int* logn_ou
 // Crypto/Alchemy/Interpreter/PT2CT/Noise.hs:107-170 (units of a modulus, shortest prefix with enough units) and
 // Crypto/Alchemy/Interpreter/PT2CT.hs:132-140 (KSPNoise), :160-177 (mul_), :207-229 (linearCyc_), :234-249
 // (CTPNoise2Units, KSPNoise2Units, Units2CTPNoise), :281-296 (the constants).
-extern "C" int alch_modulus_units(uint64_t q) {
+extern "C" int alch_modulus_units(uint64_t q) try {
     if (q < 2) return 0;
     return (int)std::floor(std::log2((double)q) / 6.1);          // mkModulus: floor (logBase 2 q / pNoiseUnit)
-}
+} catch (...) { return abi_catch(); }
 
 extern "C" int alch_select_limbs(const uint64_t* moduli, int n_moduli, int op, int gadget, int p_noise_out, int* L_in,
-                                 int* L_hint, int* L_out, int* p_noise_in) {
+                                 int* L_hint, int* L_out, int* p_noise_in) try {
     if (!moduli || n_moduli < 1 || p_noise_out < 0) return fail(ALCH_E_INVALID, "alch_select_limbs: bad argument");
     if (op != ALCH_OP_MUL && op != ALCH_OP_TUNNEL) return fail(ALCH_E_INVALID, "alch_select_limbs: unknown op");
     if (gadget != ALCH_GAD_TRIV && gadget != ALCH_GAD_BASE2) return fail(ALCH_E_INVALID, "unknown gadget");
@@ -1121,16 +1150,16 @@ extern "C" int alch_select_limbs(const uint64_t* moduli, int n_moduli, int op, i
     if (L_out) *L_out = lout;
     if (p_noise_in) *p_noise_in = op == ALCH_OP_MUL ? tot_in - MinUnits : p + TunnelPNoise;
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_host_root(uint32_t m, uint64_t q, uint64_t* psi, uint64_t* generator) {
+extern "C" int alch_host_root(uint32_t m, uint64_t q, uint64_t* psi, uint64_t* generator) try {
     if (m < 1 || q < 2) return fail(ALCH_E_INVALID, "alch_host_root: bad (m, q)");
     if (q < 3 || !h_is_prime(q)) return fail(ALCH_E_NOT_PRIME, "alch_host_root: q is not an odd prime");
     if ((q - 1) % m) return fail(ALCH_E_NO_CRT, "q is not 1 mod m");
     if (generator) *generator = h_smallest_generator(q);
     if (psi) *psi = h_root(q, m);
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
 static int ring_create_impl(uint32_t m, int L, const uint64_t* q, bool nocrt, alch_ring** out) {
     if (!out) return fail(ALCH_E_INVALID, "alch_ring_create: null out");
@@ -1183,10 +1212,10 @@ static int ring_create_impl(uint32_t m, int L, const uint64_t* q, bool nocrt, al
     return ALCH_OK;
 }
 
-extern "C" int alch_ring_create(uint32_t m, int L, const uint64_t* q, alch_ring** out) { return ring_create_impl(m, L, q, false, out); }
-extern "C" int alch_ring_create_nocrt(uint32_t m, int L, const uint64_t* q, alch_ring** out) { return ring_create_impl(m, L, q, true, out); }
+extern "C" int alch_ring_create(uint32_t m, int L, const uint64_t* q, alch_ring** out) try { return ring_create_impl(m, L, q, false, out); } catch (...) { return abi_catch(); }
+extern "C" int alch_ring_create_nocrt(uint32_t m, int L, const uint64_t* q, alch_ring** out) try { return ring_create_impl(m, L, q, true, out); } catch (...) { return abi_catch(); }
 
-extern "C" int alch_ring_destroy(alch_ring* r) {
+extern "C" int alch_ring_destroy(alch_ring* r) try {
     if (!r) return ALCH_OK;
     (void)hipSetDevice(r->device);
     if (r->scratch) { alch_buf* b = r->scratch; r->scratch = nullptr; (void)hipFree(b->dptr); delete b; }
@@ -1223,26 +1252,26 @@ extern "C" int alch_ring_destroy(alch_ring* r) {
     r->stream_owner.reset();                       // destroys the stream with its last user
     delete r;
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_ring_n(const alch_ring* r, uint32_t* n, int* L, int* word_bytes) {
+extern "C" int alch_ring_n(const alch_ring* r, uint32_t* n, int* L, int* word_bytes) try {
     if (!r) return fail(ALCH_E_INVALID, "null ring");
     if (n) *n = r->n;
     if (L) *L = r->L;
     if (word_bytes) *word_bytes = r->word;
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_ring_set_stream(alch_ring* r, void* s) {
+extern "C" int alch_ring_set_stream(alch_ring* r, void* s) try {
     if (!r) return fail(ALCH_E_INVALID, "null ring");
     BIND(r);
     HIP_TRY(hipStreamSynchronize(r->stream));
     r->stream_owner.reset();
     r->stream = (hipStream_t)s;
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) {
+extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) try {
     if (!r || !name) return fail(ALCH_E_INVALID, "null argument");
     const std::string k(name);
     if (k == "chunk") { if (value < 8) return fail(ALCH_E_INVALID, "chunk must be >= 8"); r->chunk = (size_t)value; }
@@ -1271,30 +1300,30 @@ extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) 
     else if (k == "rs_slots") { if (value < 1) return fail(ALCH_E_INVALID, "rs_slots must be >= 1"); r->rs_slots = (unsigned)value; }
     else return fail(ALCH_E_INVALID, "unknown option '" + k + "'");
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_sync(alch_ring* r) {
+extern "C" int alch_sync(alch_ring* r) try {
     if (!r) return fail(ALCH_E_INVALID, "null ring");
     BIND(r);
     HIP_TRY(hipStreamSynchronize(r->stream));
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_timer_start(alch_ring* r) {
+extern "C" int alch_timer_start(alch_ring* r) try {
     if (!r) return fail(ALCH_E_INVALID, "null ring");
     BIND(r);
     HIP_TRY(hipEventRecord(r->ev0, r->stream));
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_timer_stop(alch_ring* r, float* ms) {
+extern "C" int alch_timer_stop(alch_ring* r, float* ms) try {
     if (!r || !ms) return fail(ALCH_E_INVALID, "null argument");
     BIND(r);
     HIP_TRY(hipEventRecord(r->ev1, r->stream));
     HIP_TRY(hipEventSynchronize(r->ev1));
     HIP_TRY(hipEventElapsedTime(ms, r->ev0, r->ev1));
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
 // ------------------------------------------------------------------------------------------------------
 // helpers
@@ -1384,7 +1413,7 @@ static int buf_crt(alch_buf* b, size_t first, size_t count, bool inverse) {
 // ------------------------------------------------------------------------------------------------------
 // device buffers
 // ------------------------------------------------------------------------------------------------------
-extern "C" int alch_buf_alloc(alch_ring* r, size_t n_elems, alch_buf** out) {
+extern "C" int alch_buf_alloc(alch_ring* r, size_t n_elems, alch_buf** out) try {
     if (!r || !out || n_elems == 0) return fail(ALCH_E_INVALID, "alch_buf_alloc: bad argument");
     if (n_elems > (size_t)-1 / elem_bytes(r)) return fail(ALCH_E_INVALID, "alch_buf_alloc: n_elems * element size overflows size_t");
     BIND(r);
@@ -1415,18 +1444,18 @@ extern "C" int alch_buf_alloc(alch_ring* r, size_t n_elems, alch_buf** out) {
     }
     *out = new alch_buf{r, n_elems, p};
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_buf_view(const alch_buf* parent, size_t first, size_t count, alch_buf** out) {
+extern "C" int alch_buf_view(const alch_buf* parent, size_t first, size_t count, alch_buf** out) try {
     if (!parent || !out || count == 0) return fail(ALCH_E_INVALID, "alch_buf_view: bad argument");
     if (first + count > parent->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
     alch_buf* v = new alch_buf{parent->ring, count, reinterpret_cast<char*>(parent->dptr) + first * elem_bytes(parent->ring)};
     v->view = true;
     *out = v;
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_buf_free(alch_buf* b) {
+extern "C" int alch_buf_free(alch_buf* b) try {
     if (!b) return ALCH_OK;
     if (b->view) { delete b; return ALCH_OK; }                      // an alias owns nothing
     alch_ring* r = b->ring;
@@ -1445,33 +1474,33 @@ extern "C" int alch_buf_free(alch_buf* b) {
     (void)hipFree(b->dptr);
     delete b;
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_buf_elems(const alch_buf* b, size_t* n) {
+extern "C" int alch_buf_elems(const alch_buf* b, size_t* n) try {
     if (!b || !n) return fail(ALCH_E_INVALID, "null argument");
     *n = b->n_elems;
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_buf_device_ptr(const alch_buf* b, void** ptr, size_t* bytes) {
+extern "C" int alch_buf_device_ptr(const alch_buf* b, void** ptr, size_t* bytes) try {
     if (!b || !ptr) return fail(ALCH_E_INVALID, "null argument");
     *ptr = b->dptr;
     if (bytes) *bytes = b->n_elems * elem_bytes(b->ring);
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_buf_ring(const alch_buf* b, alch_ring** ring) {
+extern "C" int alch_buf_ring(const alch_buf* b, alch_ring** ring) try {
     if (!b || !ring) return fail(ALCH_E_INVALID, "null argument");
     *ring = b->ring;
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_ring_device(const alch_ring* r, int* device, void** hip_stream) {
+extern "C" int alch_ring_device(const alch_ring* r, int* device, void** hip_stream) try {
     if (!r) return fail(ALCH_E_INVALID, "null ring");
     if (device) *device = r->device;
     if (hip_stream) *hip_stream = (void*)r->stream;
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
 template <typename W>
 static int do_transfer(alch_ring* r, void* dev, size_t count, int64_t* host, bool to_device) {
@@ -1541,19 +1570,19 @@ static int transfer(alch_ring* r, void* dev_base, size_t first, size_t count, in
     return ALCH_OK;
 }
 
-extern "C" int alch_buf_upload(alch_buf* b, size_t first, size_t count, const int64_t* host) {
+extern "C" int alch_buf_upload(alch_buf* b, size_t first, size_t count, const int64_t* host) try {
     if (!b || !host) return fail(ALCH_E_INVALID, "null argument");
     if (first + count > b->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
     return transfer(b->ring, b->dptr, first, count, const_cast<int64_t*>(host), true);
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_buf_download(const alch_buf* b, size_t first, size_t count, int64_t* host) {
+extern "C" int alch_buf_download(const alch_buf* b, size_t first, size_t count, int64_t* host) try {
     if (!b || !host) return fail(ALCH_E_INVALID, "null argument");
     if (first + count > b->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
     return transfer(b->ring, b->dptr, first, count, host, false);
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_buf_fill_uniform(alch_buf* b, uint64_t seed) {
+extern "C" int alch_buf_fill_uniform(alch_buf* b, uint64_t seed) try {
     if (!b) return fail(ALCH_E_INVALID, "null buffer");
     alch_ring* r = b->ring;
     BIND(r);
@@ -1564,10 +1593,10 @@ extern "C" int alch_buf_fill_uniform(alch_buf* b, uint64_t seed) {
         hipLaunchKernelGGL((k_fill_uniform<u64>), dim3(ew_grid(words)), dim3(256), 0, r->stream, r->d64, (u64*)b->dptr, words, seed);
     HIP_TRY(hipGetLastError());
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_buf_crt(alch_buf* b, size_t first, size_t count) { return buf_crt(b, first, count, false); }
-extern "C" int alch_buf_crtinv(alch_buf* b, size_t first, size_t count) { return buf_crt(b, first, count, true); }
+extern "C" int alch_buf_crt(alch_buf* b, size_t first, size_t count) try { return buf_crt(b, first, count, false); } catch (...) { return abi_catch(); }
+extern "C" int alch_buf_crtinv(alch_buf* b, size_t first, size_t count) try { return buf_crt(b, first, count, true); } catch (...) { return abi_catch(); }
 
 template <typename W, int OP>
 static int do_pointwise(alch_ring* r, void* dst, const void* a, const void* b, size_t count) {
@@ -1599,9 +1628,9 @@ static int buf_pointwise(alch_buf* dst, const alch_buf* a, const alch_buf* b, si
     return do_pointwise<u64, PW_SUB>(r, dst->dptr, a->dptr, b->dptr, count);
 }
 
-extern "C" int alch_buf_mul(alch_buf* d, const alch_buf* a, const alch_buf* b, size_t count) { return buf_pointwise(d, a, b, count, PW_MUL); }
-extern "C" int alch_buf_add(alch_buf* d, const alch_buf* a, const alch_buf* b, size_t count) { return buf_pointwise(d, a, b, count, PW_ADD); }
-extern "C" int alch_buf_sub(alch_buf* d, const alch_buf* a, const alch_buf* b, size_t count) { return buf_pointwise(d, a, b, count, PW_SUB); }
+extern "C" int alch_buf_mul(alch_buf* d, const alch_buf* a, const alch_buf* b, size_t count) try { return buf_pointwise(d, a, b, count, PW_MUL); } catch (...) { return abi_catch(); }
+extern "C" int alch_buf_add(alch_buf* d, const alch_buf* a, const alch_buf* b, size_t count) try { return buf_pointwise(d, a, b, count, PW_ADD); } catch (...) { return abi_catch(); }
+extern "C" int alch_buf_sub(alch_buf* d, const alch_buf* a, const alch_buf* b, size_t count) try { return buf_pointwise(d, a, b, count, PW_SUB); } catch (...) { return abi_catch(); }
 
 static int buf_checksum(const alch_buf* b, size_t first, size_t count, uint64_t position, uint64_t* sum) {
     if (!b || !sum) return fail(ALCH_E_INVALID, "null argument");
@@ -1619,8 +1648,8 @@ static int buf_checksum(const alch_buf* b, size_t first, size_t count, uint64_t 
     return ALCH_OK;
 }
 
-extern "C" int alch_buf_checksum(const alch_buf* b, size_t first, size_t count, uint64_t* sum) { return buf_checksum(b, first, count, 0, sum); }
-extern "C" int alch_buf_checksum_at(const alch_buf* b, size_t first, size_t count, uint64_t position, uint64_t* sum) { return buf_checksum(b, first, count, position, sum); }
+extern "C" int alch_buf_checksum(const alch_buf* b, size_t first, size_t count, uint64_t* sum) try { return buf_checksum(b, first, count, 0, sum); } catch (...) { return abi_catch(); }
+extern "C" int alch_buf_checksum_at(const alch_buf* b, size_t first, size_t count, uint64_t position, uint64_t* sum) try { return buf_checksum(b, first, count, position, sum); } catch (...) { return abi_catch(); }
 
 // ------------------------------------------------------------------------------------------------------
 // host-buffer Tensor methods: stage one element through a scratch device buffer
@@ -1650,8 +1679,8 @@ static int host_unary(alch_ring* r, int64_t* data, int which) {
     return alch_buf_download(s.b, 0, 1, data);
 }
 
-extern "C" int alch_crt(alch_ring* r, int64_t* data) { return host_unary(r, data, 0); }
-extern "C" int alch_crtinv(alch_ring* r, int64_t* data) { return host_unary(r, data, 1); }
+extern "C" int alch_crt(alch_ring* r, int64_t* data) try { return host_unary(r, data, 0); } catch (...) { return abi_catch(); }
+extern "C" int alch_crtinv(alch_ring* r, int64_t* data) try { return host_unary(r, data, 1); } catch (...) { return abi_catch(); }
 
 static int host_binary(alch_ring* r, int64_t* a, const int64_t* b, int op) {
     if (!r || !a || !b) return fail(ALCH_E_INVALID, "null argument");
@@ -1665,9 +1694,9 @@ static int host_binary(alch_ring* r, int64_t* a, const int64_t* b, int op) {
     return alch_buf_download(s.b, 0, 1, a);
 }
 
-extern "C" int alch_mul(alch_ring* r, int64_t* a, const int64_t* b) { return host_binary(r, a, b, PW_MUL); }
-extern "C" int alch_add(alch_ring* r, int64_t* a, const int64_t* b) { return host_binary(r, a, b, PW_ADD); }
-extern "C" int alch_sub(alch_ring* r, int64_t* a, const int64_t* b) { return host_binary(r, a, b, PW_SUB); }
+extern "C" int alch_mul(alch_ring* r, int64_t* a, const int64_t* b) try { return host_binary(r, a, b, PW_MUL); } catch (...) { return abi_catch(); }
+extern "C" int alch_add(alch_ring* r, int64_t* a, const int64_t* b) try { return host_binary(r, a, b, PW_ADD); } catch (...) { return abi_catch(); }
+extern "C" int alch_sub(alch_ring* r, int64_t* a, const int64_t* b) try { return host_binary(r, a, b, PW_SUB); } catch (...) { return abi_catch(); }
 
 template <typename W>
 static int scal_to_mont(const alch_ring* r, const uint64_t* s, int power_of_R, Scal<W>& out) {
@@ -1695,7 +1724,7 @@ static int do_scale(alch_ring* r, void* dst, const void* src, size_t count, cons
     return ALCH_OK;
 }
 
-extern "C" int alch_scale(alch_ring* r, int64_t* a, const uint64_t* s) {
+extern "C" int alch_scale(alch_ring* r, int64_t* a, const uint64_t* s) try {
     if (!r || !a || !s) return fail(ALCH_E_INVALID, "null argument");
     ScratchBuf t;
     int rc = scratch_get(r, 1, &t.b);
@@ -1704,7 +1733,7 @@ extern "C" int alch_scale(alch_ring* r, int64_t* a, const uint64_t* s) {
     rc = r->word == 4 ? do_scale<u32>(r, t.b->dptr, t.b->dptr, 1, s) : do_scale<u64>(r, t.b->dptr, t.b->dptr, 1, s);
     if (rc != ALCH_OK) return rc;
     return alch_buf_download(t.b, 0, 1, a);
-}
+} catch (...) { return abi_catch(); }
 
 // mulG / divG / l / lInv on one host ring element: staged through the per-ring scratch element.
 static int buf_mulg_divg(alch_buf* b, size_t first, size_t count, int basis, bool divide);
@@ -1723,16 +1752,16 @@ static int host_g(alch_ring* r, int64_t* a, int basis, int which /* 0 mulG, 1 di
     if (rc != ALCH_OK) return rc;                                     // includes ALCH_NOT_DIVISIBLE: the host data stay untouched
     return alch_buf_download(s.b, 0, 1, a);
 }
-extern "C" int alch_mulg_pow(alch_ring* r, int64_t* a) { return host_g(r, a, ALCH_BASIS_POW, 0); }
-extern "C" int alch_mulg_dec(alch_ring* r, int64_t* a) { return host_g(r, a, ALCH_BASIS_DEC, 0); }
-extern "C" int alch_mulg_crt(alch_ring* r, int64_t* a) { return host_g(r, a, ALCH_BASIS_CRT, 0); }
-extern "C" int alch_divg_pow(alch_ring* r, int64_t* a) { return host_g(r, a, ALCH_BASIS_POW, 1); }
-extern "C" int alch_divg_dec(alch_ring* r, int64_t* a) { return host_g(r, a, ALCH_BASIS_DEC, 1); }
-extern "C" int alch_divg_crt(alch_ring* r, int64_t* a) { return host_g(r, a, ALCH_BASIS_CRT, 1); }
-extern "C" int alch_l(alch_ring* r, int64_t* a) { return host_g(r, a, ALCH_BASIS_POW, 2); }
-extern "C" int alch_linv(alch_ring* r, int64_t* a) { return host_g(r, a, ALCH_BASIS_POW, 3); }
+extern "C" int alch_mulg_pow(alch_ring* r, int64_t* a) try { return host_g(r, a, ALCH_BASIS_POW, 0); } catch (...) { return abi_catch(); }
+extern "C" int alch_mulg_dec(alch_ring* r, int64_t* a) try { return host_g(r, a, ALCH_BASIS_DEC, 0); } catch (...) { return abi_catch(); }
+extern "C" int alch_mulg_crt(alch_ring* r, int64_t* a) try { return host_g(r, a, ALCH_BASIS_CRT, 0); } catch (...) { return abi_catch(); }
+extern "C" int alch_divg_pow(alch_ring* r, int64_t* a) try { return host_g(r, a, ALCH_BASIS_POW, 1); } catch (...) { return abi_catch(); }
+extern "C" int alch_divg_dec(alch_ring* r, int64_t* a) try { return host_g(r, a, ALCH_BASIS_DEC, 1); } catch (...) { return abi_catch(); }
+extern "C" int alch_divg_crt(alch_ring* r, int64_t* a) try { return host_g(r, a, ALCH_BASIS_CRT, 1); } catch (...) { return abi_catch(); }
+extern "C" int alch_l(alch_ring* r, int64_t* a) try { return host_g(r, a, ALCH_BASIS_POW, 2); } catch (...) { return abi_catch(); }
+extern "C" int alch_linv(alch_ring* r, int64_t* a) try { return host_g(r, a, ALCH_BASIS_POW, 3); } catch (...) { return abi_catch(); }
 
-extern "C" int alch_decompose_triv(alch_ring* r, const int64_t* c_pow, int64_t* digits) {
+extern "C" int alch_decompose_triv(alch_ring* r, const int64_t* c_pow, int64_t* digits) try {
     if (!r || !c_pow || !digits) return fail(ALCH_E_INVALID, "null argument");
     ScratchBuf s;
     int rc = scratch_get(r, 1 + (size_t)r->L, &s.b);
@@ -1744,7 +1773,7 @@ extern "C" int alch_decompose_triv(alch_ring* r, const int64_t* c_pow, int64_t* 
     else hipLaunchKernelGGL((k_decompose_triv<u64>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d64, (const u64*)s.b->dptr, (u64*)dig, r->balanced ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return alch_buf_download(s.b, 1, (size_t)r->L, digits);
-}
+} catch (...) { return abi_catch(); }
 
 // BaseBGad 2 layout: limb i owns ceil(log2 q_i) digits starting at first[i]; returns their total.
 static int base2_layout(const alch_ring* r, Scal<u32>& first, Scal<u32>& kd) {
@@ -1766,7 +1795,7 @@ static int gadget_digits(const alch_ring* r, int gadget) {
     return base2_layout(r, f, k);
 }
 
-extern "C" int alch_decompose_base2(alch_ring* r, const int64_t* c_pow, int64_t* digits, int* n_digits) {
+extern "C" int alch_decompose_base2(alch_ring* r, const int64_t* c_pow, int64_t* digits, int* n_digits) try {
     if (!r) return fail(ALCH_E_INVALID, "null ring");
     Scal<u32> first, kd;
     const int D = base2_layout(r, first, kd);
@@ -1783,7 +1812,7 @@ extern "C" int alch_decompose_base2(alch_ring* r, const int64_t* c_pow, int64_t*
     else hipLaunchKernelGGL((k_decompose_base2<u64>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d64, (const u64*)s.b->dptr, (u64*)dig, first, kd, (u32)D);
     HIP_TRY(hipGetLastError());
     return alch_buf_download(s.b, 1, (size_t)D, digits);
-}
+} catch (...) { return abi_catch(); }
 
 // ------------------------------------------------------------------------------------------------------
 // hint
@@ -1813,16 +1842,16 @@ static int hint_from_device(alch_ring* r, int gadget, const void* src_crt, alch_
     return rc;
 }
 
-extern "C" int alch_buf_scale(alch_buf* dst, const alch_buf* src, size_t count, const uint64_t* s) {
+extern "C" int alch_buf_scale(alch_buf* dst, const alch_buf* src, size_t count, const uint64_t* s) try {
     if (!dst || !src || !s) return fail(ALCH_E_INVALID, "null argument");
     if (dst->ring != src->ring) return fail(ALCH_E_INVALID, "buffers belong to different rings");
     if (count > dst->n_elems || count > src->n_elems) return fail(ALCH_E_INVALID, "count out of bounds");
     alch_ring* r = dst->ring;
     BIND(r);
     return r->word == 4 ? do_scale<u32>(r, dst->dptr, src->dptr, count, s) : do_scale<u64>(r, dst->dptr, src->dptr, count, s);
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_buf_decompose_triv(const alch_buf* src, size_t src_index, alch_buf* dst, size_t dst_first) {
+extern "C" int alch_buf_decompose_triv(const alch_buf* src, size_t src_index, alch_buf* dst, size_t dst_first) try {
     if (!src || !dst) return fail(ALCH_E_INVALID, "null buffer");
     if (src->ring != dst->ring) return fail(ALCH_E_INVALID, "buffers belong to different rings");
     alch_ring* r = src->ring;
@@ -1835,9 +1864,9 @@ extern "C" int alch_buf_decompose_triv(const alch_buf* src, size_t src_index, al
     else hipLaunchKernelGGL((k_decompose_triv<u64>), dim3(ew_grid(total)), dim3(256), 0, r->stream, r->d64, (const u64*)c, (u64*)dig, r->balanced ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_hint_load(alch_ring* r, int gadget, const int64_t* host_crt, alch_hint** out) {
+extern "C" int alch_hint_load(alch_ring* r, int gadget, const int64_t* host_crt, alch_hint** out) try {
     if (!r || !host_crt || !out) return fail(ALCH_E_INVALID, "null argument");
     if (gadget != ALCH_GAD_TRIV && gadget != ALCH_GAD_BASE2) return fail(ALCH_E_INVALID, "unknown gadget");
     const size_t elems = 2 * (size_t)gadget_digits(r, gadget);
@@ -1848,26 +1877,26 @@ extern "C" int alch_hint_load(alch_ring* r, int gadget, const int64_t* host_crt,
     rc = hint_from_device(r, gadget, s.b->dptr, out);
     if (rc == ALCH_OK) HIP_TRY(hipStreamSynchronize(r->stream));
     return rc;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_hint_from_buf(alch_ring* r, int gadget, const alch_buf* src, alch_hint** out) {
+extern "C" int alch_hint_from_buf(alch_ring* r, int gadget, const alch_buf* src, alch_hint** out) try {
     if (!r || !src || !out) return fail(ALCH_E_INVALID, "null argument");
     if (gadget != ALCH_GAD_TRIV && gadget != ALCH_GAD_BASE2) return fail(ALCH_E_INVALID, "unknown gadget");
     if (src->ring != r || src->n_elems < 2 * (size_t)gadget_digits(r, gadget))
         return fail(ALCH_E_INVALID, "hint source needs 2 ring elements per gadget digit");
     return hint_from_device(r, gadget, src->dptr, out);
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_hint_free(alch_hint* h) {
+extern "C" int alch_hint_free(alch_hint* h) try {
     if (!h) return ALCH_OK;
     (void)hipSetDevice(h->ring->device);
     (void)hipStreamSynchronize(h->ring->stream);
     (void)hipFree(h->dptr);
     delete h;
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_ct_add_public(alch_buf* dst, const alch_buf* src, size_t batch, const uint64_t* s, const alch_buf* pub, size_t pub_index) {
+extern "C" int alch_ct_add_public(alch_buf* dst, const alch_buf* src, size_t batch, const uint64_t* s, const alch_buf* pub, size_t pub_index) try {
     if (!dst || !src || !pub) return fail(ALCH_E_INVALID, "null buffer");
     alch_ring* r = dst->ring;
     if (src->ring != r || pub->ring != r) return fail(ALCH_E_INVALID, "buffers belong to different rings");
@@ -1888,7 +1917,7 @@ extern "C" int alch_ct_add_public(alch_buf* dst, const alch_buf* src, size_t bat
     }
     HIP_TRY(hipGetLastError());
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
 // ------------------------------------------------------------------------------------------------------
 // general index: l / lInv, mulG / divG on device buffers
@@ -1961,8 +1990,8 @@ static int buf_mulg_divg(alch_buf* b, size_t first, size_t count, int basis, boo
     return flag ? ALCH_NOT_DIVISIBLE : ALCH_OK;
 }
 
-extern "C" int alch_buf_mulg(alch_buf* b, size_t first, size_t count, int basis) { return buf_mulg_divg(b, first, count, basis, false); }
-extern "C" int alch_buf_divg(alch_buf* b, size_t first, size_t count, int basis) { return buf_mulg_divg(b, first, count, basis, true); }
+extern "C" int alch_buf_mulg(alch_buf* b, size_t first, size_t count, int basis) try { return buf_mulg_divg(b, first, count, basis, false); } catch (...) { return abi_catch(); }
+extern "C" int alch_buf_divg(alch_buf* b, size_t first, size_t count, int basis) try { return buf_mulg_divg(b, first, count, basis, true); } catch (...) { return abi_catch(); }
 
 static int buf_l(alch_buf* b, size_t first, size_t count, bool inverse) {
     if (!b) return fail(ALCH_E_INVALID, "null buffer");
@@ -1972,8 +2001,8 @@ static int buf_l(alch_buf* b, size_t first, size_t count, bool inverse) {
     if (!r->gen || r->gh.rad == 1) return ALCH_OK;                    // L = identity for a two-power index
     return columns(r, inverse ? GEN_LINV : GEN_L, b->dptr, first, count, 1);
 }
-extern "C" int alch_buf_l(alch_buf* b, size_t first, size_t count) { return buf_l(b, first, count, false); }
-extern "C" int alch_buf_linv(alch_buf* b, size_t first, size_t count) { return buf_l(b, first, count, true); }
+extern "C" int alch_buf_l(alch_buf* b, size_t first, size_t count) try { return buf_l(b, first, count, false); } catch (...) { return abi_catch(); }
+extern "C" int alch_buf_linv(alch_buf* b, size_t first, size_t count) try { return buf_l(b, first, count, true); } catch (...) { return abi_catch(); }
 
 // ------------------------------------------------------------------------------------------------------
 // device-resident Tensor values: what a `GT m r` holds when it stays on the GPU between Tensor calls
@@ -1981,7 +2010,7 @@ extern "C" int alch_buf_linv(alch_buf* b, size_t first, size_t count) { return b
 // E issues one Lol call per op (Crypto/Alchemy/Interpreter/Eval.hs:120-134) and Lol one Tensor call per basis change, so a
 // ciphertext operation reaches this library as a chain of single-element calls.  With the host-buffer entry points every link
 // of that chain crosses PCIe twice; with these the element stays in HBM and a link costs one kernel launch.
-extern "C" int alch_ring_share_stream(alch_ring* r, alch_ring* with) {
+extern "C" int alch_ring_share_stream(alch_ring* r, alch_ring* with) try {
     if (!r || !with) return fail(ALCH_E_INVALID, "null ring");
     if (r->device != with->device) return fail(ALCH_E_INVALID, "alch_ring_share_stream: the rings live on different devices");
     if (r == with || r->stream == with->stream) return ALCH_OK;
@@ -1990,9 +2019,9 @@ extern "C" int alch_ring_share_stream(alch_ring* r, alch_ring* with) {
     r->stream_owner = with->stream_owner;          // releases r's own stream (destroyed with its last user), keeps with's alive
     r->stream = with->stream;
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_buf_copy(alch_buf* dst, size_t dst_first, const alch_buf* src, size_t src_first, size_t count) {
+extern "C" int alch_buf_copy(alch_buf* dst, size_t dst_first, const alch_buf* src, size_t src_first, size_t count) try {
     if (!dst || !src) return fail(ALCH_E_INVALID, "null buffer");
     if (dst->ring != src->ring) return fail(ALCH_E_INVALID, "buffers belong to different rings");
     if (dst_first + count > dst->n_elems || src_first + count > src->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
@@ -2005,11 +2034,11 @@ extern "C" int alch_buf_copy(alch_buf* dst, size_t dst_first, const alch_buf* sr
     if ((d < f ? f - d : d - f) < (ptrdiff_t)(count * elem_bytes(r))) return fail(ALCH_E_INVALID, "alch_buf_copy: overlapping ranges");
     HIP_TRY(hipMemcpyAsync(d, f, count * elem_bytes(r), hipMemcpyDeviceToDevice, r->stream));
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
 // dst[dst_first + i] = op(src[src_first + i]), i < count.  Transforms and column operators read `src` and write `dst` in one
 // kernel; the CRT-basis g products copy first.  dst and src may be the same range (in place).
-extern "C" int alch_buf_tensor_op(alch_buf* dst, size_t dst_first, const alch_buf* src, size_t src_first, size_t count, int op) {
+extern "C" int alch_buf_tensor_op(alch_buf* dst, size_t dst_first, const alch_buf* src, size_t src_first, size_t count, int op) try {
     if (!dst || !src) return fail(ALCH_E_INVALID, "null buffer");
     if (dst->ring != src->ring) return fail(ALCH_E_INVALID, "buffers belong to different rings");
     if (dst_first + count > dst->n_elems || src_first + count > src->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
@@ -2060,9 +2089,9 @@ extern "C" int alch_buf_tensor_op(alch_buf* dst, size_t dst_first, const alch_bu
     HIP_TRY(hipMemcpyAsync(&flag, r->d_flag, sizeof(int), hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(hipStreamSynchronize(r->stream));
     return flag ? ALCH_NOT_DIVISIBLE : ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_buf_mul_public(alch_buf* dst, const alch_buf* src, const alch_buf* pub, size_t pub_index, size_t count) {
+extern "C" int alch_buf_mul_public(alch_buf* dst, const alch_buf* src, const alch_buf* pub, size_t pub_index, size_t count) try {
     if (!dst || !src || !pub) return fail(ALCH_E_INVALID, "null buffer");
     alch_ring* r = dst->ring;
     if (src->ring != r || pub->ring != r) return fail(ALCH_E_INVALID, "buffers belong to different rings");
@@ -2075,9 +2104,9 @@ extern "C" int alch_buf_mul_public(alch_buf* dst, const alch_buf* src, const alc
     else hipLaunchKernelGGL((k_mul_bcast<u64>), dim3(ew_grid(words)), dim3(256), 0, r->stream, r->d64, (u64*)dst->dptr, (const u64*)src->dptr, (const u64*)pp, words);
     HIP_TRY(hipGetLastError());
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_buf_add_public(alch_buf* cts, const alch_buf* pub, size_t pub_index, size_t batch) {
+extern "C" int alch_buf_add_public(alch_buf* cts, const alch_buf* pub, size_t pub_index, size_t batch) try {
     if (!cts || !pub) return fail(ALCH_E_INVALID, "null buffer");
     alch_ring* r = cts->ring;
     if (pub->ring != r) return fail(ALCH_E_INVALID, "buffers belong to different rings");
@@ -2089,7 +2118,7 @@ extern "C" int alch_buf_add_public(alch_buf* cts, const alch_buf* pub, size_t pu
     else hipLaunchKernelGGL((k_add_bcast<u64>), dim3(ew_grid(words)), dim3(256), 0, r->stream, r->d64, (u64*)cts->dptr, (const u64*)pp, batch);
     HIP_TRY(hipGetLastError());
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
 // ------------------------------------------------------------------------------------------------------
 // the hot path
@@ -2355,7 +2384,7 @@ static int do_mul_relin(alch_ring* r, const alch_hint* hint, const void* a, cons
 }
 
 extern "C" int alch_ct_mul_relin(alch_ring* r, const alch_hint* hint, const alch_buf* a, const alch_buf* b, alch_buf* out,
-                                 size_t batch, const uint64_t* s_pre, unsigned flags) {
+                                 size_t batch, const uint64_t* s_pre, unsigned flags) try {
     if (!r || !hint || !a || !b || !out) return fail(ALCH_E_INVALID, "null argument");
     if (!r->has_crt) return fail(ALCH_E_NO_CRT, "this ring has no CRT basis");
     if (hint->ring != r || a->ring != r || b->ring != r || out->ring != r) return fail(ALCH_E_INVALID, "handles belong to different rings");
@@ -2397,7 +2426,7 @@ extern "C" int alch_ct_mul_relin(alch_ring* r, const alch_hint* hint, const alch
     if (rc != ALCH_OK) return rc;
     if (flags & ALCH_POW_OUT) return buf_crt(out, 0, 2 * batch, true);
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
 // ---- the complete mul_: (*) . modSwitch up . keySwitchQuadCirc . modSwitch down -------------------------------
 // Constants of the closing modSwitch that drops the first ddn limbs of `r` (outermost first): q_u^-1 mod q_t for the
@@ -2818,7 +2847,7 @@ static int mul_full_base2(const alch_hint* hint, const alch_buf* a, const alch_b
 }
 
 extern "C" int alch_ct_mul_full(const alch_hint* hint, const alch_buf* a, const alch_buf* b, alch_buf* out, size_t batch,
-                                const uint64_t* s_pre, unsigned flags) {
+                                const uint64_t* s_pre, unsigned flags) try {
     if (!hint || !a || !b || !out) return fail(ALCH_E_INVALID, "null argument");
     alch_ring* rh = hint->ring;
     alch_ring* rin = a->ring;
@@ -2856,12 +2885,12 @@ extern "C" int alch_ct_mul_full(const alch_hint* hint, const alch_buf* a, const 
     if (rin->stream != rh->stream) HIP_TRY(hipStreamWaitEvent(rin->stream, rh->ev_x, 0));
     if (rout->stream != rh->stream) HIP_TRY(hipStreamWaitEvent(rout->stream, rh->ev_x, 0));
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
 // ------------------------------------------------------------------------------------------------------
 // ring tunnelling: tunnel_ hint between two modSwitch_ (PT2CT.hs:224-229, Eval.hs:134)
 // ------------------------------------------------------------------------------------------------------
-extern "C" int alch_tunnel_info(const alch_ring* rr, const alch_ring* rs, uint32_t* e_prime, uint32_t* d_rel) {
+extern "C" int alch_tunnel_info(const alch_ring* rr, const alch_ring* rs, uint32_t* e_prime, uint32_t* d_rel) try {
     if (!rr || !rs) return fail(ALCH_E_INVALID, "null ring");
     u32 a = rr->m, b = rs->m;
     while (b) { const u32 t = a % b; a = b; b = t; }
@@ -2873,7 +2902,7 @@ extern "C" int alch_tunnel_info(const alch_ring* rr, const alch_ring* rs, uint32
     if (e_prime) *e_prime = a;
     if (d_rel) *d_rel = d;
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
 template <typename W>
 static int tunnel_to_mont(alch_ring* rs, void* dst, const void* src, size_t elems) {
@@ -2885,7 +2914,7 @@ static int tunnel_to_mont(alch_ring* rs, void* dst, const void* src, size_t elem
     return ALCH_OK;
 }
 
-extern "C" int alch_tunnel_create(alch_ring* rr, alch_ring* rs, int gadget, const alch_buf* lin_crt, const alch_buf* ks_crt, alch_tunnel** out) {
+extern "C" int alch_tunnel_create(alch_ring* rr, alch_ring* rs, int gadget, const alch_buf* lin_crt, const alch_buf* ks_crt, alch_tunnel** out) try {
     if (!rr || !rs || !lin_crt || !ks_crt || !out) return fail(ALCH_E_INVALID, "null argument");
     *out = nullptr;
     if (gadget != ALCH_GAD_TRIV && gadget != ALCH_GAD_BASE2) return fail(ALCH_E_INVALID, "unknown gadget");
@@ -2940,9 +2969,9 @@ extern "C" int alch_tunnel_create(alch_ring* rr, alch_ring* rs, int gadget, cons
     if (hipStreamSynchronize(rs->stream) != hipSuccess) { alch_tunnel_free(t); return fail(ALCH_E_HIP, "tunnel setup failed"); }
     *out = t;
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_tunnel_free(alch_tunnel* t) {
+extern "C" int alch_tunnel_free(alch_tunnel* t) try {
     if (!t) return ALCH_OK;
     (void)hipSetDevice(t->rs->device);
     (void)hipStreamSynchronize(t->rs->stream);
@@ -2954,7 +2983,7 @@ extern "C" int alch_tunnel_free(alch_tunnel* t) {
     if (t->re) alch_ring_destroy(t->re);
     delete t;
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
 // View of the last L - u limbs of a general-index ring (device tables shared with the ring itself).
 template <typename W>
@@ -3098,7 +3127,7 @@ static int do_tunnel(const alch_tunnel* t, alch_ring* rin, const void* in, void*
     return ALCH_OK;
 }
 
-extern "C" int alch_ct_tunnel(const alch_tunnel* t, const alch_buf* in, alch_buf* out, size_t batch, const uint64_t* s_pre, unsigned flags) {
+extern "C" int alch_ct_tunnel(const alch_tunnel* t, const alch_buf* in, alch_buf* out, size_t batch, const uint64_t* s_pre, unsigned flags) try {
     if (!t || !in || !out) return fail(ALCH_E_INVALID, "null argument");
     if ((in->ring != t->rr && !is_suffix_ring(in->ring, t->rr)) || out->ring != t->rs)
         return fail(ALCH_E_INVALID, "input / output buffers must belong to the tunnel's rings (the input may live on the last limbs of the R' ring)");
@@ -3131,7 +3160,7 @@ extern "C" int alch_ct_tunnel(const alch_tunnel* t, const alch_buf* in, alch_buf
         HIP_TRY(hipStreamWaitEvent(rin->stream, rs->ev_x, 0));
     }
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
 // ------------------------------------------------------------------------------------------------------
 // SymmSHE modSwitch on batches of linear ciphertexts (Eval.hs:130; PT2CT.hs:177,224-229)
@@ -3228,7 +3257,7 @@ static int do_mod_switch(alch_ring* rin, alch_ring* rout, const void* in, void* 
     return ALCH_OK;
 }
 
-extern "C" int alch_ct_mod_switch(const alch_buf* in, alch_buf* out, size_t batch, unsigned flags) {
+extern "C" int alch_ct_mod_switch(const alch_buf* in, alch_buf* out, size_t batch, unsigned flags) try {
     if (!in || !out) return fail(ALCH_E_INVALID, "null buffer");
     alch_ring* rin = in->ring;
     alch_ring* rout = out->ring;
@@ -3249,12 +3278,12 @@ extern "C" int alch_ct_mod_switch(const alch_buf* in, alch_buf* out, size_t batc
     if (rc != ALCH_OK) return rc;
     if (ro->stream != rw->stream) { HIP_TRY(hipEventRecord(rw->ev_x, rw->stream)); HIP_TRY(hipStreamWaitEvent(ro->stream, rw->ev_x, 0)); }
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
 // ------------------------------------------------------------------------------------------------------
 // modSwitch building block
 // ------------------------------------------------------------------------------------------------------
-extern "C" int alch_buf_rescale_drop0(const alch_buf* src, alch_buf* dst, size_t count) {
+extern "C" int alch_buf_rescale_drop0(const alch_buf* src, alch_buf* dst, size_t count) try {
     if (!src || !dst) return fail(ALCH_E_INVALID, "null buffer");
     alch_ring* rs = src->ring;
     alch_ring* rd = dst->ring;
@@ -3278,9 +3307,9 @@ extern "C" int alch_buf_rescale_drop0(const alch_buf* src, alch_buf* dst, size_t
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(rs->stream));
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_buf_rescale_add0(const alch_buf* src, alch_buf* dst, size_t count) {
+extern "C" int alch_buf_rescale_add0(const alch_buf* src, alch_buf* dst, size_t count) try {
     if (!src || !dst) return fail(ALCH_E_INVALID, "null buffer");
     alch_ring* rs = src->ring;
     alch_ring* rd = dst->ring;
@@ -3304,6 +3333,6 @@ extern "C" int alch_buf_rescale_add0(const alch_buf* src, alch_buf* dst, size_t 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(rd->stream));
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
 #include "tensor_ext.inc.hpp"

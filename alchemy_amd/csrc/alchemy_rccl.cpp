@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -17,6 +19,21 @@ struct alch_comm {
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 extern "C" const char* alch_rccl_last_error(void) { return g_err.c_str(); }
+// no C++ exception leaves the library: every entry point is a function-try-block ending here (as in alchemy_hip.hip)
+static int abi_catch() noexcept {
+    int code = ALCH_E_INTERNAL;
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        code = ALCH_E_NOMEM;
+        try { g_err = "out of host memory (std::bad_alloc)"; } catch (...) {}
+    } catch (const std::exception& e) {
+        try { g_err = std::string("internal error: ") + e.what(); } catch (...) {}
+    } catch (...) {
+        try { g_err = "internal error: unknown exception"; } catch (...) {}
+    }
+    return code;
+}
 
 #define NCCL_TRY(expr)                                                                                   \
     do {                                                                                                 \
@@ -24,7 +41,7 @@ extern "C" const char* alch_rccl_last_error(void) { return g_err.c_str(); }
         if (_r != ncclSuccess) return fail(ALCH_E_HIP, std::string(#expr) + ": " + ncclGetErrorString(_r)); \
     } while (0)
 
-extern "C" int alch_comm_init_all(int n_dev, alch_comm** out) {
+extern "C" int alch_comm_init_all(int n_dev, alch_comm** out) try {
     if (!out) return fail(ALCH_E_INVALID, "alch_comm_init_all: null out");
     *out = nullptr;
     if (n_dev < 1) return fail(ALCH_E_INVALID, "alch_comm_init_all: n_dev must be >= 1");
@@ -41,20 +58,20 @@ extern "C" int alch_comm_init_all(int n_dev, alch_comm** out) {
     if (rc != ncclSuccess) { delete c; return fail(ALCH_E_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(rc)); }
     *out = c;
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_comm_destroy(alch_comm* c) {
+extern "C" int alch_comm_destroy(alch_comm* c) try {
     if (!c) return ALCH_OK;
     for (ncclComm_t k : c->comms) (void)ncclCommDestroy(k);
     delete c;
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_comm_size(const alch_comm* c, int* n_dev) {
+extern "C" int alch_comm_size(const alch_comm* c, int* n_dev) try {
     if (!c || !n_dev) return fail(ALCH_E_INVALID, "null argument");
     *n_dev = c->n;
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
 namespace {
 struct RankBuf {
@@ -94,7 +111,7 @@ int resolve(const alch_comm* c, alch_buf* const* bufs, const char* what, std::ve
 }
 }  // namespace
 
-extern "C" int alch_hint_broadcast(alch_comm* c, int root, alch_buf* const* bufs, size_t first, size_t count) {
+extern "C" int alch_hint_broadcast(alch_comm* c, int root, alch_buf* const* bufs, size_t first, size_t count) try {
     std::vector<RankBuf> b;
     int rc = resolve(c, bufs, "alch_hint_broadcast", b);
     if (rc != ALCH_OK) return rc;
@@ -109,9 +126,9 @@ extern "C" int alch_hint_broadcast(alch_comm* c, int root, alch_buf* const* bufs
     }
     NCCL_TRY(ncclGroupEnd());
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_buf_all_gather(alch_comm* c, alch_buf* const* src, size_t first, size_t count, alch_buf* const* dst) {
+extern "C" int alch_buf_all_gather(alch_comm* c, alch_buf* const* src, size_t first, size_t count, alch_buf* const* dst) try {
     std::vector<RankBuf> s, d;
     int rc = resolve(c, src, "alch_buf_all_gather (src)", s);
     if (rc != ALCH_OK) return rc;
@@ -132,4 +149,4 @@ extern "C" int alch_buf_all_gather(alch_comm* c, alch_buf* const* src, size_t fi
     }
     NCCL_TRY(ncclGroupEnd());
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }

@@ -135,7 +135,7 @@ static int ext_gather(alch_ring* work, const void* in, void* out, const int32_t*
     return ALCH_OK;
 }
 
-extern "C" int alch_buf_embed(alch_buf* dst, const alch_buf* src, size_t count, int basis) {
+extern "C" int alch_buf_embed(alch_buf* dst, const alch_buf* src, size_t count, int basis) try {
     if (!dst || !src) return fail(ALCH_E_INVALID, "null buffer");
     alch_ring* big = dst->ring;
     alch_ring* small = src->ring;
@@ -162,9 +162,9 @@ extern "C" int alch_buf_embed(alch_buf* dst, const alch_buf* src, size_t count, 
     if (rc != ALCH_OK) return rc;
     if (basis == ALCH_BASIS_DEC && big->gen && big->gh.rad > 1 && (rc = columns(big, GEN_LINV, dst->dptr, 0, count, 1)) != ALCH_OK) return rc;
     return ext_order(big, small, false);
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_buf_twace(alch_buf* dst, const alch_buf* src, size_t count, int basis) {
+extern "C" int alch_buf_twace(alch_buf* dst, const alch_buf* src, size_t count, int basis) try {
     if (!dst || !src) return fail(ALCH_E_INVALID, "null buffer");
     alch_ring* small = dst->ring;
     alch_ring* big = src->ring;
@@ -207,9 +207,9 @@ extern "C" int alch_buf_twace(alch_buf* dst, const alch_buf* src, size_t count, 
     }
     HIP_TRY(hipGetLastError());
     return ext_order(small, big, false);
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_buf_coeffs(alch_buf* dst, const alch_buf* src, size_t count) {
+extern "C" int alch_buf_coeffs(alch_buf* dst, const alch_buf* src, size_t count) try {
     if (!dst || !src) return fail(ALCH_E_INVALID, "null buffer");
     alch_ring* small = dst->ring;
     alch_ring* big = src->ring;
@@ -224,7 +224,7 @@ extern "C" int alch_buf_coeffs(alch_buf* dst, const alch_buf* src, size_t count)
                           : ext_gather<u64>(small, src->dptr, dst->dptr, t->coeffs, big->n, small->n, t->d_rel, count);
     if (rc != ALCH_OK) return rc;
     return ext_order(small, big, false);
-}
+} catch (...) { return abi_catch(); }
 
 // ---- host-buffer forms (one ring element, Lol layout), staged through fresh device buffers of both rings ----
 static int ext_host(alch_ring* small, alch_ring* big, const int64_t* in, int64_t* out, int which /* 0 embed, 1 twace, 2 coeffs */, int basis) {
@@ -250,15 +250,15 @@ static int ext_host(alch_ring* small, alch_ring* big, const int64_t* in, int64_t
     return rc;
 }
 
-extern "C" int alch_embed_pow(alch_ring* s, alch_ring* b, const int64_t* in, int64_t* out) { return ext_host(s, b, in, out, 0, ALCH_BASIS_POW); }
-extern "C" int alch_embed_dec(alch_ring* s, alch_ring* b, const int64_t* in, int64_t* out) { return ext_host(s, b, in, out, 0, ALCH_BASIS_DEC); }
-extern "C" int alch_embed_crt(alch_ring* s, alch_ring* b, const int64_t* in, int64_t* out) { return ext_host(s, b, in, out, 0, ALCH_BASIS_CRT); }
-extern "C" int alch_twace_pow_dec(alch_ring* s, alch_ring* b, const int64_t* in, int64_t* out) { return ext_host(s, b, in, out, 1, ALCH_BASIS_POW); }
-extern "C" int alch_twace_crt(alch_ring* s, alch_ring* b, const int64_t* in, int64_t* out) { return ext_host(s, b, in, out, 1, ALCH_BASIS_CRT); }
-extern "C" int alch_coeffs(alch_ring* s, alch_ring* b, const int64_t* in, int64_t* out) { return ext_host(s, b, in, out, 2, ALCH_BASIS_POW); }
+extern "C" int alch_embed_pow(alch_ring* s, alch_ring* b, const int64_t* in, int64_t* out) try { return ext_host(s, b, in, out, 0, ALCH_BASIS_POW); } catch (...) { return abi_catch(); }
+extern "C" int alch_embed_dec(alch_ring* s, alch_ring* b, const int64_t* in, int64_t* out) try { return ext_host(s, b, in, out, 0, ALCH_BASIS_DEC); } catch (...) { return abi_catch(); }
+extern "C" int alch_embed_crt(alch_ring* s, alch_ring* b, const int64_t* in, int64_t* out) try { return ext_host(s, b, in, out, 0, ALCH_BASIS_CRT); } catch (...) { return abi_catch(); }
+extern "C" int alch_twace_pow_dec(alch_ring* s, alch_ring* b, const int64_t* in, int64_t* out) try { return ext_host(s, b, in, out, 1, ALCH_BASIS_POW); } catch (...) { return abi_catch(); }
+extern "C" int alch_twace_crt(alch_ring* s, alch_ring* b, const int64_t* in, int64_t* out) try { return ext_host(s, b, in, out, 1, ALCH_BASIS_CRT); } catch (...) { return abi_catch(); }
+extern "C" int alch_coeffs(alch_ring* s, alch_ring* b, const int64_t* in, int64_t* out) try { return ext_host(s, b, in, out, 2, ALCH_BASIS_POW); } catch (...) { return abi_catch(); }
 
 // ---- host-only tables --------------------------------------------------------------------------------------
-extern "C" int alch_ext_table(uint32_t m_small, uint32_t m_big, int which, int32_t* out, size_t* len) {
+extern "C" int alch_ext_table(uint32_t m_small, uint32_t m_big, int which, int32_t* out, size_t* len) try {
     if (!len) return fail(ALCH_E_INVALID, "null argument");
     ExtHost h;
     int rc = ext_host_tables(m_small, m_big, h);
@@ -277,9 +277,9 @@ extern "C" int alch_ext_table(uint32_t m_small, uint32_t m_big, int which, int32
     }
     *len = v->size();
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }
 
-extern "C" int alch_crt_set_dec(uint32_t m_small, uint32_t m_big, uint32_t p, int64_t* out, size_t* count) {
+extern "C" int alch_crt_set_dec(uint32_t m_small, uint32_t m_big, uint32_t p, int64_t* out, size_t* count) try {
     if (!count) return fail(ALCH_E_INVALID, "null argument");
     std::vector<int64_t> v;
     size_t c = 0;
@@ -296,4 +296,4 @@ extern "C" int alch_crt_set_dec(uint32_t m_small, uint32_t m_big, uint32_t p, in
     std::copy(v.begin(), v.end(), out);
     *count = c;
     return ALCH_OK;
-}
+} catch (...) { return abi_catch(); }

@@ -10,7 +10,8 @@
  * the Haskell-side stub.
  *
  * Conventions
- *   - plain C: no C++ types, no exceptions across the ABI.  Every function returns an int status
+ *   - plain C: no C++ types, no exceptions across the ABI (every entry point catches: std::bad_alloc -> ALCH_E_NOMEM,
+ *     anything else -> ALCH_E_INTERNAL).  Every function returns an int status
  *     (ALCH_OK == 0, negative == error); alch_last_error() gives a thread-local message.
  *   - ring R'_q = Z_q[zeta_m], ANY cyclotomic index m whose odd prime factors are <= 13 (the reference's
  *     ciphertext indices are H0' = F11648 .. H5' = F20475 = 2^a 3^b 5^c 7 13, examples/Common.hs:38-54) with
@@ -55,7 +56,8 @@ extern "C" {
                                       limb-polynomial larger than the LDS, q >= 2^62 */
 #define ALCH_E_NO_DEVICE (-5)      /* no gfx950 device / HIP runtime error at init */
 #define ALCH_E_HIP (-6)            /* HIP runtime error (message in alch_last_error) */
-#define ALCH_E_NOMEM (-7)
+#define ALCH_E_NOMEM (-7)          /* device or host allocation failed */
+#define ALCH_E_INTERNAL (-8)       /* a C++ exception was caught at the ABI (never crosses it); message in alch_last_error */
 #define ALCH_NOT_DIVISIBLE 1       /* divG family: Lol's Nothing */
 
 /* bases of alch_buf_mulg / alch_buf_divg */

@@ -1,0 +1,22 @@
+import json, sys, time, os
+sys.path.insert(0, '/root/repo')
+from alchemy_amd.tunnelhops import Hop
+B = int(sys.argv[1]); K = int(sys.argv[2]); share = int(sys.argv[3]); reps = 4
+for k in range(5):
+    hops = [Hop(k, B // K) for _ in range(K)]
+    if share:
+        for h in hops:
+            rs = list(h._rings.values())
+            for r in rs[1:]:
+                r.share_stream(rs[0])
+    for h in hops: h.run()
+    for h in hops:
+        for r in h._rings.values(): r.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for h in hops: h.run()
+    for h in hops:
+        for r in h._rings.values(): r.sync()
+    dt = (time.perf_counter() - t0) / reps
+    print(json.dumps({"hop": k, "B": B, "K": K, "share": share, "tunnels_per_s": B / dt}), flush=True)
+    del hops
