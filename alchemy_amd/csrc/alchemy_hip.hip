@@ -1298,6 +1298,26 @@ extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) 
     else if (k == "split_fused") { if (value < 0 || value > 2) return fail(ALCH_E_INVALID, "split_fused: 0, 1 or 2"); r->opts.split_fused = (int)value; }
     else if (k == "scratch_mib") { if (value < 1 || value > 65536) return fail(ALCH_E_INVALID, "scratch_mib must be 1 .. 65536"); r->scratch_mib = (size_t)value; }
     else if (k == "rs_slots") { if (value < 1) return fail(ALCH_E_INVALID, "rs_slots must be >= 1"); r->rs_slots = (unsigned)value; }
+    else if (k == "stream_dedicated") {
+        // A new stream with an (all-ones) CU mask replaces the ring's: the HIP runtime gives such a stream a hardware queue of its own.
+        // Ordinary streams share the runtime's pool of hardware queues (4 by default) by a rule that depends on how many streams the
+        // process holds, so two "independent" streams land on ONE queue every other time and their kernels run one after the other
+        // (measured with tools/queue_probe.py: the two sub-batches of the HomomRLWR pipeline at 44.7 k instead of 50.5 k pipelines/s
+        // for every odd number of other rings alive; stream priorities do not separate them reliably either: 46 k every other time).
+        // For hosts that run independent sub-batches side by side (alchemy_amd/ringround.py); every dedicated stream costs a
+        // hardware queue, so it is an option, not the default of the hundreds of rings a Lol host creates.
+        if (value != 1) return fail(ALCH_E_INVALID, "stream_dedicated: 1");
+        BIND(r);
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, r->device));
+        std::vector<uint32_t> mask((size_t)(prop.multiProcessorCount + 31) / 32, 0xffffffffu);
+        if (prop.multiProcessorCount % 32) mask.back() = (1u << (prop.multiProcessorCount % 32)) - 1u;
+        hipStream_t ns = nullptr;
+        HIP_TRY(hipExtStreamCreateWithCUMask(&ns, (uint32_t)mask.size(), mask.data()));
+        r->stream_owner = std::make_shared<StreamOwner>(ns, r->device);      // the old stream goes with its last user
+        r->stream = ns;
+    }
     else return fail(ALCH_E_INVALID, "unknown option '" + k + "'");
     return ALCH_OK;
 } catch (...) { return abi_catch(); }

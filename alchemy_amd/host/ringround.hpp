@@ -48,7 +48,9 @@ struct Limbs { int lin, lh, lout; };
 class RingRound {
 public:
     // first: index of this object's first ciphertext in the whole seeded batch (a lane of `Lanes` below, a shard of a multi-GPU run)
-    explicit RingRound(size_t batch, size_t first_ct = 0) : B(batch), first(first_ct) {
+    // dedicated_stream: the chain's one stream gets a hardware queue of its own (Lanes: two ordinary streams share a queue every other
+    // time and then run one after the other -- include/alchemy_hip.h, "stream_dedicated")
+    explicit RingRound(size_t batch, size_t first_ct = 0, bool dedicated_stream = false) : B(batch), first(first_ct), dedicated(dedicated_stream) {
         int p = 0;
         Limbs m[4], t[5];
         for (int i = 3; i >= 0; --i) check(alch_select_limbs(QS, 6, ALCH_OP_MUL, ALCH_GAD_TRIV, p, &m[i].lin, &m[i].lh, &m[i].lout, &p), "alch_select_limbs");
@@ -178,6 +180,7 @@ public:
     }
 
     const size_t B, first;
+    const bool dedicated;
     std::vector<Limbs> muls, tuns;
     std::vector<uint32_t> drel;
 
@@ -191,6 +194,7 @@ private:
             check(alch_ring_create(m, L, q.data(), &r), "alch_ring_create");
             // the op sequence is one dependency chain: all rings queue on the first ring's stream (no event per ring-to-ring hand-off)
             if (!rings.empty()) check(alch_ring_share_stream(r, rings.begin()->second), "alch_ring_share_stream");
+            else if (dedicated) check(alch_ring_set_option(r, "stream_dedicated", 1), "alch_ring_set_option");
             it = rings.emplace(key, r).first;
         }
         return it->second;
@@ -231,7 +235,7 @@ public:
         size_t at = 0;
         for (int i = 0; i < lanes; ++i) {
             const size_t b = batch / (size_t)lanes + ((size_t)i < batch % (size_t)lanes ? 1 : 0);
-            lane.emplace_back(new RingRound(b, first_ct + at));
+            lane.emplace_back(new RingRound(b, first_ct + at, true));
             firsts.push_back(at);
             at += b;
         }

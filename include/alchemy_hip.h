@@ -142,7 +142,10 @@ int alch_ring_set_stream(alch_ring *ring, void *hip_stream);
  * kernel, default 4096), "ti_split" / "ti_grid" (form and grid of the tensor + crtInv kernel), "crt_half" (0 = whole-polynomial crt at 128 KiB), "rs_half" (1 = the closing rescale at n = 2^15 always as two launches of half-size workgroups), "tunnel_ep" (read by alch_tunnel_create on ring_s: 0 = transform
  * the embedded E'-coefficients at dimension phi(s') instead of phi(e')), "tunnel_fused" (alch_ct_tunnel with TrivGad hints: 2 or 4 = digit transforms and hint products in one kernel with that many digits side by side, 0 = through HBM), "tunnel_mac" (0 = the tunnel's hint inner product one Montgomery product at a time behind a separate evalLin pass; default 1: lazy 64-bit groups, k_tunnel_mac_e), "gen_nt" (threads per workgroup of the general-index transform kernels: 128, 256, 512; 0 = by ring size), "rs_lin" / "gen_fused" (0 = the
  * composed forms of the closing rescale / the general-index key switch), "scratch_mib", "rs_slots" (resident
- * workgroups of the closing rescale kernel; for alch_ct_mul_full the options of the hint's ring apply). */
+ * workgroups of the closing rescale kernel; for alch_ct_mul_full the options of the hint's ring apply), "stream_dedicated" (1: the ring
+ * gets a NEW stream with a hardware queue of its own -- set it before other rings borrow the stream.  Ordinary streams share the HIP
+ * runtime's few hardware queues, and two streams that land on one queue run their kernels one after the other; a host that runs
+ * independent sub-batches side by side gives each a dedicated stream, see alchemy_amd/ringround.py). */
 int alch_ring_set_option(alch_ring *ring, const char *name, long value);
 int alch_sync(alch_ring *ring);
 /* HIP-event timer on the ring's stream (what bench.py brackets the timed region with). */

@@ -10,7 +10,7 @@ cp $d/${tag}_stats_kernel_stats.csv profiles/${tag}_kernel_stats.csv
 cp $d/${tag}_stats1_kernel_stats.csv profiles/${tag}_kernel_stats_one_stream_all_lines.csv
 cp $d/${tag}_general_kernel_stats.csv profiles/${tag}_general_kernel_stats.csv
 cp $d/${tag}_homom_kernel_stats.csv profiles/${tag}_homomrlwr_kernel_stats.csv
-for f in general_index homomrlwr_pipeline tunnel_base2 config2 crt_half extra; do cp $d/${tag}_$f.jsonl profiles/; done
+for f in general_index homomrlwr_pipeline homomrlwr_pipeline_1024 homomrlwr_pipeline_1024_1lane tunnel_base2 config2 crt_half extra; do cp $d/${tag}_$f.jsonl profiles/; done
 cp $d/traffic.json profiles/${tag}_traffic_pmc.json
 cp $d/traffic.json profiles/traffic_latest.json
 cat $d/commands.txt gpurun_out/pmc_$tag/commands.txt > profiles/${tag}_commands.txt

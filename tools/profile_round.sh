@@ -26,6 +26,8 @@ cd "$root"
 tool() { name=$1; shift; echo "== $name: $*" >> "$out/commands.txt"; timeout -k 10 300 "$@" 2> "$out/$name.err" | grep "^{" > "$out/${tag}_$name.jsonl" || echo "$name failed" >> "$out/commands.txt"; }
 tool general_index       python3 tools/bench_general.py
 tool homomrlwr_pipeline  python3 tools/bench_homomrlwr.py 4096
+tool homomrlwr_pipeline_1024        python3 tools/bench_homomrlwr.py 1024
+tool homomrlwr_pipeline_1024_1lane  python3 tools/bench_homomrlwr.py 1024 lanes=1
 tool tunnel_base2        python3 tools/bench_tunnel.py
 tool config2             python3 tools/bench_config2.py
 tool crt_half            python3 tools/bench_crt_half.py
