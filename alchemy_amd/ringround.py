@@ -204,6 +204,13 @@ class RingRound:
         return (time.perf_counter() - t0) / passes, out
 
 
+def lane_split(batch, lanes):
+    """Contiguous sub-batches of a batch: (sizes, first ciphertext of each); sizes differ by at most one, no lane is empty."""
+    lanes = max(1, min(lanes, batch))
+    sizes = [batch // lanes + (1 if i < batch % lanes else 0) for i in range(lanes)]
+    return sizes, [sum(sizes[:i]) for i in range(lanes)]
+
+
 class RingRoundLanes:
     """The same batch as `lanes` contiguous sub-batches, each a RingRound of its own on its own HIP stream (its own rings, hints and
     scratch; same seeds, so the union of the results is word for word RingRound(batch)'s).  The op sequence of one sub-batch is a
@@ -212,9 +219,7 @@ class RingRoundLanes:
     1 lane 46.6 k pipelines/s, 2 lanes 51.8 k, 4 lanes 48.9 k, 8 lanes 48.2 k -- two is the default, as for the headline's two chunk pipelines."""
 
     def __init__(self, batch, lanes=2, ring_opts=(), pow_handoff=True):
-        lanes = max(1, min(lanes, batch))
-        sizes = [batch // lanes + (1 if i < batch % lanes else 0) for i in range(lanes)]
-        firsts = [sum(sizes[:i]) for i in range(lanes)]
+        sizes, firsts = lane_split(batch, lanes)
         self.B, self.sizes, self.firsts = batch, sizes, firsts
         # every lane's stream gets a hardware queue of its own ("stream_dedicated", include/alchemy_hip.h): two ordinary streams share a
         # queue every other time, and two chains on one queue run one after the other (44.7 k instead of 50.5 k pipelines/s)

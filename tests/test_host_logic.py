@@ -148,3 +148,15 @@ def test_select_limbs_reproduces_pt2ct_type_level_choices():
     assert capi.select_limbs(rlwr, 11, capi.ALCH_OP_MUL, capi.ALCH_GAD_BASE2)[:3] == (4, 3, 3)
     with pytest.raises(A.AlchemyError):
         capi.select_limbs(arith, 9)                      # "You need more/bigger moduli!"
+
+
+def test_lane_split_of_the_pipeline_batch():
+    """alchemy_amd.ringround.lane_split (the sub-batches RingRoundLanes / ringround::Lanes run side by side): contiguous, covering,
+    sizes within one of each other, never an empty lane."""
+    from alchemy_amd.ringround import lane_split
+    for batch in (1, 2, 5, 9, 70, 1024, 1025):
+        for lanes in (1, 2, 3, 4, 8, 2000):
+            sizes, firsts = lane_split(batch, lanes)
+            assert len(sizes) == min(lanes, batch) and sum(sizes) == batch and min(sizes) >= 1 and max(sizes) - min(sizes) <= 1
+            assert firsts == [sum(sizes[:i]) for i in range(len(sizes))]
+    assert lane_split(1024, 2) == ([512, 512], [0, 512]) and lane_split(70, 3) == ([24, 23, 23], [0, 24, 47])
