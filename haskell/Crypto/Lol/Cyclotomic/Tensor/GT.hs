@@ -69,7 +69,7 @@ import Control.Monad                           (when)
 import Control.Monad.Random                    (Random (..))
 import Data.Constraint                         (Dict (..), (:-) (..), (\\))
 import Data.Int
-import Data.IORef
+import Control.Concurrent.MVar                 (MVar, modifyMVar, newMVar)
 import qualified Data.Map.Strict               as M
 import Data.Tagged                             (witness)
 import qualified Data.Vector.Storable          as SV
@@ -185,16 +185,17 @@ data RingAns = Served !(Ptr AlchRing)   -- ^ ALCH_OK
 
 -- | One library context per (index, modulus list, with / without CRT), created on first use and kept for the process lifetime.
 -- All contexts queue on the stream of the first one ('c_ringShareStream'): Tensor calls arrive one at a time, so calls between
--- two rings (embed, twace, coeffs) need no events.
+-- two rings (embed, twace, coeffs) need no events.  The cache sits behind an 'MVar': pure code forces tensors from any thread of a
+-- @-threaded@ program, and two threads that miss on the same key must not both create the ring (nor lose the shared stream's owner);
+-- an exception inside 'modifyMVar' leaves the cache as it was.
 {-# NOINLINE ringCache #-}
-ringCache :: IORef (M.Map (Word32, [Word64], Bool) RingAns, Maybe (Ptr AlchRing))
-ringCache = unsafePerformIO (newIORef (M.empty, Nothing))
+ringCache :: MVar (M.Map (Word32, [Word64], Bool) RingAns, Maybe (Ptr AlchRing))
+ringCache = unsafePerformIO (newMVar (M.empty, Nothing))
 
 ringFor :: Bool -> Word32 -> [Word64] -> IO RingAns
-ringFor noCRT m qs = do
-  (cache, first) <- readIORef ringCache
+ringFor noCRT m qs = modifyMVar ringCache $ \st@(cache, first) ->
   case M.lookup (m, qs, noCRT) cache of
-    Just a  -> return a
+    Just a  -> return (st, a)
     Nothing -> alloca $ \out -> withArrayLen qs $ \n pq -> do
       rc <- (if noCRT then c_ringCreateNoCRT else c_ringCreate) m (fromIntegral n) pq out
       ans <- case rc of
@@ -206,8 +207,7 @@ ringFor noCRT m qs = do
         _    -> c_lastError >>= peekCString >>= \e ->               -- no device, HIP failure, out of memory, malformed call:
                   ioError (userError ("alch_ring_create: " ++ e))   -- not a Lol Nothing; this backend has no CPU fallback
       let first' = case (first, ans) of { (Nothing, Served r) -> Just r; _ -> first }
-      writeIORef ringCache (M.insert (m, qs, noCRT) ans cache, first')
-      return ans
+      return ((M.insert (m, qs, noCRT) ans cache, first'), ans)
 
 -- | The ring that serves the Pow / Dec methods (and holds the device values) of index @m@ over @r@: the ring with CRT basis when
 -- there is one, else the ring without; @Nothing@ = this (index, element type) is lol-cpp's.
