@@ -191,7 +191,25 @@ extern "C" int alch_debug_throw(int kind) try {
 
 // HIP's current device is per host thread: every entry point first makes the ring's device current, so a host that
 // calls from another OS thread (Haskell `safe` FFI calls on a -threaded RTS) still launches on the right GPU.
+// Every entry point that touches a ring also takes the lock of the ring's DEVICE for the length of the call (recursive: entry points
+// call each other).  A ring's scratch, pools and events are plain members, and calls between rings (embed / twace, tunnels, mul_ over
+// three rings) touch several rings at once, so the unit of mutual exclusion is the device: a host that forces tensors from several
+// threads (a -threaded Haskell RTS, parallel sparks) gets serialised launches instead of corrupted scratch, and threads that drive
+// different GPUs (examples/ringround_multi.cpp) never meet.  alch_buf_free / alch_hint_free / alch_tunnel_free stay outside it: they
+// come from finalizer threads and must not wait behind a call that is synchronising the device.
+static std::recursive_mutex& device_mutex(int dev) {
+    static std::recursive_mutex mu[64];
+    return mu[(dev >= 0 && dev < 64) ? dev : 0];
+}
+#define ALCH_CAT2(a, b) a##b
+#define ALCH_CAT(a, b) ALCH_CAT2(a, b)
+#ifndef ALCH_NO_DEVICE_LOCK
+#define ALCH_DEVICE_LOCK(dev) std::lock_guard<std::recursive_mutex> ALCH_CAT(_alch_dev_lock_, __LINE__)(device_mutex(dev))
+#else
+#define ALCH_DEVICE_LOCK(dev) ((void)0)   // tests/test_gpu_threads.py's self-test only (tools/build_variant.sh nolock): never in a product build
+#endif
 #define BIND(ringp)                                                                                     \
+    ALCH_DEVICE_LOCK((ringp)->device);                                                                  \
     do {                                                                                                \
         if (hipSetDevice((ringp)->device) != hipSuccess)                                                \
             return fail(ALCH_E_HIP, "hipSetDevice(" + std::to_string((ringp)->device) + ") failed");    \
@@ -1217,6 +1235,7 @@ extern "C" int alch_ring_create_nocrt(uint32_t m, int L, const uint64_t* q, alch
 
 extern "C" int alch_ring_destroy(alch_ring* r) try {
     if (!r) return ALCH_OK;
+    ALCH_DEVICE_LOCK(r->device);
     (void)hipSetDevice(r->device);
     if (r->scratch) { alch_buf* b = r->scratch; r->scratch = nullptr; (void)hipFree(b->dptr); delete b; }
     if (r->stream) (void)hipStreamSynchronize(r->stream);

@@ -31,10 +31,12 @@
  *            generator of Z_q^*, u = i0 + p i1 (mod m_l) where s_l = (i0 - 1) m'_l + digitrev_p(i1);
  *            for a two-power index: slot k holds a(psi^(2*brev(k)+1)), psi = omega_m.
  *       g    = prod_{odd p | m} (1 - zeta_p)   (1 for a two-power index)
- *   - all work is queued on the ring's HIP stream; alch_sync() waits for it.  Entry points are
- *     re-entrant across rings; one ring must not be driven from two threads at once.  A ring is bound to the
- *     HIP device that was current when it was created; every entry point makes that device current for the
- *     calling thread first, so rings may be used from any OS thread (Haskell `safe` calls on a -threaded RTS).
+ *   - all work is queued on the ring's HIP stream; alch_sync() waits for it.  Entry points are thread-safe: a call that
+ *     touches a ring holds the lock of that ring's DEVICE until it returns (calls on one GPU are serialised -- they only queue
+ *     work --, calls on different GPUs run side by side), so a host may force tensors from any number of threads (a -threaded
+ *     Haskell RTS).  The *_free functions do not take it (finalizer threads): free a handle only when no call is using it.
+ *     A ring is bound to the HIP device that was current when it was created; every entry point makes that device current for
+ *     the calling thread first, so rings may be used from any OS thread (Haskell `safe` calls).
  *   - there is NO CPU fallback: without a gfx950 device every compute entry point fails with
  *     ALCH_E_NO_DEVICE.
  */

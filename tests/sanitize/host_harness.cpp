@@ -33,6 +33,7 @@ hipError_t hipMemcpy(void*, const void*, size_t, int) { return NO_DEVICE; }
 hipError_t hipMemcpyAsync(void*, const void*, size_t, int, void*) { return NO_DEVICE; }
 hipError_t hipMemsetAsync(void*, int, size_t, void*) { return NO_DEVICE; }
 hipError_t hipStreamCreateWithFlags(void**, unsigned) { return NO_DEVICE; }
+hipError_t hipExtStreamCreateWithCUMask(void**, unsigned, const unsigned*) { return NO_DEVICE; }
 hipError_t hipStreamDestroy(void*) { return NO_DEVICE; }
 hipError_t hipStreamSynchronize(void*) { return NO_DEVICE; }
 hipError_t hipStreamWaitEvent(void*, void*, unsigned) { return NO_DEVICE; }
