@@ -1,5 +1,7 @@
+"""Probe (recorded dead end): a Tunnel.hs hop as K sub-batches on K streams.  usage: tools/hop_lanes_probe.py BATCH K SHARE_STREAM
+Measured: 378 -> 383 / 180 -> 189 / 538 -> 535 / 543 -> 547 / 899 -> 868 k tunnels/s for K = 1 -> 2: two big VALU-bound kernels dominate a hop."""
 import json, sys, time, os
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from alchemy_amd.tunnelhops import Hop
 B = int(sys.argv[1]); K = int(sys.argv[2]); share = int(sys.argv[3]); reps = 4
 for k in range(5):

@@ -2,7 +2,7 @@
 streams the lanes shared a hardware queue for every odd D (44.7 k instead of 50.5 k pipelines/s); with the dedicated streams RingRoundLanes
 asks for (option stream_dedicated) every D gives 50.5 k (profiles/r04_queue_probe.txt)."""
 import json, sys, time, os
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import alchemy_amd as A
 from alchemy_amd.ringround import RingRoundLanes
 QS = [1543651201, 689270401, 718099201, 720720001]

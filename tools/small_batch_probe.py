@@ -1,5 +1,7 @@
-import sys, json, time
-sys.path.insert(0, '/root/repo')
+"""Probe (recorded dead end): alch_ct_mul_relin / alch_ct_mul_full at n = 2^15 on batches of 256 .. 2048 with the launch option
+`chunk` 128 .. 1024 -- the persistent-grid kernels have no tails to overlap: +-2 %."""
+import sys, json, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import alchemy_amd as A
 from alchemy_amd import capi
 qs = [2147352577, 2146959361, 2146041857, 2145976321]
