@@ -4,6 +4,7 @@
 // No CPU fallback lives here: every compute entry point needs a gfx950 device and reports
 // ALCH_E_NO_DEVICE / ALCH_E_HIP otherwise.  Nothing in this library includes or links oracle/.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -35,11 +36,20 @@ struct ExtTab {
     int32_t* fibres = nullptr;         // [n_small][fibre]: CRT slots of the big ring above a slot of the small ring (twaceCRT)
 };
 
+// live streams with a hardware queue of their own (ring option "stream_dedicated"): capped, because the HIP runtime does not survive
+// running out of hardware queues (observed: a segmentation fault inside the runtime after ~250 such streams in one process)
+static std::atomic<int> g_dedicated_streams{0};
+constexpr int MAX_DEDICATED_STREAMS = 32;
+
 struct StreamOwner {
     hipStream_t s;
     int device;
-    StreamOwner(hipStream_t s_, int d) : s(s_), device(d) {}
-    ~StreamOwner() { if (s) { (void)hipSetDevice(device); (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } }
+    bool dedicated;
+    StreamOwner(hipStream_t s_, int d, bool dedicated_ = false) : s(s_), device(d), dedicated(dedicated_) {}
+    ~StreamOwner() {
+        if (s) { (void)hipSetDevice(device); (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+        if (dedicated) --g_dedicated_streams;
+    }
     StreamOwner(const StreamOwner&) = delete;
     StreamOwner& operator=(const StreamOwner&) = delete;
 };
@@ -1327,6 +1337,12 @@ extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) 
         // hardware queue, so it is an option, not the default of the hundreds of rings a Lol host creates.
         if (value != 1) return fail(ALCH_E_INVALID, "stream_dedicated: 1");
         BIND(r);
+        if (++g_dedicated_streams > MAX_DEDICATED_STREAMS) {
+            --g_dedicated_streams;
+            return fail(ALCH_E_UNSUPPORTED, "stream_dedicated: " + std::to_string(MAX_DEDICATED_STREAMS) + " dedicated streams are alive in this process already "
+                                            "(each holds a hardware queue; the ring keeps its ordinary stream)");
+        }
+        struct Undo { bool armed = true; ~Undo() { if (armed) --g_dedicated_streams; } } undo;       // any failure below gives the slot back
         HIP_TRY(hipStreamSynchronize(r->stream));
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, r->device));
@@ -1334,7 +1350,8 @@ extern "C" int alch_ring_set_option(alch_ring* r, const char* name, long value) 
         if (prop.multiProcessorCount % 32) mask.back() = (1u << (prop.multiProcessorCount % 32)) - 1u;
         hipStream_t ns = nullptr;
         HIP_TRY(hipExtStreamCreateWithCUMask(&ns, (uint32_t)mask.size(), mask.data()));
-        r->stream_owner = std::make_shared<StreamOwner>(ns, r->device);      // the old stream goes with its last user
+        r->stream_owner = std::make_shared<StreamOwner>(ns, r->device, true);   // the old stream goes with its last user
+        undo.armed = false;                                                      // the owner returns the slot when the stream dies
         r->stream = ns;
     }
     else return fail(ALCH_E_INVALID, "unknown option '" + k + "'");

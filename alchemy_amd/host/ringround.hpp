@@ -194,7 +194,10 @@ private:
             check(alch_ring_create(m, L, q.data(), &r), "alch_ring_create");
             // the op sequence is one dependency chain: all rings queue on the first ring's stream (no event per ring-to-ring hand-off)
             if (!rings.empty()) check(alch_ring_share_stream(r, rings.begin()->second), "alch_ring_share_stream");
-            else if (dedicated) check(alch_ring_set_option(r, "stream_dedicated", 1), "alch_ring_set_option");
+            else if (dedicated) {
+                const int rc = alch_ring_set_option(r, "stream_dedicated", 1);
+                if (rc != ALCH_OK && rc != ALCH_E_UNSUPPORTED) check(rc, "alch_ring_set_option");   // UNSUPPORTED: the process holds its share of dedicated streams -- an ordinary one is still correct
+            }
             it = rings.emplace(key, r).first;
         }
         return it->second;

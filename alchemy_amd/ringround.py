@@ -67,7 +67,11 @@ class RingRound:
             if self.one_stream and self.rings:
                 r.share_stream(next(iter(self.rings.values())))
             elif self.dedicated_stream:
-                r.set_option("stream_dedicated", 1)
+                try:
+                    r.set_option("stream_dedicated", 1)
+                except capi.AlchemyError as e:       # the process holds its 32 dedicated streams already: an ordinary stream is still correct
+                    if e.code != capi.ALCH_E_UNSUPPORTED:
+                        raise
             self.rings[(m, L)] = r
         return self.rings[(m, L)]
 

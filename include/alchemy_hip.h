@@ -147,7 +147,8 @@ int alch_ring_set_stream(alch_ring *ring, void *hip_stream);
  * workgroups of the closing rescale kernel; for alch_ct_mul_full the options of the hint's ring apply), "stream_dedicated" (1: the ring
  * gets a NEW stream with a hardware queue of its own -- set it before other rings borrow the stream.  Ordinary streams share the HIP
  * runtime's few hardware queues, and two streams that land on one queue run their kernels one after the other; a host that runs
- * independent sub-batches side by side gives each a dedicated stream, see alchemy_amd/ringround.py). */
+ * independent sub-batches side by side gives each a dedicated stream (at most 32 alive per process: ALCH_E_UNSUPPORTED beyond, the ring
+ * keeps its ordinary stream), see alchemy_amd/ringround.py). */
 int alch_ring_set_option(alch_ring *ring, const char *name, long value);
 int alch_sync(alch_ring *ring);
 /* HIP-event timer on the ring's stream (what bench.py brackets the timed region with). */

@@ -169,6 +169,35 @@ def test_shared_stream_outlives_the_ring_that_created_it():
     third.close()
 
 
+def test_dedicated_streams_are_capped_and_refused_gracefully():
+    """Option stream_dedicated: at most 32 alive per process (the HIP runtime does not survive running out of hardware queues); beyond
+    that the call fails with ALCH_E_UNSUPPORTED and the ring keeps working on its ordinary stream; destroying a ring frees its slot."""
+    qs = RLWR_QS[:1]
+    rings, refused = [], 0
+    for _ in range(40):
+        r = A.Ring(128 * 7, qs)
+        rings.append(r)
+        try:
+            r.set_option("stream_dedicated", 1)
+        except capi.AlchemyError as e:
+            assert e.code == capi.ALCH_E_UNSUPPORTED
+            refused += 1
+    assert 8 <= refused < 40                                       # other tests of this process may hold a few dedicated streams
+    rng = np.random.default_rng(8)
+    x = rand_elems(rng, 1, rings[0].n, qs)
+    for r in (rings[0], rings[-1]):                                # a dedicated one and a refused one
+        b = r.upload(x); b.crt(); b.crtinv()
+        assert np.array_equal(b.download(), x)
+        b.free()
+    rings[0].close()                                               # its slot is free again
+    rings[-1].set_option("stream_dedicated", 1)
+    b = rings[-1].upload(x); b.crt(); b.crtinv()
+    assert np.array_equal(b.download(), x)
+    b.free()
+    for r in rings[1:]:
+        r.close()
+
+
 def test_transfers_small_and_large_round_trip():
     r = A.Ring(1 << 16, CFG3_QS)                                 # one element = 1 MiB of int64
     rng = np.random.default_rng(5)
