@@ -1203,7 +1203,10 @@ inline int gen_threads(const GenDev<W>& G) {
     // more than 40 KiB per polynomial (H3', phi = 11520): only three workgroups fit a CU's LDS, so they are made 8 waves wide
     // (measured on H3': crt 63 -> 59 ns, mul_ 302 k -> 338 k/s; on the 36-KiB rings 512 threads change nothing, below 18 KiB they lose)
     if (bytes > 40960) return 512;
-    return bytes <= 18432 ? GEN_T_SMALL : GEN_T;
+#ifndef ALCH_GEN_SMALL_BYTES
+#define ALCH_GEN_SMALL_BYTES 18431        // round 4: a polynomial of exactly 18 KiB (phi = 4608: H0', the E' of the H1' -> H2' hop) does better on 256 threads
+#endif
+    return bytes <= ALCH_GEN_SMALL_BYTES ? GEN_T_SMALL : GEN_T;
 }
 
 template <typename W, int NT>
