@@ -220,7 +220,8 @@ class RingRoundLanes:
     scratch; same seeds, so the union of the results is word for word RingRound(batch)'s).  The op sequence of one sub-batch is a
     single dependency chain of ~130 kernels, half of them memory-bound passes or the thin last wave of a transform grid; a second
     chain fills those with its own VALU-bound transforms.  Measured on MI355X at 1024 ciphertexts (tools/bench_homomrlwr_dual.py):
-    1 lane 46.6 k pipelines/s, 2 lanes 51.8 k, 4 lanes 48.9 k, 8 lanes 48.2 k -- two is the default, as for the headline's two chunk pipelines."""
+    1 lane 46.6 k pipelines/s, 2 lanes 51.5 k, 3 lanes 52.2 k, 4 lanes 50.7 k, 6 lanes 51.5 k (each lane on a hardware queue of its own) -- flat
+    beyond two, which is the default, as for the headline's two chunk pipelines."""
 
     def __init__(self, batch, lanes=2, ring_opts=(), pow_handoff=True):
         sizes, firsts = lane_split(batch, lanes)
