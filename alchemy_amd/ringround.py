@@ -234,13 +234,9 @@ class RingRoundLanes:
     def run(self):
         """One pass over the whole batch; the result buffers of the lanes in batch order (lane i holds ciphertexts firsts[i] ...).
         The lanes' stages are issued in turn (RingRound.steps): both chains are on the device from the first stage to the last."""
-        gens = [rr.steps() for rr in self.lanes]
-        live = True
-        while live:
-            live = False
-            for g in gens:
-                if next(g, StopIteration) is not StopIteration:
-                    live = True
+        gens, done = [rr.steps() for rr in self.lanes], object()
+        while gens:
+            gens = [g for g in gens if next(g, done) is not done]      # one stage of every lane that still has one
         return [rr.result for rr in self.lanes]
 
     def sync(self):
