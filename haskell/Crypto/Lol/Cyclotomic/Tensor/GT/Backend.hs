@@ -35,13 +35,13 @@ foreign import ccall unsafe "alch_select_limbs"        c_selectLimbs     :: Ptr 
 foreign import ccall unsafe "alch_modulus_units"       c_modulusUnits    :: Word64 -> IO CInt
 foreign import ccall unsafe "alch_host_root"           c_hostRoot        :: Word32 -> Word64 -> Ptr Word64 -> Ptr Word64 -> IO CInt
 foreign import ccall unsafe "alch_ring_n"              c_ringN           :: Ptr AlchRing -> Ptr Word32 -> Ptr CInt -> Ptr CInt -> IO CInt
-foreign import ccall unsafe "alch_ring_set_stream"     c_ringSetStream   :: Ptr AlchRing -> Ptr () -> IO CInt
+foreign import ccall safe   "alch_ring_set_stream"     c_ringSetStream   :: Ptr AlchRing -> Ptr () -> IO CInt
 foreign import ccall unsafe "alch_buf_ring"            c_bufRing         :: Ptr AlchBuf -> Ptr (Ptr AlchRing) -> IO CInt
 foreign import ccall unsafe "alch_ring_device"         c_ringDevice      :: Ptr AlchRing -> Ptr CInt -> Ptr (Ptr ()) -> IO CInt
 foreign import ccall safe   "alch_ring_share_stream"   c_ringShareStream :: Ptr AlchRing -> Ptr AlchRing -> IO CInt
-foreign import ccall unsafe "alch_ring_set_option"     c_ringSetOption   :: Ptr AlchRing -> CString -> CLong -> IO CInt
+foreign import ccall safe   "alch_ring_set_option"     c_ringSetOption   :: Ptr AlchRing -> CString -> CLong -> IO CInt
 foreign import ccall safe   "alch_sync"                c_sync            :: Ptr AlchRing -> IO CInt
-foreign import ccall unsafe "alch_timer_start"         c_timerStart      :: Ptr AlchRing -> IO CInt
+foreign import ccall safe   "alch_timer_start"         c_timerStart      :: Ptr AlchRing -> IO CInt
 foreign import ccall safe   "alch_timer_stop"          c_timerStop       :: Ptr AlchRing -> Ptr CFloat -> IO CInt
 
 -- Tensor crt / crtInv (Lol: crtFuncs), zipWithT (*) (+) (-), scalar multiply: one ring element, in place
@@ -81,9 +81,10 @@ foreign import ccall safe   "alch_decompose_base2"     c_decomposeBase2  :: Ptr 
 foreign import ccall safe   "alch_buf_alloc"           c_bufAlloc        :: Ptr AlchRing -> CSize -> Ptr (Ptr AlchBuf) -> IO CInt
 foreign import ccall safe   "alch_buf_free"            c_bufFree         :: Ptr AlchBuf -> IO CInt
 -- device-resident Tensor values (GT's constructor GTDev): pooled single-element buffers, aliases, copies, the unary Tensor methods
--- out of place.  The launches return at once (asynchronous on the ring's stream): `unsafe` imports, a few microseconds each.
+-- out of place.  Everything that touches a ring takes the device lock (include/alchemy_hip.h, threading) and may wait behind another
+-- thread's call: `safe` imports; only the pure accessors below stay `unsafe`.
 foreign import ccall unsafe "alch_buf_view"            c_bufView         :: Ptr AlchBuf -> CSize -> CSize -> Ptr (Ptr AlchBuf) -> IO CInt
-foreign import ccall unsafe "alch_buf_copy"            c_bufCopy         :: Ptr AlchBuf -> CSize -> Ptr AlchBuf -> CSize -> CSize -> IO CInt
+foreign import ccall safe   "alch_buf_copy"            c_bufCopy         :: Ptr AlchBuf -> CSize -> Ptr AlchBuf -> CSize -> CSize -> IO CInt
 foreign import ccall safe   "alch_buf_tensor_op"       c_bufTensorOp     :: Ptr AlchBuf -> CSize -> Ptr AlchBuf -> CSize -> CSize -> CInt -> IO CInt
 foreign import ccall unsafe "alch_buf_elems"           c_bufElems        :: Ptr AlchBuf -> Ptr CSize -> IO CInt
 foreign import ccall unsafe "alch_buf_device_ptr"      c_bufDevicePtr    :: Ptr AlchBuf -> Ptr (Ptr ()) -> Ptr CSize -> IO CInt

@@ -61,6 +61,24 @@ def test_blocking_calls_are_safe_imports():
         assert imps[name][0] == "safe", name
 
 
+def test_unsafe_imports_are_pure_accessors_only():
+    """An `unsafe` foreign call cannot be pre-empted: it must never wait.  Since every entry point that touches a ring holds the
+    per-device lock (and may synchronise a stream), only accessors whose C body takes no lock and issues no HIP call may be `unsafe`."""
+    imps = haskell_imports()
+    unsafe = sorted(n for n, (safety, _) in imps.items() if safety == "unsafe")
+    src = ""
+    for f in ("alchemy_hip.hip", "tensor_ext.inc.hpp"):
+        src += open(os.path.join(ROOT, "alchemy_amd", "csrc", f)).read()
+    for name in unsafe:
+        m = re.search(r'^extern "C" [^\n]*\b%s\([^{]*\{(.*?)^\}' % name, src, flags=re.M | re.S)
+        if m is None:                                            # one-line definitions
+            m = re.search(r'^extern "C" [^\n]*\b%s\(.*$' % name, src, flags=re.M)
+        assert m is not None, name
+        body = m.group(0)
+        for forbidden in ("BIND(", "ALCH_DEVICE_LOCK", "hipStreamSynchronize", "hipMemcpy", "hipLaunchKernelGGL", "hipMalloc"):
+            assert forbidden not in body, f"{name} is imported unsafe but its body contains {forbidden}"
+
+
 TENSOR_METHODS = ["scalarPow", "l", "lInv", "mulGPow", "mulGDec", "divGPow", "divGDec", "crtFuncs", "tGaussianDec",
                   "gSqNormDec", "twacePowDec", "embedPow", "embedDec", "crtExtFuncs", "coeffs", "powBasisPow", "crtSetDec",
                   "fmapT", "zipWithT", "unzipT", "entailIndexT", "entailEqT", "entailZTT", "entailNFDataT",
