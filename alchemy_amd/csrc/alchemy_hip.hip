@@ -161,6 +161,9 @@ struct alch_hint {
 // ------------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 
+// element ranges of the C ABI are checked without forming first + count or 2 * batch (a huge argument must not wrap past the check)
+static inline bool range_ok(size_t first, size_t count, size_t n) { return count <= n && first <= n - count; }
+static inline bool pairs_ok(size_t batch, size_t n) { return batch <= n / 2; }
 static int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
@@ -1460,7 +1463,7 @@ static int do_crt(alch_ring* r, void* data, size_t first_elem, size_t count, boo
 
 static int buf_crt(alch_buf* b, size_t first, size_t count, bool inverse) {
     if (!b) return fail(ALCH_E_INVALID, "null buffer");
-    if (first + count > b->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
+    if (!range_ok(first, count, b->n_elems)) return fail(ALCH_E_INVALID, "element range out of bounds");
     alch_ring* r = b->ring;
     BIND(r);
     return r->word == 4 ? do_crt<u32>(r, b->dptr, first, count, inverse) : do_crt<u64>(r, b->dptr, first, count, inverse);
@@ -1504,7 +1507,7 @@ extern "C" int alch_buf_alloc(alch_ring* r, size_t n_elems, alch_buf** out) try 
 
 extern "C" int alch_buf_view(const alch_buf* parent, size_t first, size_t count, alch_buf** out) try {
     if (!parent || !out || count == 0) return fail(ALCH_E_INVALID, "alch_buf_view: bad argument");
-    if (first + count > parent->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
+    if (!range_ok(first, count, parent->n_elems)) return fail(ALCH_E_INVALID, "element range out of bounds");
     alch_buf* v = new alch_buf{parent->ring, count, reinterpret_cast<char*>(parent->dptr) + first * elem_bytes(parent->ring)};
     v->view = true;
     *out = v;
@@ -1628,13 +1631,13 @@ static int transfer(alch_ring* r, void* dev_base, size_t first, size_t count, in
 
 extern "C" int alch_buf_upload(alch_buf* b, size_t first, size_t count, const int64_t* host) try {
     if (!b || !host) return fail(ALCH_E_INVALID, "null argument");
-    if (first + count > b->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
+    if (!range_ok(first, count, b->n_elems)) return fail(ALCH_E_INVALID, "element range out of bounds");
     return transfer(b->ring, b->dptr, first, count, const_cast<int64_t*>(host), true);
 } catch (...) { return abi_catch(); }
 
 extern "C" int alch_buf_download(const alch_buf* b, size_t first, size_t count, int64_t* host) try {
     if (!b || !host) return fail(ALCH_E_INVALID, "null argument");
-    if (first + count > b->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
+    if (!range_ok(first, count, b->n_elems)) return fail(ALCH_E_INVALID, "element range out of bounds");
     return transfer(b->ring, b->dptr, first, count, host, false);
 } catch (...) { return abi_catch(); }
 
@@ -1690,7 +1693,7 @@ extern "C" int alch_buf_sub(alch_buf* d, const alch_buf* a, const alch_buf* b, s
 
 static int buf_checksum(const alch_buf* b, size_t first, size_t count, uint64_t position, uint64_t* sum) {
     if (!b || !sum) return fail(ALCH_E_INVALID, "null argument");
-    if (first + count > b->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
+    if (!range_ok(first, count, b->n_elems)) return fail(ALCH_E_INVALID, "element range out of bounds");
     alch_ring* r = b->ring;
     BIND(r);
     const size_t words = count * elem_words(r);
@@ -1912,7 +1915,7 @@ extern "C" int alch_buf_decompose_triv(const alch_buf* src, size_t src_index, al
     if (src->ring != dst->ring) return fail(ALCH_E_INVALID, "buffers belong to different rings");
     alch_ring* r = src->ring;
     BIND(r);
-    if (src_index >= src->n_elems || dst_first + (size_t)r->L > dst->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
+    if (src_index >= src->n_elems || !range_ok(dst_first, (size_t)r->L, dst->n_elems)) return fail(ALCH_E_INVALID, "element range out of bounds");
     const char* c = reinterpret_cast<const char*>(src->dptr) + src_index * elem_bytes(r);
     char* dig = reinterpret_cast<char*>(dst->dptr) + dst_first * elem_bytes(r);
     const size_t total = (size_t)r->L * elem_words(r);
@@ -1957,7 +1960,7 @@ extern "C" int alch_ct_add_public(alch_buf* dst, const alch_buf* src, size_t bat
     alch_ring* r = dst->ring;
     if (src->ring != r || pub->ring != r) return fail(ALCH_E_INVALID, "buffers belong to different rings");
     if (!r->has_crt) return fail(ALCH_E_UNSUPPORTED, "scalar products are implemented for rings with Montgomery constants (prime moduli) only");
-    if (2 * batch > dst->n_elems || 2 * batch > src->n_elems || pub_index >= pub->n_elems) return fail(ALCH_E_INVALID, "count out of bounds");
+    if (!pairs_ok(batch, dst->n_elems) || !pairs_ok(batch, src->n_elems) || pub_index >= pub->n_elems) return fail(ALCH_E_INVALID, "count out of bounds");
     if (batch == 0) return ALCH_OK;
     BIND(r);
     const size_t words = 2 * batch * elem_words(r);
@@ -2015,7 +2018,7 @@ static int columns(alch_ring* r, GenOp op, void* data, size_t first, size_t coun
 // Returns ALCH_OK, ALCH_NOT_DIVISIBLE (Lol's Nothing; the data are then unspecified) or an error.
 static int buf_mulg_divg(alch_buf* b, size_t first, size_t count, int basis, bool divide) {
     if (!b) return fail(ALCH_E_INVALID, "null buffer");
-    if (first + count > b->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
+    if (!range_ok(first, count, b->n_elems)) return fail(ALCH_E_INVALID, "element range out of bounds");
     if (basis != ALCH_BASIS_POW && basis != ALCH_BASIS_DEC && basis != ALCH_BASIS_CRT) return fail(ALCH_E_INVALID, "unknown basis");
     alch_ring* r = b->ring;
     BIND(r);
@@ -2051,7 +2054,7 @@ extern "C" int alch_buf_divg(alch_buf* b, size_t first, size_t count, int basis)
 
 static int buf_l(alch_buf* b, size_t first, size_t count, bool inverse) {
     if (!b) return fail(ALCH_E_INVALID, "null buffer");
-    if (first + count > b->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
+    if (!range_ok(first, count, b->n_elems)) return fail(ALCH_E_INVALID, "element range out of bounds");
     alch_ring* r = b->ring;
     BIND(r);
     if (!r->gen || r->gh.rad == 1) return ALCH_OK;                    // L = identity for a two-power index
@@ -2080,7 +2083,7 @@ extern "C" int alch_ring_share_stream(alch_ring* r, alch_ring* with) try {
 extern "C" int alch_buf_copy(alch_buf* dst, size_t dst_first, const alch_buf* src, size_t src_first, size_t count) try {
     if (!dst || !src) return fail(ALCH_E_INVALID, "null buffer");
     if (dst->ring != src->ring) return fail(ALCH_E_INVALID, "buffers belong to different rings");
-    if (dst_first + count > dst->n_elems || src_first + count > src->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
+    if (!range_ok(dst_first, count, dst->n_elems) || !range_ok(src_first, count, src->n_elems)) return fail(ALCH_E_INVALID, "element range out of bounds");
     if (count == 0) return ALCH_OK;
     alch_ring* r = dst->ring;
     BIND(r);
@@ -2097,7 +2100,7 @@ extern "C" int alch_buf_copy(alch_buf* dst, size_t dst_first, const alch_buf* sr
 extern "C" int alch_buf_tensor_op(alch_buf* dst, size_t dst_first, const alch_buf* src, size_t src_first, size_t count, int op) try {
     if (!dst || !src) return fail(ALCH_E_INVALID, "null buffer");
     if (dst->ring != src->ring) return fail(ALCH_E_INVALID, "buffers belong to different rings");
-    if (dst_first + count > dst->n_elems || src_first + count > src->n_elems) return fail(ALCH_E_INVALID, "element range out of bounds");
+    if (!range_ok(dst_first, count, dst->n_elems) || !range_ok(src_first, count, src->n_elems)) return fail(ALCH_E_INVALID, "element range out of bounds");
     if (op < ALCH_T_CRT || op > ALCH_T_DIVG_CRT) return fail(ALCH_E_INVALID, "alch_buf_tensor_op: unknown op");
     alch_ring* r = dst->ring;
     BIND(r);
@@ -2166,7 +2169,7 @@ extern "C" int alch_buf_add_public(alch_buf* cts, const alch_buf* pub, size_t pu
     if (!cts || !pub) return fail(ALCH_E_INVALID, "null buffer");
     alch_ring* r = cts->ring;
     if (pub->ring != r) return fail(ALCH_E_INVALID, "buffers belong to different rings");
-    if (2 * batch > cts->n_elems || pub_index >= pub->n_elems) return fail(ALCH_E_INVALID, "count out of bounds");
+    if (!pairs_ok(batch, cts->n_elems) || pub_index >= pub->n_elems) return fail(ALCH_E_INVALID, "count out of bounds");
     BIND(r);
     const size_t words = batch * elem_words(r);
     const char* pp = reinterpret_cast<const char*>(pub->dptr) + pub_index * elem_bytes(r);
@@ -2446,7 +2449,7 @@ extern "C" int alch_ct_mul_relin(alch_ring* r, const alch_hint* hint, const alch
     if (hint->ring != r || a->ring != r || b->ring != r || out->ring != r) return fail(ALCH_E_INVALID, "handles belong to different rings");
     if (batch == 0) return ALCH_OK;
     BIND(r);
-    if (a->n_elems < 2 * batch || b->n_elems < 2 * batch || out->n_elems < 2 * batch)
+    if (!pairs_ok(batch, a->n_elems) || !pairs_ok(batch, b->n_elems) || !pairs_ok(batch, out->n_elems))
         return fail(ALCH_E_INVALID, "buffers must hold 2*batch ring elements");
     if (out == a || out == b) return fail(ALCH_E_INVALID, "out must not alias an input");
     const void* pa = a->dptr;
@@ -2848,7 +2851,7 @@ static int mul_full_base2(const alch_hint* hint, const alch_buf* a, const alch_b
     if (flags & ~(unsigned)ALCH_POW_OUT) return fail(ALCH_E_UNSUPPORTED, "only ALCH_POW_OUT is accepted");
     if (!rh->has_crt) return fail(ALCH_E_NO_CRT, "the hint's ring has no CRT basis");
     if (batch == 0) return ALCH_OK;
-    if (a->n_elems < 2 * batch || b->n_elems < 2 * batch || out->n_elems < 2 * batch) return fail(ALCH_E_INVALID, "buffers must hold 2*batch ring elements");
+    if (!pairs_ok(batch, a->n_elems) || !pairs_ok(batch, b->n_elems) || !pairs_ok(batch, out->n_elems)) return fail(ALCH_E_INVALID, "buffers must hold 2*batch ring elements");
     BIND(rh);
     const int dup = in_down ? 0 : rh->L - rin->L;
     alch_buf *ua = nullptr, *ub = nullptr, *ks = nullptr, *c2h = nullptr;
@@ -2916,7 +2919,7 @@ extern "C" int alch_ct_mul_full(const alch_hint* hint, const alch_buf* a, const 
     if (flags & ~(unsigned)ALCH_POW_OUT) return fail(ALCH_E_UNSUPPORTED, "only ALCH_POW_OUT is accepted");
     if (batch == 0) return ALCH_OK;
     BIND(rh);
-    if (a->n_elems < 2 * batch || b->n_elems < 2 * batch || out->n_elems < 2 * batch)
+    if (!pairs_ok(batch, a->n_elems) || !pairs_ok(batch, b->n_elems) || !pairs_ok(batch, out->n_elems))
         return fail(ALCH_E_INVALID, "buffers must hold 2*batch ring elements");
     if (!rh->ev_x) HIP_TRY(hipEventCreateWithFlags(&rh->ev_x, hipEventDisableTiming));
     if (rin->stream != rh->stream) {
@@ -3189,7 +3192,7 @@ extern "C" int alch_ct_tunnel(const alch_tunnel* t, const alch_buf* in, alch_buf
         return fail(ALCH_E_INVALID, "input / output buffers must belong to the tunnel's rings (the input may live on the last limbs of the R' ring)");
     if (flags & ~(unsigned)(ALCH_POW_IN | ALCH_POW_OUT)) return fail(ALCH_E_INVALID, "unknown flag");
     if (batch == 0) return ALCH_OK;
-    if (in->n_elems < 2 * batch || out->n_elems < 2 * batch) return fail(ALCH_E_INVALID, "buffers must hold 2*batch ring elements");
+    if (!pairs_ok(batch, in->n_elems) || !pairs_ok(batch, out->n_elems)) return fail(ALCH_E_INVALID, "buffers must hold 2*batch ring elements");
     alch_ring* rs = t->rs;
     alch_ring* rr = t->rr;
     BIND(rs);
@@ -3323,7 +3326,7 @@ extern "C" int alch_ct_mod_switch(const alch_buf* in, alch_buf* out, size_t batc
     if (rin->L == rout->L || !(up ? is_suffix_ring(rin, rout) : is_suffix_ring(rout, rin)))
         return fail(ALCH_E_INVALID, "the smaller ring's moduli must be the last limbs of the bigger ring's (same index and word size)");
     if (batch == 0) return ALCH_OK;
-    if (in->n_elems < 2 * batch || out->n_elems < 2 * batch) return fail(ALCH_E_INVALID, "buffers must hold 2*batch ring elements");
+    if (!pairs_ok(batch, in->n_elems) || !pairs_ok(batch, out->n_elems)) return fail(ALCH_E_INVALID, "buffers must hold 2*batch ring elements");
     alch_ring* rw = up ? rout : rin;                          // the ring whose stream carries the work
     alch_ring* ro = up ? rin : rout;
     BIND(rw);

@@ -116,7 +116,7 @@ extern "C" int alch_hint_broadcast(alch_comm* c, int root, alch_buf* const* bufs
     int rc = resolve(c, bufs, "alch_hint_broadcast", b);
     if (rc != ALCH_OK) return rc;
     if (root < 0 || root >= c->n) return fail(ALCH_E_INVALID, "alch_hint_broadcast: root out of range");
-    for (auto& x : b) if (first + count > x.elems) return fail(ALCH_E_INVALID, "alch_hint_broadcast: element range out of bounds");
+    for (auto& x : b) if (count > x.elems || first > x.elems - count) return fail(ALCH_E_INVALID, "alch_hint_broadcast: element range out of bounds");
     if (count == 0) return ALCH_OK;
     const size_t bytes = count * b[0].elem_bytes, off = first * b[0].elem_bytes;
     NCCL_TRY(ncclGroupStart());
@@ -135,8 +135,8 @@ extern "C" int alch_buf_all_gather(alch_comm* c, alch_buf* const* src, size_t fi
     if ((rc = resolve(c, dst, "alch_buf_all_gather (dst)", d)) != ALCH_OK) return rc;
     if (s[0].elem_bytes != d[0].elem_bytes) return fail(ALCH_E_INVALID, "alch_buf_all_gather: source and destination rings differ");
     for (int r = 0; r < c->n; ++r) {
-        if (first + count > s[(size_t)r].elems) return fail(ALCH_E_INVALID, "alch_buf_all_gather: source range out of bounds");
-        if ((size_t)c->n * count > d[(size_t)r].elems) return fail(ALCH_E_INVALID, "alch_buf_all_gather: dst must hold n_dev * count elements");
+        if (count > s[(size_t)r].elems || first > s[(size_t)r].elems - count) return fail(ALCH_E_INVALID, "alch_buf_all_gather: source range out of bounds");
+        if (count > d[(size_t)r].elems / (size_t)c->n) return fail(ALCH_E_INVALID, "alch_buf_all_gather: dst must hold n_dev * count elements");
         if (s[(size_t)r].stream != d[(size_t)r].stream)
             return fail(ALCH_E_INVALID, "alch_buf_all_gather: a rank's source and destination rings must share a stream (the same ring, or alch_ring_share_stream)");
     }

@@ -216,7 +216,7 @@ extern "C" int alch_buf_coeffs(alch_buf* dst, const alch_buf* src, size_t count)
     const ExtTab* t = nullptr;
     int rc = ext_tables(small, big, &t);
     if (rc != ALCH_OK) return rc;
-    if (count > src->n_elems || count * (size_t)t->d_rel > dst->n_elems) return fail(ALCH_E_INVALID, "dst must hold d_rel * count elements");
+    if (count > src->n_elems || count > dst->n_elems / (size_t)t->d_rel) return fail(ALCH_E_INVALID, "dst must hold d_rel * count elements");
     if (count == 0) return ALCH_OK;
     BIND(small);
     if ((rc = ext_order(small, big, true)) != ALCH_OK) return rc;

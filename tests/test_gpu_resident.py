@@ -104,6 +104,26 @@ def test_views_and_copies():
         one.copy_from(big, 2)
 
 
+def test_element_ranges_that_wrap_size_t_are_refused():
+    """first + count and 2 * batch are never formed by the range checks: an argument near 2^64 that would wrap past a naive
+    `first + count > n_elems` test is ALCH_E_INVALID, and nothing reaches the device (the data are unchanged afterwards)."""
+    import ctypes as C
+    r = A.Ring(2912 * 4, RLWR_QS[:3])
+    rng = np.random.default_rng(3)
+    xs = rand_elems(rng, 4, r.n, r.qs)
+    a, b = r.upload(xs), r.upload(xs)
+    l, huge, half = capi.load_library(), 2**64 - 1, 2**63 + 1                # huge + 2 = 1, 2 * half = 2 (mod 2^64)
+    cs = C.c_uint64()
+    for rc in (l.alch_buf_crt(a._h, huge, 2), l.alch_buf_crtinv(a._h, huge, 2), l.alch_buf_checksum(a._h, huge, 2, C.byref(cs)),
+               l.alch_buf_copy(a._h, huge, b._h, 0, 2), l.alch_buf_copy(a._h, 0, b._h, huge, 2),
+               l.alch_buf_tensor_op(a._h, huge, b._h, 0, 2, capi.ALCH_T_CRT), l.alch_buf_tensor_op(a._h, 0, b._h, huge, 2, capi.ALCH_T_CRT),
+               l.alch_ct_mod_switch(a._h, b._h, half, 0)):
+        assert rc == capi.ALCH_E_INVALID, rc
+    v = C.c_void_p()
+    assert l.alch_buf_view(a._h, huge, 2, C.byref(v)) == capi.ALCH_E_INVALID
+    assert np.array_equal(a.download(), xs) and np.array_equal(b.download(), xs)
+
+
 def test_recycled_buffers_are_ordered_on_the_stream(oracle_lib):
     """alloc / op / free chains without any synchronisation: a freed element may be handed out again while the kernel that reads it
     is still queued -- the next writer is queued behind it on the same stream, so results never change."""

@@ -91,6 +91,9 @@ def test_one_rank_collectives_through_rccl(rccl):
     assert rccl.alch_hint_broadcast(comm, 1, bufs, 0, 1) == capi.ALCH_E_INVALID              # root out of range
     assert rccl.alch_hint_broadcast(comm, 0, bufs, 5, 2) == capi.ALCH_E_INVALID              # range out of bounds
     assert rccl.alch_buf_all_gather(comm, bufs, 0, 5, dsts) == capi.ALCH_E_INVALID           # dst too small
+    big = C.c_size_t(2**64 - 1)
+    assert rccl.alch_hint_broadcast(comm, 0, bufs, big, 2) == capi.ALCH_E_INVALID            # first + count wraps: still out of bounds
+    assert rccl.alch_buf_all_gather(comm, bufs, big, 2, dsts) == capi.ALCH_E_INVALID
     other = A.Ring(11648, [1543651201, 689270401])
     ob = other.alloc(4)
     assert rccl.alch_buf_all_gather(comm, bufs, 0, 1, (C.c_void_p * 1)(ob._h)) == capi.ALCH_E_INVALID   # different rings
