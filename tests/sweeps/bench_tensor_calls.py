@@ -5,7 +5,7 @@ representations:
             asynchronous launch, the stream is synchronised once after the timed calls
 next to the CPU restatement (oracle/lol_tensor*.c: the Lol-like scalar algorithm, one thread) on the same element.
 Rings: H0' = F11648 with five HomomRLWR moduli (the first hop's ciphertext ring) and n = 2^15 with the four config-3 moduli.
-One JSON line per ring.  Run on the GPU box:  python tools/bench_tensor_calls.py"""
+One JSON line per ring.  Run on the GPU box:  python tests/sweeps/bench_tensor_calls.py"""
 import json
 import os
 import sys
@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch  # noqa: F401,E402  (one HIP runtime per process: before the library)
 import alchemy_amd as A  # noqa: E402
 from alchemy_amd import capi  # noqa: E402

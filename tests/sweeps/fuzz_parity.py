@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU box: alch_ct_mul_relin and alch_ct_mul_full on two-power rings of random size, limb count, moduli
 class (31-bit, below 2^30), gadget (TrivGad; BaseBGad 2 at small sizes, hint at, above or below the operands' limb count), batch and launch options, every result word compared with the C restatement (oracle/ is the checker, as in
-tests/).  usage: tools/fuzz_parity.py [seconds] [seed]   -- prints one line per case class and a final tally; exits non-zero on a mismatch."""
+tests/).  usage: tests/sweeps/fuzz_parity.py [seconds] [seed]   -- prints one line per case class and a final tally; exits non-zero on a mismatch."""
 import os, random, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import alchemy_amd as A

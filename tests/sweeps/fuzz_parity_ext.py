@@ -2,9 +2,9 @@
 """Randomised sweep of the Tensor methods between two rings m | m' (embedPow / embedDec / embedCRT, twacePowDec / twaceCRT, coeffs) on
 random divisor pairs (phi(m') <= 400: the checker is the by-definition Python model, oracle/model_gen.py) and two moduli = 1 mod m',
 plus the identities crt . embedPow = embedCRT . crt and crt . twacePowDec = twaceCRT . crt through the library's own crt.
-usage: tools/fuzz_parity_ext.py [seconds] [seed]"""
+usage: tests/sweeps/fuzz_parity_ext.py [seconds] [seed]"""
 import os, random, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import alchemy_amd as A

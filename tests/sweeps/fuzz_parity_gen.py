@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on general cyclotomic indices: alch_ct_mul_relin (TrivGad), alch_ct_mul_full (TrivGad) and alch_ct_mod_switch
 on random indices m = 2^a 3^b 5^c 7^d 13^e with phi(m) <= 3000, random 1..5 moduli = 1 mod m (29..31 bits), random batches and launch
-options (gen_fused, gen_nt, rs_lin), every result word compared with the general C restatement.  usage: tools/fuzz_parity_gen.py [seconds] [seed]"""
+options (gen_fused, gen_nt, rs_lin), every result word compared with the general C restatement.  usage: tests/sweeps/fuzz_parity_gen.py [seconds] [seed]"""
 import os, random, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import alchemy_amd as A

@@ -2,9 +2,9 @@
 """Randomised parity sweep of the per-element Tensor methods the Haskell instance binds (host buffers through the C ABI): crt, crtInv,
 mulGPow / mulGDec / mulGCRT, divGPow / divGDec / divGCRT (with Lol's Nothing), l, lInv, zipWithT (*) / (+) / (-), on random indices
 (two-power and 2^a 3^b 5^c 7^d 13^e, phi <= 4000) and 1..4 moduli = 1 mod m, against the C restatements; crtInv . crt = id, divG . mulG = id
-and l . lInv = id are checked on the way.  usage: tools/fuzz_parity_tensor.py [seconds] [seed]"""
+and l . lInv = id are checked on the way.  usage: tests/sweeps/fuzz_parity_tensor.py [seconds] [seed]"""
 import os, random, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import alchemy_amd as A

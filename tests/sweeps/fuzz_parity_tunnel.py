@@ -2,9 +2,9 @@
 """Randomised parity sweep of alch_ct_tunnel: random index pairs (r', s') with lcm <= 60000 and phi <= 3000 that satisfy Lol's tunnel
 conditions (alch_tunnel_info decides), 1..4 moduli = 1 mod lcm(r', s'), TrivGad or BaseBGad 2 hints, random linear functions, hints,
 ciphertexts, encoding scalars, tunnel_ep / tunnel_fused options and the Pow-basis-out flag, against the C restatement's composition
-(tests/helpers.py::oracle_tunnel -- the checker of the tunnel tests).  usage: tools/fuzz_parity_tunnel.py [seconds] [seed]"""
+(tests/helpers.py::oracle_tunnel -- the checker of the tunnel tests).  usage: tests/sweeps/fuzz_parity_tunnel.py [seconds] [seed]"""
 import math, os, random, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import alchemy_amd as A

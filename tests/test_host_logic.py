@@ -48,6 +48,26 @@ def test_library_links_no_oracle_code():
                     assert "oracle" not in st and "lol_tensor" not in st, (f, st)
 
 
+def test_only_tests_smoke_and_bench_use_the_oracle():
+    """oracle/ is test infrastructure: outside oracle/ itself, only tests/, __graft_entry__.py and bench.py may import it or load
+    its library; tools/ and examples/ (measurement and replay programs of the product) must not."""
+    allowed = {os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")}
+    skip = {os.path.join(ROOT, d) for d in ("tests", "oracle", "gpurun_out", ".git", "docs", "profiles")}
+    offenders = []
+    for dirpath, dirs, files in os.walk(ROOT):
+        dirs[:] = [d for d in dirs if os.path.join(dirpath, d) not in skip and d != "__pycache__"]
+        for f in files:
+            path = os.path.join(dirpath, f)
+            if path in allowed or not f.endswith((".py", ".sh", ".cpp", ".hpp", ".hip", ".h", ".c")):
+                continue
+            for line in open(path, errors="replace"):
+                st = line.strip()
+                if st.startswith(("import oracle", "from oracle")) or (st.startswith("#include") and ("oracle/" in st or "lol_tensor" in st)) \
+                        or "liblol_oracle" in st:
+                    offenders.append((os.path.relpath(path, ROOT), st))
+    assert not offenders, offenders
+
+
 @pytest.mark.parametrize("m,q", [(32, ARITH_QS[0]), (512, ARITH_QS[1]), (512, ARITH_QS[2]), (1 << 16, CFG3_QS[0]),
                                  (1 << 16, CFG3_QS[3]), (1 << 15, CFG2_Q60), (4096, 12289), (1 << 16, 65537)])
 def test_root_rule_matches_oracle(oracle_lib, m, q):
