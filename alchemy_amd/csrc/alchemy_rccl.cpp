@@ -1,9 +1,12 @@
 // libalchemy_rccl.so -- RCCL collectives on the library's device buffers (include/alchemy_rccl.h).
 // Uses only the public C ABI of libalchemy_hip.so (alch_buf_device_ptr, alch_buf_ring, alch_ring_device, alch_ring_n,
-// alch_buf_elems), the HIP runtime and RCCL.  One process, rank r = device r, group calls from the calling thread.
+// alch_buf_elems), the HIP runtime and RCCL.  Two launch models share the collectives: ONE process over devices 0 .. n-1
+// (alch_comm_init_all: rank r = device r, group calls from the calling thread) and ONE PROCESS PER GPU (alch_comm_init_rank: the
+// process holds one rank on its current device; the 128-byte id of alch_comm_unique_id travels over the host's own channel).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstring>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -12,9 +15,13 @@
 #include "../../include/alchemy_rccl.h"
 
 struct alch_comm {
-    int n = 0;
-    std::vector<ncclComm_t> comms;
+    int n = 0;                          // ranks of the communicator (all processes)
+    std::vector<ncclComm_t> comms;      // one per LOCAL rank
+    std::vector<int> ranks;             // local rank i is rank ranks[i] ...
+    std::vector<int> devices;           // ... and lives on HIP device devices[i]
+    int n_local() const { return (int)comms.size(); }
 };
+static_assert(ALCH_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the id handed between processes is RCCL's ncclUniqueId");
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -52,11 +59,47 @@ extern "C" int alch_comm_init_all(int n_dev, alch_comm** out) try {
     alch_comm* c = new alch_comm();
     c->n = n_dev;
     c->comms.resize((size_t)n_dev);
-    std::vector<int> devs((size_t)n_dev);
-    for (int r = 0; r < n_dev; ++r) devs[(size_t)r] = r;
-    ncclResult_t rc = ncclCommInitAll(c->comms.data(), n_dev, devs.data());
+    c->ranks.resize((size_t)n_dev);
+    c->devices.resize((size_t)n_dev);
+    for (int r = 0; r < n_dev; ++r) c->ranks[(size_t)r] = c->devices[(size_t)r] = r;
+    ncclResult_t rc = ncclCommInitAll(c->comms.data(), n_dev, c->devices.data());
     if (rc != ncclSuccess) { delete c; return fail(ALCH_E_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(rc)); }
     *out = c;
+    return ALCH_OK;
+} catch (...) { return abi_catch(); }
+
+extern "C" int alch_comm_unique_id(unsigned char* id) try {
+    if (!id) return fail(ALCH_E_INVALID, "alch_comm_unique_id: null id");
+    ncclUniqueId u;
+    NCCL_TRY(ncclGetUniqueId(&u));
+    std::memcpy(id, u.internal, ALCH_COMM_ID_BYTES);
+    return ALCH_OK;
+} catch (...) { return abi_catch(); }
+
+extern "C" int alch_comm_init_rank(int n_ranks, int rank, const unsigned char* id, alch_comm** out) try {
+    if (!out) return fail(ALCH_E_INVALID, "alch_comm_init_rank: null out");
+    *out = nullptr;
+    if (!id) return fail(ALCH_E_INVALID, "alch_comm_init_rank: null id");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(ALCH_E_INVALID, "alch_comm_init_rank: need 0 <= rank < n_ranks");
+    int visible = 0, dev = -1;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible < 1 || hipGetDevice(&dev) != hipSuccess) return fail(ALCH_E_NO_DEVICE, "no HIP device");
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, ALCH_COMM_ID_BYTES);
+    alch_comm* c = new alch_comm();
+    c->n = n_ranks;
+    c->comms.resize(1);
+    c->ranks.assign(1, rank);
+    c->devices.assign(1, dev);
+    ncclResult_t rc = ncclCommInitRank(c->comms.data(), n_ranks, u, rank);      // blocks until all n_ranks processes have called it
+    if (rc != ncclSuccess) { delete c; return fail(ALCH_E_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(rc)); }
+    *out = c;
+    return ALCH_OK;
+} catch (...) { return abi_catch(); }
+
+extern "C" int alch_comm_local(const alch_comm* c, int* n_local, int* first_rank) try {
+    if (!c || !n_local || !first_rank) return fail(ALCH_E_INVALID, "null argument");
+    *n_local = c->n_local();
+    *first_rank = c->ranks[0];
     return ALCH_OK;
 } catch (...) { return abi_catch(); }
 
@@ -84,8 +127,8 @@ struct RankBuf {
 // Resolves one buffer per rank and checks that rank r's buffer lives on device r and that all rings have one element size.
 int resolve(const alch_comm* c, alch_buf* const* bufs, const char* what, std::vector<RankBuf>& out) {
     if (!c || !bufs) return fail(ALCH_E_INVALID, std::string(what) + ": null argument");
-    out.resize((size_t)c->n);
-    for (int r = 0; r < c->n; ++r) {
+    out.resize((size_t)c->n_local());
+    for (int r = 0; r < c->n_local(); ++r) {
         if (!bufs[r]) return fail(ALCH_E_INVALID, std::string(what) + ": null buffer for rank " + std::to_string(r));
         alch_ring* ring = nullptr;
         void* p = nullptr;
@@ -102,9 +145,9 @@ int resolve(const alch_comm* c, alch_buf* const* bufs, const char* what, std::ve
         b.elems = elems;
         b.elem_bytes = (size_t)n * (size_t)L * (size_t)word;
         b.stream = static_cast<hipStream_t>(stream);
-        if (b.device != r)
-            return fail(ALCH_E_INVALID, std::string(what) + ": the buffer of rank " + std::to_string(r) + " lives on device " + std::to_string(b.device) +
-                                            " (rank r = device r: create that rank's rings with device r current)");
+        if (b.device != c->devices[(size_t)r])
+            return fail(ALCH_E_INVALID, std::string(what) + ": the buffer of rank " + std::to_string(c->ranks[(size_t)r]) + " lives on device " + std::to_string(b.device) +
+                                            ", its rank on device " + std::to_string(c->devices[(size_t)r]) + " (create that rank's rings with its device current)");
         if (b.elem_bytes != out[0].elem_bytes) return fail(ALCH_E_INVALID, std::string(what) + ": the ranks' rings differ in dimension, limbs or word size");
     }
     return ALCH_OK;
@@ -120,8 +163,8 @@ extern "C" int alch_hint_broadcast(alch_comm* c, int root, alch_buf* const* bufs
     if (count == 0) return ALCH_OK;
     const size_t bytes = count * b[0].elem_bytes, off = first * b[0].elem_bytes;
     NCCL_TRY(ncclGroupStart());
-    for (int r = 0; r < c->n; ++r) {
-        ncclResult_t e = ncclBroadcast(b[(size_t)root].ptr + off, b[(size_t)r].ptr + off, bytes, ncclChar, root, c->comms[(size_t)r], b[(size_t)r].stream);
+    for (int r = 0; r < c->n_local(); ++r) {      // in place on every rank: the root sends what it holds, the others' send buffers are not read
+        ncclResult_t e = ncclBroadcast(b[(size_t)r].ptr + off, b[(size_t)r].ptr + off, bytes, ncclChar, root, c->comms[(size_t)r], b[(size_t)r].stream);
         if (e != ncclSuccess) { (void)ncclGroupEnd(); return fail(ALCH_E_HIP, std::string("ncclBroadcast: ") + ncclGetErrorString(e)); }
     }
     NCCL_TRY(ncclGroupEnd());
@@ -134,7 +177,7 @@ extern "C" int alch_buf_all_gather(alch_comm* c, alch_buf* const* src, size_t fi
     if (rc != ALCH_OK) return rc;
     if ((rc = resolve(c, dst, "alch_buf_all_gather (dst)", d)) != ALCH_OK) return rc;
     if (s[0].elem_bytes != d[0].elem_bytes) return fail(ALCH_E_INVALID, "alch_buf_all_gather: source and destination rings differ");
-    for (int r = 0; r < c->n; ++r) {
+    for (int r = 0; r < c->n_local(); ++r) {
         if (count > s[(size_t)r].elems || first > s[(size_t)r].elems - count) return fail(ALCH_E_INVALID, "alch_buf_all_gather: source range out of bounds");
         if (count > d[(size_t)r].elems / (size_t)c->n) return fail(ALCH_E_INVALID, "alch_buf_all_gather: dst must hold n_dev * count elements");
         if (s[(size_t)r].stream != d[(size_t)r].stream)
@@ -143,7 +186,7 @@ extern "C" int alch_buf_all_gather(alch_comm* c, alch_buf* const* src, size_t fi
     if (count == 0) return ALCH_OK;
     const size_t bytes = count * s[0].elem_bytes, off = first * s[0].elem_bytes;
     NCCL_TRY(ncclGroupStart());
-    for (int r = 0; r < c->n; ++r) {
+    for (int r = 0; r < c->n_local(); ++r) {
         ncclResult_t e = ncclAllGather(s[(size_t)r].ptr + off, d[(size_t)r].ptr, bytes, ncclChar, c->comms[(size_t)r], s[(size_t)r].stream);
         if (e != ncclSuccess) { (void)ncclGroupEnd(); return fail(ALCH_E_HIP, std::string("ncclAllGather: ") + ncclGetErrorString(e)); }
     }
