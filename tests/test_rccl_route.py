@@ -157,6 +157,12 @@ def test_one_process_per_gpu_communicator_with_one_rank(rccl, tmp_path):
     assert d["n_gpus"] == 1 and d["ranks_in_this_process"] == 1 and d["first_rank"] == 0
     assert d["shard_checksums_ok"] == [True] and d["all_gather_slices_ok"] == [True] and d["ciphertexts_checked_per_shard"] == 64
     assert os.path.getsize(tmp_path / "rccl_id") == ID_BYTES
+    # the launcher a native host would use for N processes (here N = 1: the box has one GPU)
+    out = subprocess.run([os.path.join(ROOT, "tools", "launch_ringround_ranks.sh"), "1", "--batch", "32", "--gather", "2", "--passes", "1"],
+                         capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["shard_checksums_ok"] == [True] and d["all_gather_slices_ok"] == [True]
 
 
 @pytest.mark.gpu

@@ -1,0 +1,23 @@
+#!/bin/bash
+# One process per GPU without Python: starts N copies of examples/ringround_multi (rank r on device r), which meet through RCCL
+# (alch_comm_unique_id -> a file -> alch_comm_init_rank; include/alchemy_rccl.h).  Prints every rank's JSON line; exit status 0 only
+# when every rank's checks passed.   usage: tools/launch_ringround_ranks.sh N [--batch B] [--passes K] [--gather G] [--lanes S]
+set -u
+N=${1:-1}; shift || true
+root="$(cd "$(dirname "$0")/.." && pwd)"
+cd "$root"
+[ -x examples/ringround_multi ] || tools/build_examples.sh
+dir=$(mktemp -d /tmp/alch_ranks.XXXXXX)
+pids=()
+for r in $(seq 0 $((N - 1))); do
+    ./examples/ringround_multi --world "$N" --rank "$r" --device "$r" --id-file "$dir/id" "$@" > "$dir/rank_$r.json" 2> "$dir/rank_$r.err" &
+    pids+=($!)
+done
+rc=0
+for r in $(seq 0 $((N - 1))); do
+    wait "${pids[$r]}" || rc=1
+    cat "$dir/rank_$r.json"
+    [ -s "$dir/rank_$r.err" ] && sed "s/^/rank $r: /" "$dir/rank_$r.err" >&2
+done
+rm -rf "$dir"
+exit $rc
