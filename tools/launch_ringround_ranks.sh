@@ -14,8 +14,16 @@ for r in $(seq 0 $((N - 1))); do
     pids+=($!)
 done
 rc=0
+# a rank that fails before or inside a collective would leave its peers waiting in RCCL for ever: the first failure ends them all
+left=$N
+while [ "$left" -gt 0 ]; do
+    if wait -n; then :; else
+        rc=1
+        for p in "${pids[@]}"; do kill "$p" 2> /dev/null; done
+    fi
+    left=$((left - 1))
+done
 for r in $(seq 0 $((N - 1))); do
-    wait "${pids[$r]}" || rc=1
     cat "$dir/rank_$r.json"
     [ -s "$dir/rank_$r.err" ] && sed "s/^/rank $r: /" "$dir/rank_$r.err" >&2
 done
