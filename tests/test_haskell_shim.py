@@ -54,6 +54,37 @@ def test_every_entry_point_is_imported_with_the_header_signature():
         assert sig[:-1] == [CTYPE[p] for p in params], (name, sig[:-1], params)
 
 
+def test_rccl_module_imports_every_entry_point_of_its_header():
+    """haskell/.../GT/Rccl.hs against include/alchemy_rccl.h: same mechanical check (name, arity, types), every import safe (each of
+    these calls can block on RCCL), and the id size equals the header's ALCH_COMM_ID_BYTES."""
+    ctype = dict(CTYPE)
+    ctype.update({"alch_comm*": "Ptr AlchComm", "alch_comm**": "Ptr (Ptr AlchComm)", "unsigned char*": "Ptr Word8", "alch_buf**": "Ptr (Ptr AlchBuf)"})
+    text = open(os.path.join(ROOT, "include", "alchemy_rccl.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for ret, star, name, args in re.findall(r"^((?:const\s+)?\w+)\s*(\*?)\s*(alch_\w+)\s*\(([^)]*)\)\s*;", text, flags=re.M):
+        params = []
+        for a in [x.strip() for x in args.replace("\n", " ").split(",")]:
+            if a == "void" or not a:
+                continue
+            a = re.sub(r"\*\s+\*", "**", re.sub(r"\bconst\b", "", a)).strip()
+            m = re.match(r"((?:unsigned\s+)?\w+)\s*(\**)\s*\w+$", a)
+            assert m, (name, a)
+            params.append(m.group(1) + m.group(2))
+        protos[name] = ((ret + star).replace("  ", " "), params)
+    hs = open(os.path.join(ROOT, "haskell", "Crypto", "Lol", "Cyclotomic", "Tensor", "GT", "Rccl.hs")).read()
+    imps = {}
+    for safety, cname, sig in re.findall(r'^foreign import ccall (safe|unsafe)\s+"(\w+)"\s+\w+\s*::\s*(.+)$', hs, flags=re.M):
+        assert cname not in imps and safety == "safe", cname
+        imps[cname] = [t.strip() for t in sig.split("->")]
+    assert len(protos) == 9 and set(imps) == set(protos), (sorted(set(protos) ^ set(imps)))
+    for name, (ret, params) in protos.items():
+        assert imps[name][-1] == RET[ret], (name, imps[name][-1], ret)
+        assert imps[name][:-1] == [ctype[p] for p in params], (name, imps[name][:-1], params)
+    n = re.search(r"#define ALCH_COMM_ID_BYTES (\d+)", open(os.path.join(ROOT, "include", "alchemy_rccl.h")).read()).group(1)
+    assert re.search(r"^commIdBytes = " + n + r"$", hs, flags=re.M)
+
+
 def test_blocking_calls_are_safe_imports():
     imps = haskell_imports()
     for name in ("alch_ct_mul_relin", "alch_ct_mul_full", "alch_sync", "alch_buf_upload", "alch_buf_download",
